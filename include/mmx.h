@@ -1,0 +1,169 @@
+/*
+ * mmx.h -- C ABI of libmmx.so: MI355X (gfx950) chromatin force field + L-BFGS minimizer.
+ *
+ * This is the drop-in boundary for the one path MultiMM obtains from OpenMM in
+ * MultiMM.min_energy() (reference: src/multimm/model.py:859-897) for the force terms that
+ * MultiMM.add_forcefield() installs (model.py:812-857).  Every entry point names the reference
+ * call sites it replaces.  Plain pointers and sizes only; no C++/torch types cross the ABI.
+ *
+ * Conventions
+ *   - Units: nm, kJ/mol, rad (OpenMM's defaults, i.e. what the reference's bare floats mean).
+ *   - Every function returns int: MMX_OK (0) or a negative MMX_ERR_* class; nothing throws or
+ *     aborts across the ABI.  mmx_last_error(h) gives the message of the last failure.
+ *   - The caller owns all input buffers (host memory); the library copies before returning.
+ *     Output buffers are caller-allocated host memory.
+ *   - A handle is bound to one GPU and one HIP stream; it is not thread-safe.  Distinct handles
+ *     (same or different GPUs) may be driven from distinct host threads/processes.
+ *   - There is no CPU fallback: if no gfx950 device is usable mmx_create fails with MMX_ERR_HIP.
+ */
+#ifndef MMX_H
+#define MMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMX_OK 0
+#define MMX_ERR_BAD_ARG (-1)
+#define MMX_ERR_HIP (-2)
+#define MMX_ERR_RCCL (-3)
+#define MMX_ERR_NAN (-4)   /* non-finite energy met by the minimizer / compute */
+#define MMX_ERR_STATE (-5) /* call made in the wrong order (e.g. compute before set_positions) */
+
+/* Energy-term slots of mmx_compute()/mmx_stats (order of model.py:812-857 collapsed on kernels). */
+enum {
+    MMX_T_EV = 0,        /* add_evforce               model.py:164-217 */
+    MMX_T_GAUSS = 1,     /* add_compartment_blocks + add_subcompartment_blocks  model.py:219-384 */
+    MMX_T_BOND = 2,      /* add_harmonic_bonds        model.py:625-636 */
+    MMX_T_ANGLE = 3,     /* add_stiffness             model.py:708-720 */
+    MMX_T_LOOP = 4,      /* add_loops (harmonic)      model.py:638-659 */
+    MMX_T_CONTAINER = 5, /* add_spherical_container   model.py:453-466 */
+    MMX_T_LAMINA = 6,    /* add_Blamina_interaction   model.py:468-507 */
+    MMX_T_CENTRAL = 7,   /* add_central_force         model.py:552-623 */
+    MMX_N_TERMS = 8
+};
+
+/* Kernel slots of mmx_stats.kernel_* and mmx_time_kernel(). */
+enum {
+    MMX_K_CELL_BUILD = 0, /* K1: bbox + cell hash + count + scan + fill + in-cell order */
+    MMX_K_NONBONDED = 1,  /* K2: cell-list pair kernel (or K2x all-pairs when cutoff <= 0) */
+    MMX_K_BACKBONE = 2,   /* K3: bonds + angles */
+    MMX_K_LOOPS = 3,      /* K4: loop restraints */
+    MMX_K_CONFINE = 4,    /* K5: container + lamina + central */
+    MMX_K_LBFGS = 5,      /* K6: all L-BFGS vector kernels of one accepted iteration */
+    MMX_K_REDUCE = 6,     /* energy/dot reductions + line-search controller */
+    MMX_N_KERNELS = 8
+};
+
+/* mmx_set_compartments() modes */
+#define MMX_COMP_COB 0 /* E[2] = {Ea, Eb}:            model.py:246-253 */
+#define MMX_COMP_SCB 1 /* E[4] = {Ea1, Ea2, Eb1, Eb2}: model.py:322-333 */
+
+/* mmx_stats.status */
+#define MMX_MIN_CONVERGED 0
+#define MMX_MIN_MAX_ITERATIONS 1
+#define MMX_MIN_LS_INCREASE_GRADIENT (-2) /* liblbfgs LBFGSERR_INCREASEGRADIENT */
+#define MMX_MIN_LS_MIN_STEP (-3)
+#define MMX_MIN_LS_MAX_STEP (-4)
+#define MMX_MIN_LS_MAX_LINESEARCH (-5)
+#define MMX_MIN_NAN (-6)
+
+typedef struct mmx_handle_s *mmx_handle;
+
+typedef struct {
+    int32_t iterations;  /* accepted L-BFGS iterations */
+    int32_t evaluations; /* energy+force evaluations */
+    int32_t status;      /* MMX_MIN_* */
+    int32_t n_beads;
+    double e_initial, e_final;
+    double gnorm_final; /* ||grad||_2 over 3N */
+    double xnorm_final; /* max(1, ||x||_2) */
+    double rms_force;   /* gnorm / sqrt(N), kJ/mol/nm */
+    double seconds;     /* wall time of the call */
+    double energy_terms[MMX_N_TERMS]; /* at the final point */
+    /* Live per-kernel HIP-event timing (only filled when option "profile" > 0). */
+    double kernel_ns[MMX_N_KERNELS];     /* summed event-measured duration of sampled launches */
+    int64_t kernel_samples[MMX_N_KERNELS]; /* number of sampled launches behind kernel_ns */
+    int64_t kernel_launches[MMX_N_KERNELS];/* launches issued during the call */
+} mmx_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* Replaces: Platform.getPlatformByName + Simulation(...) context creation, model.py:863-876. */
+int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out);
+int mmx_destroy(mmx_handle h);
+/* Message of the last error on h (h == NULL: last error of a failed mmx_create on this thread). */
+const char *mmx_last_error(mmx_handle h);
+/* Library/ABI version, for loaders. */
+int mmx_abi_version(void);
+
+/* ---- system description (replaces the OpenMM Force-object construction in model.py) ----------- */
+/* context.setPositions, model.py:877.  xyz_nm is [N,3] row-major. */
+int mmx_set_positions(mmx_handle h, const float *xyz_nm);
+/* context.getState(getPositions=True).getPositions(), model.py:889-892. */
+int mmx_get_positions(mmx_handle h, float *xyz_nm);
+/* Per-particle parameter "s" of the compartment/lamina forces, model.py:236-239, 485.  s in {-2..2}. */
+int mmx_set_labels(mmx_handle h, const int8_t *s);
+/* HarmonicBondForce + HarmonicAngleForce over the backbone with the reference's chr_ends index
+ * quirks (bond (i,i+1) dropped when i in chr_ends; angle (i,i+1,i+2) dropped when i in chr_ends or
+ * chr_ends-1): model.py:625-636, 708-720. */
+int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, float bond_r0, float bond_k,
+                     float angle_theta0, float angle_k, int32_t use_bond, int32_t use_angle);
+/* Same, with explicit per-bead masks: bit0 = bond (i,i+1) present, bit1 = angle (i,i+1,i+2) present. */
+int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, float bond_k, float angle_theta0,
+                           float angle_k, int32_t use_bond, int32_t use_angle);
+/* Loop HarmonicBondForce: bonds (m[l], n[l]) with rest length r0[l], constant k.  model.py:651-659. */
+int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop);
+/* CustomNonbondedForce "epsilon*(sigma/(r+r_small))^EV_POWER", model.py:181-201.
+ * cutoff_nm <= 0: NoCutoff (what the reference does); > 0: plain truncation (CutoffNonPeriodic). */
+int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm);
+/* CustomNonbondedForce "-E*exp(-r^2/(2*rc^2))" with the label-pair amplitude table of the mode.
+ * May be called once per mode; the amplitudes of COB and SCB add (both use rc = r_comp). */
+int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm);
+/* CustomExternalForce "C*(max(0,r-R2)^2+max(0,R1-r)^2)", model.py:453-466. */
+int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]);
+/* CustomExternalForce "B*(sin(pi*(r-R1)/(R2-R1))^8-1)*(delta(s+1)+delta(s+2))", model.py:499-507. */
+int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]);
+/* CustomExternalForce "G*chrom_s*(r-R1)^2", model.py:579-586; w is [N] chrom_strength. */
+int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w);
+/* Removes a term again (term = MMX_T_*). */
+int mmx_disable_term(mmx_handle h, int32_t term);
+
+/* ---- tunables that are not part of the physics ------------------------------------------------
+ * key                 meaning                                                      default
+ * "deterministic"     1: order beads inside cells by id (bitwise reproducible)        1
+ * "profile"           k>0: HIP-event time every k-th launch of each kernel slot       0
+ * "poll_interval"     evaluations enqueued between host polls of the device state     32
+ * "nb_variant"        non-bonded kernel variant (0 = default)                         0
+ */
+int mmx_set_option(mmx_handle h, const char *key, double value);
+int mmx_get_option(mmx_handle h, const char *key, double *value);
+
+/* ---- compute (parity hook) --------------------------------------------------------------------
+ * One evaluation of all enabled terms at the current positions: context.getState(getEnergy=True,
+ * getForces=True).  forces_out is [N,3] (may be NULL), energy_terms_out is [MMX_N_TERMS]. */
+int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out);
+
+/* ---- minimize ---------------------------------------------------------------------------------
+ * simulation.minimizeEnergy(), model.py:886 == OpenMM LocalEnergyMinimizer.minimize(context,
+ * tolerance = 10 kJ/mol/nm, maxIterations = 0): liblbfgs L-BFGS (m = 6, backtracking strong-Wolfe
+ * line search).  Runs entirely on the device; blocks until finished.  Positions are updated in
+ * place (read them with mmx_get_positions).  max_iters == 0: until converged. */
+int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * Launches kernel slot `kernel` (MMX_K_*) `reps` times back to back at the current positions on the
+ * handle's stream between two HIP events and returns the mean duration per launch and the
+ * algorithmic bytes one launch moves (DESIGN.md "Kernels").  Results of the launches are discarded. */
+int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes);
+/* Diagnostics of the last cell build: n_cells, max beads per cell, cell edge (nm), pair-candidate
+ * count (bead x stencil occupancy) and pairs inside the cutoff; any pointer may be NULL. */
+int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double *cell_edge, double *pair_candidates,
+                  double *pairs_within_cutoff);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMX_H */

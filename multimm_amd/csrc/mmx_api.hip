@@ -1,0 +1,930 @@
+// mmx_api.hip -- host side of libmmx.so: handle, C ABI (include/mmx.h), launch sequences.
+// gfx950 only; there is no CPU path in this library.
+#include "../../include/mmx.h"
+#include "mmx_bonded.hpp"
+#include "mmx_cells.hpp"
+#include "mmx_common.hpp"
+#include "mmx_lbfgs.hpp"
+#include "mmx_nonbonded.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace mmx;
+
+namespace {
+
+constexpr int kChunk = 64;
+constexpr int kMaxEvents = 8192;
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+} // namespace
+
+struct mmx_handle_s {
+    int n = 0, n4 = 0, device = 0;
+    hipStream_t stream = nullptr;
+    FFParams P{};
+    bool have_pos = false;
+    // vectors (float, padded to n4*4)
+    float *x = nullptr, *xp = nullptr, *g = nullptr, *gp = nullptr, *d = nullptr, *S = nullptr, *Y = nullptr;
+    float4 *pos4 = nullptr;
+    int8_t *labels = nullptr;
+    uint8_t *flags = nullptr;
+    float *cf_w = nullptr;
+    // cells
+    int *cell_of = nullptr, *count = nullptr, *cursor = nullptr, *start = nullptr, *istart = nullptr,
+        *perm = nullptr;
+    int2 *items = nullptr;
+    GridParams *grid = nullptr;
+    unsigned *bbox = nullptr;
+    int maxcells = 262144;
+    int max_items = 0;
+    int last_items = -1;
+    // reductions / state
+    double *part = nullptr, *rows = nullptr;
+    MinState *st = nullptr;      // device
+    MinState *st_host = nullptr; // pinned
+    // loops (CSR over beads carrying a loop end)
+    int n_loops = 0, n_rows = 0;
+    int *row_bead = nullptr, *row_start = nullptr, *partner = nullptr;
+    float *loop_r0 = nullptr;
+    // all-pairs scratch
+    float4 *fpart = nullptr;
+    float2 *epart = nullptr;
+    int ap_slices = 0;
+    // compartments
+    float tab_cob[25]{}, tab_scb[25]{};
+    bool has_cob = false, has_scb = false;
+    float ev_cut = 0.f, g_cut = 0.f, g_rc = 0.15f;
+    // options
+    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0;
+    // profiling
+    std::vector<EventPair> ev_pool, ev_used;
+    int64_t launches[MMX_N_KERNELS]{};
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+            return MMX_ERR_HIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+int fail(mmx_handle h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+template <class T>
+hipError_t dalloc(T **p, size_t count) {
+    hipError_t e = hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    return e;
+}
+
+bool all_pairs(const mmx_handle_s *h) {
+    return (h->P.use_ev && h->ev_cut <= 0.f) || (h->P.use_gauss && h->g_cut <= 0.f);
+}
+bool has_nb(const mmx_handle_s *h) { return h->P.use_ev || h->P.use_gauss; }
+
+float hmin_of(const mmx_handle_s *h) {
+    float rc = 0.f;
+    if (h->P.use_ev) rc = std::max(rc, h->ev_cut);
+    if (h->P.use_gauss) rc = std::max(rc, h->g_cut);
+    return rc * 1.001f;
+}
+
+// Derived constants refreshed before every launch sequence.
+void refresh_params(mmx_handle_s *h) {
+    FFParams &P = h->P;
+    P.n = h->n;
+    const float inf = std::numeric_limits<float>::infinity();
+    P.ev_rc2 = (P.use_ev && h->ev_cut > 0.f) ? h->ev_cut * h->ev_cut : inf;
+    P.g_rc2 = (P.use_gauss && h->g_cut > 0.f) ? h->g_cut * h->g_cut : inf;
+    if (all_pairs(h)) {
+        P.rc2max = inf;
+    } else {
+        float rc = 0.f;
+        if (P.use_ev) rc = std::max(rc, h->ev_cut);
+        if (P.use_gauss) rc = std::max(rc, h->g_cut);
+        P.rc2max = rc * rc;
+    }
+    P.ev_pmode = (P.ev_power == 6.0f) ? 6 : (P.ev_power == 3.0f) ? 3 : 0;
+    P.use_gauss = (h->has_cob || h->has_scb) ? 1 : 0;
+    for (int i = 0; i < 25; ++i) P.table[i] = (h->has_cob ? h->tab_cob[i] : 0.f) + (h->has_scb ? h->tab_scb[i] : 0.f);
+    P.g_inv_rc2 = 1.0f / (h->g_rc * h->g_rc);
+    P.g_c2 = (float)(-1.4426950408889634 / (2.0 * (double)h->g_rc * (double)h->g_rc));
+}
+
+int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
+
+// ---- profiling helpers ----------------------------------------------------------------------
+bool prof_begin(mmx_handle_s *h, int slot, EventPair &ep) {
+    h->launches[slot]++;
+    if (h->profile <= 0) return false;
+    if ((h->launches[slot] - 1) % h->profile != 0) return false;
+    if (h->ev_pool.empty()) return false;
+    ep = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    ep.slot = slot;
+    (void)hipEventRecord(ep.a, h->stream);
+    return true;
+}
+void prof_end(mmx_handle_s *h, bool on, EventPair &ep) {
+    if (!on) return;
+    (void)hipEventRecord(ep.b, h->stream);
+    h->ev_used.push_back(ep);
+}
+void prof_collect(mmx_handle_s *h, mmx_stats *out) {
+    for (auto &ep : h->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess && out) {
+            out->kernel_ns[ep.slot] += (double)ms * 1e6;
+            out->kernel_samples[ep.slot] += 1;
+        }
+        h->ev_pool.push_back(ep);
+    }
+    h->ev_used.clear();
+}
+
+// ---- launch sequences -----------------------------------------------------------------------
+template <int PMODE>
+void launch_nb_cells_p(mmx_handle_s *h, int grid) {
+    const FFParams &P = h->P;
+    dim3 b(192), gdim(grid);
+#define NBC(EV, GA)                                                                                         \
+    hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4, h->perm, h->start,    \
+                       h->items, h->grid, h->st, h->g, h->part)
+    if (P.use_ev && P.use_gauss) NBC(true, true);
+    else if (P.use_ev) NBC(true, false);
+    else NBC(false, true);
+#undef NBC
+}
+
+template <int PMODE>
+void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
+    const FFParams &P = h->P;
+    dim3 b(256), gdim((h->n + 255) / 256, h->ap_slices);
+#define NBA(EV, GA)                                                                                         \
+    hipLaunchKernelGGL((k_nb_allpairs<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4, tiles_per_slice,   \
+                       h->fpart, h->epart, h->st)
+    if (P.use_ev && P.use_gauss) NBA(true, true);
+    else if (P.use_ev) NBA(true, false);
+    else NBA(false, true);
+#undef NBA
+}
+
+int nb_grid(const mmx_handle_s *h) {
+    int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
+    int g = items + items / 4 + 64;
+    return std::max(256, std::min(g, kPartStride));
+}
+
+void enqueue_build(mmx_handle_s *h, bool move) {
+    const int n = h->n;
+    const int gb = (n + 255) / 256;
+    if (move)
+        hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
+                           h->pos4, h->bbox, h->st);
+    else
+        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
+                           h->pos4, h->bbox, h->st);
+    if (has_nb(h) && !all_pairs(h)) {
+        const float hm = hmin_of(h);
+        hipLaunchKernelGGL(k_cell_count, dim3(gb), dim3(256), 0, h->stream, n, h->pos4, h->bbox, hm, h->maxcells,
+                           h->cell_of, h->count, h->st);
+        hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox, hm, h->maxcells,
+                           h->count, h->start, h->istart, h->grid, h->st);
+        hipLaunchKernelGGL(k_cell_fill, dim3(gb), dim3(256), 0, h->stream, n, h->cell_of, h->start, h->cursor,
+                           h->perm, h->st);
+        hipLaunchKernelGGL((k_cell_order<kChunk>), dim3(1024), dim3(256), 0, h->stream, h->grid, h->start,
+                           h->istart, h->count, h->cursor, h->perm, h->items, h->deterministic, h->st);
+    }
+}
+
+// One full energy+gradient evaluation followed by the line-search controller.
+void enqueue_eval(mmx_handle_s *h, bool move) {
+    EventPair ep{};
+    CtlArgs A{};
+    bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
+    enqueue_build(h, move);
+    prof_end(h, on, ep);
+
+    on = prof_begin(h, MMX_K_NONBONDED, ep);
+    if (!has_nb(h)) {
+        (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
+    } else if (all_pairs(h)) {
+        const int tiles = (h->n + 255) / 256;
+        const int tps = (tiles + h->ap_slices - 1) / h->ap_slices;
+        switch (h->P.ev_pmode) {
+        case 6: launch_nb_allpairs_p<6>(h, tps); break;
+        case 3: launch_nb_allpairs_p<3>(h, tps); break;
+        default: launch_nb_allpairs_p<0>(h, tps); break;
+        }
+        const int gf = grid_beads(h->n);
+        hipLaunchKernelGGL(k_nb_allpairs_fold, dim3(gf), dim3(256), 0, h->stream, h->n, h->ap_slices, h->fpart,
+                           h->epart, h->g, h->part, h->st);
+        A.nblk[P_EV] = A.nblk[P_GAUSS] = gf;
+    } else {
+        const int gn = nb_grid(h);
+        switch (h->P.ev_pmode) {
+        case 6: launch_nb_cells_p<6>(h, gn); break;
+        case 3: launch_nb_cells_p<3>(h, gn); break;
+        default: launch_nb_cells_p<0>(h, gn); break;
+        }
+        A.nblk[P_EV] = A.nblk[P_GAUSS] = gn;
+    }
+    prof_end(h, on, ep);
+
+    const int gb = grid_beads(h->n);
+    if (h->flags && (h->P.use_bond || h->P.use_angle)) {
+        on = prof_begin(h, MMX_K_BACKBONE, ep);
+        hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                           h->st);
+        prof_end(h, on, ep);
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
+    }
+    if (h->n_rows > 0) {
+        const int gl = std::min((h->n_rows + 255) / 256, 1024);
+        on = prof_begin(h, MMX_K_LOOPS, ep);
+        hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
+                           h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st);
+        prof_end(h, on, ep);
+        A.nblk[P_LOOP] = gl;
+    }
+    on = prof_begin(h, MMX_K_CONFINE, ep);
+    hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
+                       h->part, h->st);
+    prof_end(h, on, ep);
+    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
+
+    on = prof_begin(h, MMX_K_REDUCE, ep);
+    hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, h->stream, A, h->part, h->st);
+    prof_end(h, on, ep);
+}
+
+// History update + direction; every kernel is a no-op unless the controller accepted the step.
+void enqueue_accept(mmx_handle_s *h) {
+    EventPair ep{};
+    const int g4 = std::min((h->n4 + 255) / 256, 1024);
+    bool on = prof_begin(h, MMX_K_LBFGS, ep);
+    hipLaunchKernelGGL(k_history, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
+                       (const float4 *)h->g, (float4 *)h->gp, (float4 *)h->S, (float4 *)h->Y, h->rows, h->st);
+    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(256), 0, h->stream, g4, h->rows, h->st);
+    hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->g,
+                       (const float4 *)h->S, (const float4 *)h->Y, (float4 *)h->d, h->st);
+    prof_end(h, on, ep);
+}
+
+int push_state(mmx_handle_s *h) {
+    HIPCHK(h, hipMemcpyAsync(h->st, h->st_host, sizeof(MinState), hipMemcpyHostToDevice, h->stream));
+    return MMX_OK;
+}
+int pull_state(mmx_handle_s *h) {
+    HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
+    return MMX_OK;
+}
+
+int ensure_allpairs_scratch(mmx_handle_s *h) {
+    if (!all_pairs(h) || !has_nb(h)) return MMX_OK;
+    const int tiles = (h->n + 255) / 256;
+    int slices = std::max(1, std::min(64, (2048 + tiles - 1) / tiles));
+    slices = std::min(slices, tiles);
+    if (slices != h->ap_slices || !h->fpart) {
+        if (h->fpart) (void)hipFree(h->fpart);
+        if (h->epart) (void)hipFree(h->epart);
+        h->fpart = nullptr;
+        h->epart = nullptr;
+        HIPCHK(h, dalloc(&h->fpart, (size_t)slices * h->n));
+        HIPCHK(h, dalloc(&h->epart, (size_t)slices * h->n));
+        h->ap_slices = slices;
+    }
+    return MMX_OK;
+}
+
+// First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
+int prime_items(mmx_handle_s *h) {
+    if (!has_nb(h) || all_pairs(h)) return MMX_OK;
+    enqueue_build(h, false);
+    return pull_state(h);
+}
+
+int prepare(mmx_handle_s *h) {
+    if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set (mmx_set_positions)");
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_params(h);
+    int rc = ensure_allpairs_scratch(h);
+    if (rc) return rc;
+    return MMX_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int mmx_abi_version(void) { return 1; }
+
+const char *mmx_last_error(mmx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
+    if (!out) return MMX_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n_beads < 1 || n_beads > (1 << 28)) {
+        g_create_error = "n_beads out of range";
+        return MMX_ERR_BAD_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device visible (libmmx has no CPU path)";
+        return MMX_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_error = "device_id out of range";
+        return MMX_ERR_BAD_ARG;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        g_create_error = "hipGetDeviceProperties failed";
+        return MMX_ERR_HIP;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", libmmx is built for gfx950 (MI355X) only";
+        return MMX_ERR_HIP;
+    }
+    mmx_handle_s *h = new (std::nothrow) mmx_handle_s();
+    if (!h) return MMX_ERR_BAD_ARG;
+    h->n = n_beads;
+    h->n4 = (3 * n_beads + 3) / 4;
+    h->device = device_id;
+    h->max_items = (n_beads + kChunk - 1) / kChunk + std::min(n_beads, h->maxcells) + 64;
+    auto boot = [&]() -> int {
+        HIPCHK(h, hipSetDevice(device_id));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t nv = (size_t)h->n4 * 4;
+        HIPCHK(h, dalloc(&h->x, nv));
+        HIPCHK(h, dalloc(&h->xp, nv));
+        HIPCHK(h, dalloc(&h->g, nv));
+        HIPCHK(h, dalloc(&h->gp, nv));
+        HIPCHK(h, dalloc(&h->d, nv));
+        HIPCHK(h, dalloc(&h->S, nv * MMX_M));
+        HIPCHK(h, dalloc(&h->Y, nv * MMX_M));
+        HIPCHK(h, dalloc(&h->pos4, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->labels, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->cell_of, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->perm, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->count, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->cursor, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->start, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->istart, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->items, (size_t)h->max_items));
+        HIPCHK(h, dalloc(&h->grid, 1));
+        HIPCHK(h, dalloc(&h->bbox, 8));
+        HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
+        HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWS * MMX_NBASIS * kPartStride));
+        HIPCHK(h, dalloc(&h->st, 1));
+        HIPCHK(h, hipHostMalloc((void **)&h->st_host, sizeof(MinState), hipHostMallocDefault));
+        std::memset(h->st_host, 0, sizeof(MinState));
+        const unsigned bb[8] = {kEncPosInf, kEncPosInf, kEncPosInf, kEncNegInf, kEncNegInf, kEncNegInf, 0, 0};
+        HIPCHK(h, hipMemcpy(h->bbox, bb, sizeof(bb), hipMemcpyHostToDevice));
+        for (int i = 0; i < 256; ++i) {
+            EventPair ep{};
+            HIPCHK(h, hipEventCreate(&ep.a));
+            HIPCHK(h, hipEventCreate(&ep.b));
+            h->ev_pool.push_back(ep);
+        }
+        return MMX_OK;
+    };
+    int rc = boot();
+    if (rc != MMX_OK) {
+        g_create_error = h->err;
+        mmx_destroy(h);
+        return rc;
+    }
+    h->P.bond_r0 = 0.1f;
+    *out = h;
+    return MMX_OK;
+}
+
+int mmx_destroy(mmx_handle h) {
+    if (!h) return MMX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
+                    h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->cursor,   h->start,     h->istart,
+                    h->perm,  h->items,  h->grid,   h->bbox,  h->part,   h->rows,     h->st,        h->row_bead,
+                    h->row_start, h->partner, h->loop_r0, h->fpart, h->epart};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->st_host) (void)hipHostFree(h->st_host);
+    for (auto &ep : h->ev_pool) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (auto &ep : h->ev_used) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MMX_OK;
+}
+
+int mmx_set_positions(mmx_handle h, const float *xyz) {
+    if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < (size_t)3 * h->n; ++i)
+        if (!std::isfinite(xyz[i])) return fail(h, MMX_ERR_BAD_ARG, "non-finite position");
+    HIPCHK(h, hipMemcpyAsync(h->x, xyz, sizeof(float) * 3 * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_pos = true;
+    return MMX_OK;
+}
+
+int mmx_get_positions(mmx_handle h, float *xyz) {
+    if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(xyz, h->x, sizeof(float) * 3 * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMX_OK;
+}
+
+int mmx_set_labels(mmx_handle h, const int8_t *s) {
+    if (!h || !s) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    for (int i = 0; i < h->n; ++i)
+        if (s[i] < -2 || s[i] > 2) return fail(h, MMX_ERR_BAD_ARG, "label outside {-2..2}");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->labels, s, (size_t)h->n, hipMemcpyHostToDevice));
+    return MMX_OK;
+}
+
+int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, float bond_k, float angle_theta0,
+                           float angle_k, int32_t use_bond, int32_t use_angle) {
+    if (!h || !flags) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    const int n = h->n;
+    for (int i = 0; i < n; ++i) {
+        if ((flags[i] & 1) && i + 1 >= n) return fail(h, MMX_ERR_BAD_ARG, "bond flag on the last bead");
+        if ((flags[i] & 2) && i + 2 >= n) return fail(h, MMX_ERR_BAD_ARG, "angle flag on the last two beads");
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->flags) HIPCHK(h, dalloc(&h->flags, (size_t)n));
+    HIPCHK(h, hipMemcpy(h->flags, flags, (size_t)n, hipMemcpyHostToDevice));
+    h->P.bond_r0 = bond_r0;
+    h->P.bond_k = bond_k;
+    h->P.ang_th0 = angle_theta0;
+    h->P.ang_k = angle_k;
+    h->P.use_bond = use_bond ? 1 : 0;
+    h->P.use_angle = use_angle ? 1 : 0;
+    return MMX_OK;
+}
+
+int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, float bond_r0, float bond_k,
+                     float angle_theta0, float angle_k, int32_t use_bond, int32_t use_angle) {
+    if (!h || (!chr_ends && n_ends > 0) || n_ends < 0) return fail(h, MMX_ERR_BAD_ARG, "bad chr_ends");
+    const int n = h->n;
+    // model.py:629 "i not in chr_ends" ; model.py:712 "(i not in chr_ends) and (i not in chr_ends - 1)"
+    std::vector<uint8_t> in_ends((size_t)n + 2, 0), in_ends_m1((size_t)n + 2, 0);
+    for (int k = 0; k < n_ends; ++k) {
+        const int e = chr_ends[k];
+        if (e < 0 || e > n) return fail(h, MMX_ERR_BAD_ARG, "chr_ends entry outside [0, N]");
+        in_ends[e] = 1;
+        if (e >= 1) in_ends_m1[e - 1] = 1;
+    }
+    std::vector<uint8_t> flags((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        uint8_t f = 0;
+        if (i <= n - 2 && !in_ends[i]) f |= 1;
+        if (i <= n - 3 && !in_ends[i] && !in_ends_m1[i]) f |= 2;
+        flags[i] = f;
+    }
+    return mmx_set_backbone_masks(h, flags.data(), bond_r0, bond_k, angle_theta0, angle_k, use_bond, use_angle);
+}
+
+int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop) {
+    if (!h || n_loops < 0 || (n_loops > 0 && (!m || !n || !r0))) return fail(h, MMX_ERR_BAD_ARG, "bad loop arrays");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int l = 0; l < n_loops; ++l) {
+        if (m[l] < 0 || m[l] >= h->n || n[l] < 0 || n[l] >= h->n || m[l] == n[l])
+            return fail(h, MMX_ERR_BAD_ARG, "loop anchor out of range or degenerate");
+        if (!std::isfinite(r0[l])) return fail(h, MMX_ERR_BAD_ARG, "non-finite loop rest length");
+    }
+    // CSR over beads that carry a loop end; entries of a bead keep loop order (fixed summation order).
+    std::vector<int> deg((size_t)h->n, 0);
+    for (int l = 0; l < n_loops; ++l) {
+        deg[m[l]]++;
+        deg[n[l]]++;
+    }
+    std::vector<int> row_of((size_t)h->n, -1), row_bead, row_start;
+    int ne = 0;
+    for (int b = 0; b < h->n; ++b)
+        if (deg[b]) {
+            row_of[b] = (int)row_bead.size();
+            row_bead.push_back(b);
+            row_start.push_back(ne);
+            ne += deg[b];
+        }
+    row_start.push_back(ne);
+    std::vector<int> fill(row_start.begin(), row_start.end()), partner((size_t)ne);
+    std::vector<float> er0((size_t)ne);
+    for (int l = 0; l < n_loops; ++l) {
+        int q = fill[row_of[m[l]]]++;
+        partner[q] = n[l];
+        er0[q] = r0[l];
+        q = fill[row_of[n[l]]]++;
+        partner[q] = m[l];
+        er0[q] = r0[l];
+    }
+    for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0})
+        if (p) (void)hipFree(p);
+    h->row_bead = h->row_start = h->partner = nullptr;
+    h->loop_r0 = nullptr;
+    h->n_rows = (int)row_bead.size();
+    h->n_loops = n_loops;
+    h->P.loop_k = k_loop;
+    if (h->n_rows > 0) {
+        HIPCHK(h, dalloc(&h->row_bead, row_bead.size()));
+        HIPCHK(h, dalloc(&h->row_start, row_start.size()));
+        HIPCHK(h, dalloc(&h->partner, partner.size()));
+        HIPCHK(h, dalloc(&h->loop_r0, er0.size()));
+        HIPCHK(h, hipMemcpy(h->row_bead, row_bead.data(), row_bead.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->row_start, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->loop_r0, er0.data(), er0.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return MMX_OK;
+}
+
+int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power))
+        return fail(h, MMX_ERR_BAD_ARG, "bad excluded-volume parameters");
+    h->P.use_ev = 1;
+    h->P.ev_eps = eps;
+    h->P.ev_sigma = sigma;
+    h->P.ev_rs = r_small;
+    h->P.ev_power = power;
+    h->ev_cut = cutoff_nm;
+    return MMX_OK;
+}
+
+int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm) {
+    if (!h || !E || !(rc > 0.f)) return fail(h, MMX_ERR_BAD_ARG, "bad compartment parameters");
+    auto idx = [](int si, int sj) { return (si + 2) * 5 + (sj + 2); };
+    if (mode == MMX_COMP_COB) { // model.py:246-250: A = {1,2}, B = {-1,-2}
+        std::memset(h->tab_cob, 0, sizeof(h->tab_cob));
+        for (int a : {1, 2})
+            for (int b : {1, 2}) h->tab_cob[idx(a, b)] = E[0];
+        for (int a : {-1, -2})
+            for (int b : {-1, -2}) h->tab_cob[idx(a, b)] = E[1];
+        h->has_cob = true;
+    } else if (mode == MMX_COMP_SCB) { // model.py:322-328: Ea1 (2,2), Ea2 (1,1), Eb1 (-1,-1), Eb2 (-2,-2)
+        std::memset(h->tab_scb, 0, sizeof(h->tab_scb));
+        h->tab_scb[idx(2, 2)] = E[0];
+        h->tab_scb[idx(1, 1)] = E[1];
+        h->tab_scb[idx(-1, -1)] = E[2];
+        h->tab_scb[idx(-2, -2)] = E[3];
+        h->has_scb = true;
+    } else {
+        return fail(h, MMX_ERR_BAD_ARG, "unknown compartment mode");
+    }
+    h->g_rc = rc;
+    h->g_cut = cutoff_nm;
+    h->P.use_gauss = 1;
+    return MMX_OK;
+}
+
+int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]) {
+    if (!h || !centre) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->P.use_container = 1;
+    h->P.sc_C = C;
+    h->P.sc_R1 = R1;
+    h->P.sc_R2 = R2;
+    h->P.cx = centre[0];
+    h->P.cy = centre[1];
+    h->P.cz = centre[2];
+    return MMX_OK;
+}
+
+int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]) {
+    if (!h || !centre || !(R2 != R1)) return fail(h, MMX_ERR_BAD_ARG, "bad lamina parameters");
+    h->P.use_lamina = 1;
+    h->P.ibl_B = B;
+    h->P.ibl_R1 = R1;
+    h->P.ibl_R2 = R2;
+    h->P.cx = centre[0];
+    h->P.cy = centre[1];
+    h->P.cz = centre[2];
+    return MMX_OK;
+}
+
+int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w) {
+    if (!h || !centre || !w) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->cf_w) HIPCHK(h, dalloc(&h->cf_w, (size_t)h->n));
+    HIPCHK(h, hipMemcpy(h->cf_w, w, sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice));
+    h->P.use_central = 1;
+    h->P.cf_G = G;
+    h->P.cf_R1 = R1;
+    h->P.cx = centre[0];
+    h->P.cy = centre[1];
+    h->P.cz = centre[2];
+    return MMX_OK;
+}
+
+int mmx_disable_term(mmx_handle h, int32_t term) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    switch (term) {
+    case MMX_T_EV: h->P.use_ev = 0; break;
+    case MMX_T_GAUSS: h->has_cob = h->has_scb = false; h->P.use_gauss = 0; break;
+    case MMX_T_BOND: h->P.use_bond = 0; break;
+    case MMX_T_ANGLE: h->P.use_angle = 0; break;
+    case MMX_T_LOOP: h->n_rows = 0; h->n_loops = 0; break;
+    case MMX_T_CONTAINER: h->P.use_container = 0; break;
+    case MMX_T_LAMINA: h->P.use_lamina = 0; break;
+    case MMX_T_CENTRAL: h->P.use_central = 0; break;
+    default: return fail(h, MMX_ERR_BAD_ARG, "unknown term");
+    }
+    return MMX_OK;
+}
+
+int mmx_set_option(mmx_handle h, const char *key, double value) {
+    if (!h || !key) return MMX_ERR_BAD_ARG;
+    const std::string k(key);
+    if (k == "deterministic") h->deterministic = value != 0.0;
+    else if (k == "profile") h->profile = (int)value;
+    else if (k == "poll_interval") h->poll_interval = std::max(1, (int)value);
+    else if (k == "nb_variant") h->nb_variant = (int)value;
+    else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
+    return MMX_OK;
+}
+
+int mmx_get_option(mmx_handle h, const char *key, double *value) {
+    if (!h || !key || !value) return MMX_ERR_BAD_ARG;
+    const std::string k(key);
+    if (k == "deterministic") *value = h->deterministic;
+    else if (k == "profile") *value = h->profile;
+    else if (k == "poll_interval") *value = h->poll_interval;
+    else if (k == "nb_variant") *value = h->nb_variant;
+    else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
+    return MMX_OK;
+}
+
+int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    int rc = prepare(h);
+    if (rc) return rc;
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if ((rc = prime_items(h))) return rc;
+    enqueue_eval(h, false);
+    if ((rc = pull_state(h))) return rc;
+    HIPCHK(h, hipGetLastError());
+    prof_collect(h, nullptr);
+    if (energy_terms_out)
+        for (int t = 0; t < MMX_N_TERMS; ++t) energy_terms_out[t] = h->st_host->eterms[t];
+    if (forces_out) {
+        std::vector<float> g((size_t)3 * h->n);
+        HIPCHK(h, hipMemcpy(g.data(), h->g, sizeof(float) * g.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < g.size(); ++i) forces_out[i] = -g[i];
+    }
+    const double f = h->st_host->ftrial;
+    if (!(f - f == 0.0)) return fail(h, MMX_ERR_NAN, "non-finite energy");
+    return MMX_OK;
+}
+
+int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) {
+    if (!h || max_iters < 0 || !(tolerance >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad minimize arguments");
+    int rc = prepare(h);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    mmx_stats local;
+    std::memset(&local, 0, sizeof(local));
+    for (int k = 0; k < MMX_N_KERNELS; ++k) h->launches[k] = 0;
+
+    // epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2))  (OpenMM LocalEnergyMinimizer)
+    std::vector<float> hx((size_t)3 * h->n);
+    HIPCHK(h, hipMemcpy(hx.data(), h->x, sizeof(float) * hx.size(), hipMemcpyDeviceToHost));
+    double nrm = 0.0;
+    for (float v : hx) nrm += (double)v * (double)v;
+    nrm /= (double)h->n;
+    nrm = nrm < 1.0 ? 1.0 : std::sqrt(nrm);
+
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if ((rc = prime_items(h))) return rc;
+
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_INIT;
+    h->st_host->k = 1;
+    h->st_host->max_iters = max_iters;
+    h->st_host->epsilon = tolerance / nrm;
+    h->st_host->n_items = h->last_items > 0 ? h->last_items : 0;
+    if ((rc = push_state(h))) return rc;
+    const size_t nv = (size_t)h->n4 * 4;
+    HIPCHK(h, hipMemsetAsync(h->S, 0, sizeof(float) * nv * MMX_M, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
+
+    enqueue_eval(h, false);
+    enqueue_accept(h);
+    if ((rc = pull_state(h))) return rc;
+    local.e_initial = h->st_host->fx;
+    while (h->st_host->phase != PH_DONE) {
+        int batch = h->poll_interval;
+        if (max_iters > 0) batch = std::max(1, std::min(batch, max_iters - h->st_host->iters));
+        for (int b = 0; b < batch; ++b) {
+            enqueue_eval(h, true);
+            enqueue_accept(h);
+        }
+        if ((rc = pull_state(h))) return rc;
+        if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
+    }
+    HIPCHK(h, hipGetLastError());
+    const MinState &s = *h->st_host;
+    if (s.status < 0 && s.evals > 1) {
+        // line search failed: liblbfgs reverts to the last accepted point
+        const int g4 = std::min((h->n4 + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->xp, (float4 *)h->x);
+        hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->gp, (float4 *)h->g);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    prof_collect(h, &local);
+    local.iterations = s.iters;
+    local.evaluations = s.evals;
+    local.status = s.status;
+    local.n_beads = h->n;
+    local.e_final = s.fx;
+    local.gnorm_final = s.gnorm;
+    local.xnorm_final = s.xnorm;
+    local.rms_force = s.gnorm / std::sqrt((double)h->n);
+    for (int t = 0; t < MMX_N_TERMS; ++t) local.energy_terms[t] = s.eterms_acc[t];
+    for (int k = 0; k < MMX_N_KERNELS; ++k) local.kernel_launches[k] = h->launches[k];
+    local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out) *out = local;
+    if (s.status == MMX_MIN_NAN) return fail(h, MMX_ERR_NAN, "non-finite energy during minimization");
+    return MMX_OK;
+}
+
+int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) {
+    if (!h || reps < 1 || !mean_us) return fail(h, MMX_ERR_BAD_ARG, "bad arguments");
+    if (kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE)
+        return fail(h, MMX_ERR_BAD_ARG, "mmx_time_kernel covers slots 0..4; L-BFGS slots are timed live (option profile)");
+    int rc = prepare(h);
+    if (rc) return rc;
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if ((rc = prime_items(h))) return rc;
+    enqueue_eval(h, false); // warm: builds cells, fills every buffer the slot reads
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    const int gb = grid_beads(h->n);
+    const int saved_profile = h->profile;
+    h->profile = 0;
+    double bytes = 0.0;
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        switch (kernel) {
+        case MMX_K_CELL_BUILD:
+            enqueue_build(h, false);
+            bytes = 56.0 * h->n;
+            break;
+        case MMX_K_NONBONDED:
+            if (!has_nb(h)) break;
+            if (all_pairs(h)) {
+                const int tiles = (h->n + 255) / 256;
+                const int tps = (tiles + h->ap_slices - 1) / h->ap_slices;
+                switch (h->P.ev_pmode) {
+                case 6: launch_nb_allpairs_p<6>(h, tps); break;
+                case 3: launch_nb_allpairs_p<3>(h, tps); break;
+                default: launch_nb_allpairs_p<0>(h, tps); break;
+                }
+                hipLaunchKernelGGL(k_nb_allpairs_fold, dim3(gb), dim3(256), 0, h->stream, h->n, h->ap_slices,
+                                   h->fpart, h->epart, h->g, h->part, h->st);
+            } else {
+                const int gn = nb_grid(h);
+                switch (h->P.ev_pmode) {
+                case 6: launch_nb_cells_p<6>(h, gn); break;
+                case 3: launch_nb_cells_p<3>(h, gn); break;
+                default: launch_nb_cells_p<0>(h, gn); break;
+                }
+            }
+            bytes = 32.0 * h->n;
+            break;
+        case MMX_K_BACKBONE:
+            if (!h->flags) break;
+            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                               h->st);
+            bytes = 25.0 * h->n;
+            break;
+        case MMX_K_LOOPS:
+            if (h->n_rows <= 0) break;
+            hipLaunchKernelGGL(k_loops, dim3(std::min((h->n_rows + 255) / 256, 1024)), dim3(256), 0, h->stream, h->P,
+                               h->n_rows, h->pos4, h->row_bead, h->row_start, h->partner, h->loop_r0, h->g, h->part,
+                               h->st);
+            bytes = 64.0 * h->n_loops;
+            break;
+        case MMX_K_CONFINE:
+            hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g,
+                               h->d, h->part, h->st);
+            bytes = 25.0 * h->n;
+            break;
+        }
+    }
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    h->profile = saved_profile;
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(h, hipGetLastError());
+    *mean_us = (double)ms * 1e3 / reps;
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
+    return MMX_OK;
+}
+
+// Census of the pair work at the current positions (diagnostics for DESIGN.md / bench): one thread
+// per bead walks its 27-cell stencil.
+__global__ __launch_bounds__(256) static void k_census(int n, const float4 *__restrict__ pos4,
+                                                       const int *__restrict__ perm, const int *__restrict__ start,
+                                                       const int *__restrict__ cell_of,
+                                                       const GridParams *__restrict__ grid, float rc2,
+                                                       double *__restrict__ out /* [2] */) {
+    __shared__ double s_w[4];
+    const GridParams G = *grid;
+    double cand = 0.0, within = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = pos4[i];
+        const int c = cell_of[i];
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, G.nz - 1); ++zz)
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.ny - 1); ++yy) {
+                const int row = (zz * G.ny + yy) * G.nx;
+                const int rs = start[row + max(cx - 1, 0)], re = start[row + min(cx + 1, G.nx - 1) + 1];
+                cand += (double)(re - rs);
+                for (int q = rs; q < re; ++q) {
+                    const float4 o = pos4[perm[q]];
+                    const float dx = p.x - o.x, dy = p.y - o.y, dz = p.z - o.z;
+                    if (dx * dx + dy * dy + dz * dz < rc2) within += 1.0;
+                }
+            }
+    }
+    const double a = block_sum<256>(cand, s_w);
+    const double b = block_sum<256>(within, s_w);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], a);
+        atomicAdd(&out[1], b);
+    }
+}
+
+int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double *cell_edge, double *pair_candidates,
+                  double *pairs_within_cutoff) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    int rc = prepare(h);
+    if (rc) return rc;
+    if (!has_nb(h) || all_pairs(h)) return fail(h, MMX_ERR_STATE, "census needs a cutoff (cell-list mode)");
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if ((rc = prime_items(h))) return rc;
+    double *dout = nullptr;
+    HIPCHK(h, dalloc(&dout, 2));
+    hipLaunchKernelGGL(k_census, dim3(grid_beads(h->n)), dim3(256), 0, h->stream, h->n, h->pos4, h->perm, h->start,
+                       h->cell_of, h->grid, h->P.rc2max, dout);
+    double res[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(dout);
+    if (n_cells) *n_cells = h->st_host->ncells;
+    if (max_per_cell) *max_per_cell = h->st_host->max_per_cell;
+    if (cell_edge) *cell_edge = h->st_host->cell_edge;
+    if (pair_candidates) *pair_candidates = res[0];
+    if (pairs_within_cutoff) *pairs_within_cutoff = res[1] - (double)h->n; // minus self pairs
+    return MMX_OK;
+}
+
+} // extern "C"

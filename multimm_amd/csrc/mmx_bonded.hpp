@@ -1,0 +1,216 @@
+// mmx_bonded.hpp -- K3 backbone bonds+angles, K4 loop restraints, K5 confinement/lamina/central (+ dots).
+// All three are per-bead gather kernels: the thread of bead i computes every contribution to
+// the gradient of bead i itself (neighbours come from L1/L2), so there are no atomics and the result
+// is bitwise reproducible.  Each does g[i] += dE/dx_i.
+#pragma once
+#include "mmx_common.hpp"
+
+namespace mmx {
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(const float4 p) { return {p.x, p.y, p.z}; }
+__device__ __forceinline__ F3 sub(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float dot(F3 a, F3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+
+// HarmonicBondForce E = 1/2 k (r-r0)^2; returns E, adds dE/dx_i to (gx,gy,gz).  model.py:625-636, 651-659.
+__device__ __forceinline__ float bond_grad(F3 pi, F3 pj, float r0, float k, float &gx, float &gy, float &gz) {
+    const F3 d = sub(pi, pj);
+    const float r2 = dot(d, d);
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    const float r = r2 * rinv;
+    const float dr = r - r0;
+    const float s = k * dr * rinv; // dE/dr / r ; d == 0 => zero gradient
+    gx = fmaf(s, d.x, gx);
+    gy = fmaf(s, d.y, gy);
+    gz = fmaf(s, d.z, gz);
+    return 0.5f * k * dr * dr;
+}
+
+// HarmonicAngleForce E = 1/2 k (theta-theta0)^2, theta at the middle bead.  OpenMM force form:
+// a = x_i-x_j, b = x_k-x_j, c = a x b (|c| clamped >= 1e-6),
+//   F_i = -dEdth*(a x c)/(|a|^2|c|), F_k = -dEdth*(c x b)/(|b|^2|c|), F_j = -(F_i+F_k).   model.py:708-720.
+// Returns E and the FORCES on the two end beads.
+__device__ __forceinline__ float angle_forces(F3 pi, F3 pj, F3 pk, float th0, float kk, F3 &fi, F3 &fk) {
+    const F3 a = sub(pi, pj), b = sub(pk, pj);
+    const F3 c = cross(a, b);
+    const float cn = sqrtf(dot(c, c));
+    const float dt = dot(a, b);
+    const float theta = atan2f(cn, dt);
+    const float rp = fmaxf(cn, 1e-6f);
+    const float aa = fmaxf(dot(a, a), 1e-30f), bb = fmaxf(dot(b, b), 1e-30f);
+    const float dth = theta - th0;
+    const float dE = kk * dth;
+    const float ta = -dE / (aa * rp), tc = -dE / (bb * rp);
+    const F3 ac = cross(a, c), cb = cross(c, b);
+    fi = {ta * ac.x, ta * ac.y, ta * ac.z};
+    fk = {tc * cb.x, tc * cb.y, tc * cb.z};
+    return 0.5f * kk * dth * dth;
+}
+
+// K3.  flags[i] bit0: bond (i,i+1) present, bit1: angle (i,i+1,i+2) present.
+// Algorithmic traffic: read 12 B position + 1 B flag, read-modify-write 12 B gradient = 25 B/bead (+12 RMW read).
+__global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4 *__restrict__ pos4,
+                                                  const uint8_t *__restrict__ flags, float *__restrict__ g,
+                                                  double *__restrict__ part, const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    const int n = P.n;
+    double eb = 0.0, ea = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int f0 = flags[i];
+        const int fm1 = i >= 1 ? flags[i - 1] : 0;
+        const int fm2 = i >= 2 ? flags[i - 2] : 0;
+        const F3 p0 = f3(pos4[i]);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        F3 pm1 = p0, pm2 = p0, pp1 = p0, pp2 = p0;
+        if (i >= 1) pm1 = f3(pos4[i - 1]);
+        if (i >= 2) pm2 = f3(pos4[i - 2]);
+        if (i + 1 < n) pp1 = f3(pos4[i + 1]);
+        if (i + 2 < n) pp2 = f3(pos4[i + 2]);
+        if (P.use_bond) {
+            if (fm1 & 1) (void)bond_grad(p0, pm1, P.bond_r0, P.bond_k, gx, gy, gz);
+            if (f0 & 1) eb += (double)bond_grad(p0, pp1, P.bond_r0, P.bond_k, gx, gy, gz);
+        }
+        if (P.use_angle) {
+            F3 fi, fk;
+            if (fm2 & 2) { // angle (i-2,i-1,i): this bead is the k end
+                (void)angle_forces(pm2, pm1, p0, P.ang_th0, P.ang_k, fi, fk);
+                gx -= fk.x;
+                gy -= fk.y;
+                gz -= fk.z;
+            }
+            if (fm1 & 2) { // angle (i-1,i,i+1): this bead is the middle
+                (void)angle_forces(pm1, p0, pp1, P.ang_th0, P.ang_k, fi, fk);
+                gx += fi.x + fk.x;
+                gy += fi.y + fk.y;
+                gz += fi.z + fk.z;
+            }
+            if (f0 & 2) { // angle (i,i+1,i+2): this bead is the i end; it also owns the energy
+                ea += (double)angle_forces(p0, pp1, pp2, P.ang_th0, P.ang_k, fi, fk);
+                gx -= fi.x;
+                gy -= fi.y;
+                gz -= fi.z;
+            }
+        }
+        g[3 * i] += gx;
+        g[3 * i + 1] += gy;
+        g[3 * i + 2] += gz;
+    }
+    const double sb = block_sum<256>(eb, s_w);
+    const double sa = block_sum<256>(ea, s_w);
+    if (threadIdx.x == 0) {
+        part[P_BOND * kPartStride + blockIdx.x] = sb;
+        part[P_ANGLE * kPartStride + blockIdx.x] = sa;
+    }
+}
+
+// K4.  Loops as a CSR over the beads that carry at least one loop end: row r = bead row_bead[r],
+// entries [row_start[r], row_start[r+1]) = (partner, r0).  Each loop appears in two rows; each row
+// books half of the loop's energy.  Algorithmic traffic 64 B/loop.
+__global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, const float4 *__restrict__ pos4,
+                                               const int *__restrict__ row_bead, const int *__restrict__ row_start,
+                                               const int *__restrict__ partner, const float *__restrict__ r0,
+                                               float *__restrict__ g, double *__restrict__ part,
+                                               const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    double e = 0.0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) {
+        const int b = row_bead[r];
+        const F3 pb = f3(pos4[b]);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int q = row_start[r]; q < row_start[r + 1]; ++q)
+            e += 0.5 * (double)bond_grad(pb, f3(pos4[partner[q]]), r0[q], P.loop_k, gx, gy, gz);
+        g[3 * b] += gx;
+        g[3 * b + 1] += gy;
+        g[3 * b + 2] += gz;
+    }
+    const double s = block_sum<256>(e, s_w);
+    if (threadIdx.x == 0) part[P_LOOP * kPartStride + blockIdx.x] = s;
+}
+
+// K5.  Container (model.py:454-456), B-lamina "sin" shell (model.py:503-505), central force
+// (model.py:584-586) on r = |x - centre|; afterwards the gradient of bead i is final, so the kernel
+// also produces the three reductions the line search needs: g.d, g.g, x.x.
+// Algorithmic traffic: read 16 B pos4, read-modify-write 12 B gradient (+12 B d when DOTS).
+template <bool DOTS>
+__global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 *__restrict__ pos4,
+                                                 const float *__restrict__ cf_w, float *__restrict__ g,
+                                                 const float *__restrict__ d, double *__restrict__ part,
+                                                 const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    const int n = P.n;
+    double ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
+    const bool any = P.use_container | P.use_lamina | P.use_central;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = pos4[i];
+        float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
+        if (any) {
+            const float dx = p.x - P.cx, dy = p.y - P.cy, dz = p.z - P.cz;
+            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+            const float r = r2 * rinv;
+            float dEdr = 0.f;
+            if (P.use_container) {
+                const float o = fmaxf(r - P.sc_R2, 0.f), in = fmaxf(P.sc_R1 - r, 0.f);
+                ec += (double)(P.sc_C * (o * o + in * in));
+                dEdr += 2.f * P.sc_C * (o - in);
+            }
+            if (P.use_lamina) {
+                const int s = (__float_as_int(p.w) & 7) - 2;
+                if (s < 0) {
+                    const float w = 3.14159265358979f / (P.ibl_R2 - P.ibl_R1);
+                    float sn, cs;
+                    sincosf(w * (r - P.ibl_R1), &sn, &cs);
+                    const float s2 = sn * sn, s4 = s2 * s2;
+                    el += (double)(P.ibl_B * (s4 * s4 - 1.f));
+                    dEdr += P.ibl_B * 8.f * s4 * s2 * sn * cs * w;
+                }
+            }
+            if (P.use_central) {
+                const float q = r - P.cf_R1, gw = P.cf_G * cf_w[i];
+                ef += (double)(gw * q * q);
+                dEdr += 2.f * gw * q;
+            }
+            const float s = dEdr * rinv; // r == 0 => (dx,dy,dz) == 0 => zero gradient
+            gx = fmaf(s, dx, gx);
+            gy = fmaf(s, dy, gy);
+            gz = fmaf(s, dz, gz);
+            g[3 * i] = gx;
+            g[3 * i + 1] = gy;
+            g[3 * i + 2] = gz;
+        }
+        if (DOTS) {
+            const float d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2];
+            gd += (double)gx * d0 + (double)gy * d1 + (double)gz * d2;
+            gg += (double)gx * gx + (double)gy * gy + (double)gz * gz;
+            xx += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
+        }
+    }
+    const double sc = block_sum<256>(ec, s_w);
+    const double sl = block_sum<256>(el, s_w);
+    const double sf = block_sum<256>(ef, s_w);
+    if (threadIdx.x == 0) {
+        part[P_CONT * kPartStride + blockIdx.x] = sc;
+        part[P_LAM * kPartStride + blockIdx.x] = sl;
+        part[P_CENT * kPartStride + blockIdx.x] = sf;
+    }
+    if (DOTS) {
+        const double s1 = block_sum<256>(gd, s_w);
+        const double s2 = block_sum<256>(gg, s_w);
+        const double s3 = block_sum<256>(xx, s_w);
+        if (threadIdx.x == 0) {
+            part[P_GD * kPartStride + blockIdx.x] = s1;
+            part[P_GG * kPartStride + blockIdx.x] = s2;
+            part[P_XX * kPartStride + blockIdx.x] = s3;
+        }
+    }
+}
+
+} // namespace mmx

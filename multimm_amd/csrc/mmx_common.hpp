@@ -1,0 +1,169 @@
+// mmx_common.hpp -- shared device/host structures and wave-level helpers (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMX_M 6                    // L-BFGS history (liblbfgs default m, used by OpenMM)
+#define MMX_NBASIS (2 * MMX_M + 1) // basis {S_0..S_5, Y_0..Y_5, g}
+#define MMX_NROWS 3                // Gram rows recomputed per accepted iteration: s_new, y_new, g
+
+namespace mmx {
+
+constexpr int kPartStride = 16384; // max per-slot block partials
+constexpr int kWave = 64;
+
+// Partial-sum slots (double, one value per block) written by the force kernels.
+enum PartSlot {
+    P_EV = 0, P_GAUSS, P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT, // == MMX_T_* order
+    P_GD, P_GG, P_XX,                                                 // g.d, g.g, x.x
+    P_NSLOTS
+};
+
+// Minimizer phases (device-side state machine, one transition per evaluation).
+enum Phase { PH_IDLE = 0, PH_INIT = 1, PH_LINESEARCH = 2, PH_DONE = 3 };
+
+struct GridParams {
+    float ox, oy, oz; // origin (bbox min)
+    float h, inv_h;   // cell edge >= max cutoff
+    int nx, ny, nz, ncells;
+};
+
+// Force-field constants, passed by value as kernel arguments.
+struct FFParams {
+    int n;
+    int use_ev, ev_pmode; // pmode: 6 / 3 integer fast paths, 0 generic pow
+    float ev_eps, ev_sigma, ev_rs, ev_power, ev_rc2; // rc2 = +inf when NoCutoff
+    int use_gauss;
+    float g_c2;      // -log2(e) / (2 rc^2)
+    float g_inv_rc2; // 1 / rc^2
+    float g_rc2;     // cutoff^2 (+inf when NoCutoff)
+    float rc2max;    // max of the two cutoffs, squared
+    float table[25]; // amplitude E(s_i+2, s_j+2)
+    int use_bond, use_angle;
+    float bond_r0, bond_k, ang_th0, ang_k;
+    float loop_k;
+    int use_container, use_lamina, use_central;
+    float sc_C, sc_R1, sc_R2;
+    float ibl_B, ibl_R1, ibl_R2;
+    float cf_G, cf_R1;
+    float cx, cy, cz;
+};
+
+// Device-resident minimizer state; mirrored to pinned host memory when polled.
+struct MinState {
+    int phase;
+    int accepted;   // 1: the evaluation just controlled ended an iteration -> history/direction kernels run
+    int store_hist; // 1: store (s,y) of the accepted step in slot `end`
+    int status;
+    int iters, evals, ls_count, k, end, bound, max_iters;
+    int n_items;    // non-bonded work items of the last cell build
+    int ncells, max_per_cell;
+    int nan_seen;
+    int pad0;
+    double fx;      // energy at the last accepted point
+    double ftrial;  // energy of the last evaluation
+    double finit, dginit, step, epsilon;
+    double gnorm, xnorm;
+    double cell_edge;
+    double eterms[8];       // per-term energies of the last evaluation
+    double eterms_acc[8];   // ... at the last accepted point
+    double ys[MMX_M];
+    double gram[MMX_NBASIS * MMX_NBASIS];
+    double coef[MMX_NBASIS];
+};
+
+// ---- wave helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Orders LDS traffic between lanes of ONE wave (no s_barrier needed: a wave's DS ops retire in order).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Block-wide sum of one double per thread; result valid on thread 0.  Fixed order => deterministic.
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v, double *lds /* [BLOCK/64] */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) r += lds[w];
+    }
+    return r;
+}
+
+// Monotone float <-> uint encoding for atomicMin/atomicMax on floats.
+__device__ __forceinline__ unsigned enc_ordered(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+constexpr unsigned kEncPosInf = 0xFF800000u; // enc(+inf)
+constexpr unsigned kEncNegInf = 0x007FFFFFu; // enc(-inf)
+
+// Grid derived from the bounding box; every thread that calls it gets identical values.
+__device__ __forceinline__ GridParams grid_from_bbox(const unsigned *bbox, float hmin, int maxcells) {
+    GridParams G;
+    G.ox = dec_ordered(bbox[0]);
+    G.oy = dec_ordered(bbox[1]);
+    G.oz = dec_ordered(bbox[2]);
+    float ex = dec_ordered(bbox[3]) - G.ox, ey = dec_ordered(bbox[4]) - G.oy, ez = dec_ordered(bbox[5]) - G.oz;
+    if (!(ex >= 0.f) || !(ex < 1e30f)) ex = 0.f; // empty / non-finite box: one cell
+    if (!(ey >= 0.f) || !(ey < 1e30f)) ey = 0.f;
+    if (!(ez >= 0.f) || !(ez < 1e30f)) ez = 0.f;
+    float h = hmin;
+    for (int it = 0; it < 200; ++it) {
+        float fx = floorf(ex / h) + 1.f, fy = floorf(ey / h) + 1.f, fz = floorf(ez / h) + 1.f;
+        if (fx * fy * fz <= (float)maxcells) {
+            G.nx = (int)fx;
+            G.ny = (int)fy;
+            G.nz = (int)fz;
+            break;
+        }
+        h *= 1.25f;
+        G.nx = G.ny = G.nz = 1;
+    }
+    G.h = h;
+    G.inv_h = 1.0f / h;
+    G.ncells = G.nx * G.ny * G.nz;
+    return G;
+}
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) {
+    int c = (int)floorf((p - o) * inv_h);
+    return min(max(c, 0), n - 1);
+}
+
+} // namespace mmx

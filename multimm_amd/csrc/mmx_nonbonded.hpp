@@ -1,0 +1,232 @@
+// mmx_nonbonded.hpp -- K2 (cell-list pair kernel) and K2x (exact all-pairs kernel).
+//
+// Pair physics (reference: model.py:199 EV power law; model.py:246-250 / 322-328 compartment Gaussians):
+//   E_ev  = eps*(sigma/(r+r_small))^p            F_i += p*E_ev/((r+r_small) r) * d,   d = x_i - x_j
+//   E_g   = -A(s_i,s_j)*exp(-r^2/(2 rc^2))       F_i += -(A/rc^2)*exp(.) * d
+// Every bead sums over its full neighbour shell (each pair is visited from both ends, energies are
+// halved): no atomics, no write conflicts, summation order fixed by the in-cell bead order.
+#pragma once
+#include "mmx_common.hpp"
+
+namespace mmx {
+
+template <int PMODE>
+__device__ __forceinline__ float ev_pow(float t, float p) {
+    if (PMODE == 6) {
+        const float t2 = t * t;
+        return t2 * t2 * t2;
+    } else if (PMODE == 3) {
+        return t * t * t;
+    } else {
+        return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(t)); // v_exp_f32(p * v_log_f32(t))
+    }
+}
+
+struct PairAcc {
+    float fx, fy, fz, eev, eg;
+};
+
+// One (i,j) interaction accumulated on the i side.  `wi`/`wj` are the packed (bead<<3 | label+2) words;
+// equal words mean the same bead (self term skipped).  tab5 points at row s_i of the amplitude table.
+template <int PMODE, bool EV, bool GAUSS>
+__device__ __forceinline__ void pair_accum(const FFParams &P, const float4 pi, const int wi, const float4 q,
+                                           const float *tab5, PairAcc &a) {
+    const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
+    const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const int wj = __float_as_int(q.w);
+    if (r2 < P.rc2max && wj != wi) {
+        const float r2s = fmaxf(r2, 1e-20f);
+        const float rinv = __builtin_amdgcn_rsqf(r2s);
+        const float r = r2s * rinv;
+        float fs = 0.f;
+        if (EV) {
+            const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
+            float E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+            E = r2 < P.ev_rc2 ? E : 0.f;
+            a.eev += E;
+            fs = P.ev_power * E * u * rinv;
+        }
+        if (GAUSS) {
+            const float A = tab5[wj & 7];
+            float g = A * __builtin_amdgcn_exp2f(r2 * P.g_c2);
+            g = r2 < P.g_rc2 ? g : 0.f;
+            a.eg -= g;
+            fs = fmaf(-g, P.g_inv_rc2, fs);
+        }
+        a.fx = fmaf(fs, dx, a.fx);
+        a.fy = fmaf(fs, dy, a.fy);
+        a.fz = fmaf(fs, dz, a.fz);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 v1: one 192-thread block per work item {cell, chunk of <=64 home beads}; wave w sweeps the
+// z-layer cz+w-1 of the 27-cell stencil (3 x-contiguous runs of sorted beads each).  Neighbour
+// beads are gathered 64 at a time with one coalesced float4 load per lane into a per-wave LDS tile
+// and consumed as broadcast ds_read_b128.  The three partial forces meet in LDS and wave 0 writes
+// g = -F; energies leave through wave-shuffle reductions as one double per block.
+// ------------------------------------------------------------------------------------------------
+template <int PMODE, bool EV, bool GAUSS>
+__global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4 *__restrict__ pos4,
+                                                  const int *__restrict__ perm, const int *__restrict__ start,
+                                                  const int2 *__restrict__ items,
+                                                  const GridParams *__restrict__ grid,
+                                                  const MinState *__restrict__ st, float *__restrict__ g,
+                                                  double *__restrict__ part) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float4 s_tile[3][64];
+    __shared__ float s_red[2][5][64];
+    __shared__ float s_tab[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 25) s_tab[threadIdx.x] = P.table[threadIdx.x];
+    const GridParams G = *grid;
+    const int n_items = st->n_items;
+    __syncthreads();
+    double acc_ev = 0.0, acc_g = 0.0;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int2 it = items[item];
+        const int c = it.x;
+        const int cs = start[c], ce = start[c + 1];
+        const int hidx = cs + it.y * 64 + lane;
+        const bool act = hidx < ce;
+        const int bead = act ? perm[hidx] : 0;
+        float4 pi = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-1));
+        if (act) pi = pos4[bead];
+        const int wi = __float_as_int(pi.w);
+        const float *tab5 = s_tab + 5 * (act ? (wi & 7) : 0);
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        const int zz = cz + wave - 1;
+        PairAcc a = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (zz >= 0 && zz < G.nz) {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = cy + dy;
+                if (yy < 0 || yy >= G.ny) continue;
+                const int row = (zz * G.ny + yy) * G.nx;
+                const int rs = start[row + x0], re = start[row + x1 + 1];
+                for (int base = rs; base < re; base += 64) {
+                    const int j = base + lane;
+                    float4 pj = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-2));
+                    if (j < re) pj = pos4[perm[j]];
+                    wave_lds_sync(); // previous tile fully consumed
+                    s_tile[wave][lane] = pj;
+                    wave_lds_sync();
+                    const int cnt = min(64, re - base);
+#pragma unroll 4
+                    for (int t = 0; t < cnt; ++t) {
+                        const float4 q = s_tile[wave][t];
+                        pair_accum<PMODE, EV, GAUSS>(P, pi, wi, q, tab5, a);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // s_red free (previous item consumed)
+        if (wave > 0) {
+            s_red[wave - 1][0][lane] = a.fx;
+            s_red[wave - 1][1][lane] = a.fy;
+            s_red[wave - 1][2][lane] = a.fz;
+            s_red[wave - 1][3][lane] = a.eev;
+            s_red[wave - 1][4][lane] = a.eg;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float fx = a.fx + s_red[0][0][lane] + s_red[1][0][lane];
+            const float fy = a.fy + s_red[0][1][lane] + s_red[1][1][lane];
+            const float fz = a.fz + s_red[0][2][lane] + s_red[1][2][lane];
+            const float ev = a.eev + s_red[0][3][lane] + s_red[1][3][lane];
+            const float eg = a.eg + s_red[0][4][lane] + s_red[1][4][lane];
+            if (act) {
+                g[3 * bead] = -fx;
+                g[3 * bead + 1] = -fy;
+                g[3 * bead + 2] = -fz;
+            }
+            const float sev = wave_sum(act ? ev : 0.f), seg = wave_sum(act ? eg : 0.f);
+            acc_ev += 0.5 * (double)sev;
+            acc_g += 0.5 * (double)seg;
+        }
+    }
+    if (threadIdx.x == 0) {
+        part[P_EV * kPartStride + blockIdx.x] = acc_ev;
+        part[P_GAUSS * kPartStride + blockIdx.x] = acc_g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2x: exact all-pairs (NoCutoff, what the reference does).  Block = 256 home beads, blockIdx.y = j
+// slice; j tiles of 256 beads are staged in LDS and broadcast-read.  Partial forces per slice go to
+// fpart[slice][bead] and are folded in a fixed order by k_nb_allpairs_fold.
+// ------------------------------------------------------------------------------------------------
+template <int PMODE, bool EV, bool GAUSS>
+__global__ __launch_bounds__(256) void k_nb_allpairs(const FFParams P, const float4 *__restrict__ pos4, int tiles_per_slice,
+                                                     float4 *__restrict__ fpart, float2 *__restrict__ epart,
+                                                     const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float4 s_tile[256];
+    __shared__ float s_tab[32];
+    if (threadIdx.x < 25) s_tab[threadIdx.x] = P.table[threadIdx.x];
+    const int n = P.n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < n;
+    float4 pi = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-1));
+    if (act) pi = pos4[i];
+    const int wi = __float_as_int(pi.w);
+    __syncthreads();
+    const float *tab5 = s_tab + 5 * (act ? (wi & 7) : 0);
+    PairAcc a = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int t0 = blockIdx.y * tiles_per_slice;
+    for (int tt = 0; tt < tiles_per_slice; ++tt) {
+        const int jb = (t0 + tt) * 256;
+        if (jb >= n) break;
+        const int j = jb + threadIdx.x;
+        __syncthreads();
+        // padded entries sit at -1e18: r2 ~ 1e36 stays finite; the inactive-i mask below removes them
+        s_tile[threadIdx.x] = j < n ? pos4[j] : make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-2));
+        __syncthreads();
+        const int cnt = min(256, n - jb);
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {
+            const float4 q = s_tile[t];
+            pair_accum<PMODE, EV, GAUSS>(P, pi, wi, q, tab5, a);
+        }
+    }
+    if (act) {
+        const size_t o = (size_t)blockIdx.y * (size_t)n + (size_t)i;
+        fpart[o] = make_float4(a.fx, a.fy, a.fz, 0.f);
+        epart[o] = make_float2(a.eev, a.eg);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nb_allpairs_fold(int n, int nslices, const float4 *__restrict__ fpart,
+                                                          const float2 *__restrict__ epart, float *__restrict__ g,
+                                                          double *__restrict__ part,
+                                                          const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    double ev = 0.0, eg = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float fx = 0.f, fy = 0.f, fz = 0.f, e1 = 0.f, e2 = 0.f;
+        for (int s = 0; s < nslices; ++s) {
+            const float4 f = fpart[(size_t)s * n + i];
+            const float2 e = epart[(size_t)s * n + i];
+            fx += f.x;
+            fy += f.y;
+            fz += f.z;
+            e1 += e.x;
+            e2 += e.y;
+        }
+        g[3 * i] = -fx;
+        g[3 * i + 1] = -fy;
+        g[3 * i + 2] = -fz;
+        ev += 0.5 * (double)e1;
+        eg += 0.5 * (double)e2;
+    }
+    const double sev = block_sum<256>(ev, s_w);
+    const double seg = block_sum<256>(eg, s_w);
+    if (threadIdx.x == 0) {
+        part[P_EV * kPartStride + blockIdx.x] = sev;
+        part[P_GAUSS * kPartStride + blockIdx.x] = seg;
+    }
+}
+
+} // namespace mmx

@@ -1,0 +1,278 @@
+"""ctypes binding of libmmx.so (C ABI: include/mmx.h) -- the device engine behind ``PLATFORM = MI355X``.
+
+The engine plays the part OpenMM's Context/Platform plays for the reference
+(``model.py:863-892``): it owns the system on one GPU, evaluates energies/forces and runs the
+L-BFGS minimizer.  Failures surface as ``MMXError`` (the analogue of ``openmm.OpenMMException`` that
+``bridge.py:65`` catches); there is no CPU fallback in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .system import ChromatinSystem
+
+N_TERMS = 8
+N_KERNELS = 8
+TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")
+KERNEL_NAMES = ("cell_build", "nonbonded", "backbone", "loops", "confine", "lbfgs", "reduce", "_")
+K_CELL_BUILD, K_NONBONDED, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE = range(7)
+COMP_COB, COMP_SCB = 0, 1
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmmx.so")
+
+
+class MMXError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmmx error {code}: {message}")
+        self.code = code
+
+
+class MMXStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("evaluations", C.c_int32), ("status", C.c_int32), ("n_beads", C.c_int32),
+        ("e_initial", C.c_double), ("e_final", C.c_double), ("gnorm_final", C.c_double),
+        ("xnorm_final", C.c_double), ("rms_force", C.c_double), ("seconds", C.c_double),
+        ("energy_terms", C.c_double * N_TERMS),
+        ("kernel_ns", C.c_double * N_KERNELS), ("kernel_samples", C.c_int64 * N_KERNELS),
+        ("kernel_launches", C.c_int64 * N_KERNELS),
+    ]
+
+    def as_dict(self) -> dict:
+        d = {k: getattr(self, k) for k in ("iterations", "evaluations", "status", "n_beads", "e_initial",
+                                           "e_final", "gnorm_final", "xnorm_final", "rms_force", "seconds")}
+        d["energy_terms"] = {TERM_NAMES[i]: self.energy_terms[i] for i in range(N_TERMS)}
+        d["kernel_us_mean"] = {
+            KERNEL_NAMES[i]: (self.kernel_ns[i] / self.kernel_samples[i] / 1e3 if self.kernel_samples[i] else None)
+            for i in range(N_KERNELS - 1)}
+        d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(N_KERNELS - 1)}
+        return d
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against include/mmx.h
+_P = C.c_void_p
+SIGNATURES = {
+    "mmx_abi_version": (C.c_int, []),
+    "mmx_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "mmx_destroy": (C.c_int, [_P]),
+    "mmx_last_error": (C.c_char_p, [_P]),
+    "mmx_set_positions": (C.c_int, [_P, _P]),
+    "mmx_get_positions": (C.c_int, [_P, _P]),
+    "mmx_set_labels": (C.c_int, [_P, _P]),
+    "mmx_set_backbone": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                   C.c_int32]),
+    "mmx_set_backbone_masks": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
+    "mmx_set_loops": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float]),
+    "mmx_set_excluded_volume": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "mmx_set_compartments": (C.c_int, [_P, C.c_int32, _P, C.c_float, C.c_float]),
+    "mmx_set_container": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
+    "mmx_set_lamina": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
+    "mmx_set_central": (C.c_int, [_P, C.c_float, C.c_float, _P, _P]),
+    "mmx_disable_term": (C.c_int, [_P, C.c_int32]),
+    "mmx_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "mmx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
+    "mmx_compute": (C.c_int, [_P, _P, _P]),
+    "mmx_minimize": (C.c_int, [_P, C.c_double, C.c_int32, C.POINTER(MMXStats)]),
+    "mmx_time_kernel": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mmx_nb_census": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Loads libmmx.so (never builds, never falls back).  Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise MMXError(-2, f"{p} not found: build it with `python -m multimm_amd.build` "
+                           "(hipcc, gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """One minimizer context on one MI355X."""
+
+    def __init__(self, n_beads: int, device: int = 0):
+        self._lib = load_library()
+        self._h = _P()
+        self.n = int(n_beads)
+        rc = self._lib.mmx_create(self.n, int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.mmx_last_error(None)
+            raise MMXError(rc, msg.decode() if msg else "mmx_create failed")
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = self._lib.mmx_last_error(self._h)
+            raise MMXError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mmx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- system description --------------------------------------------------------------------
+    def set_positions(self, xyz_nm):
+        a = _f32(xyz_nm).reshape(self.n, 3)
+        self._chk(self._lib.mmx_set_positions(self._h, a.ctypes.data))
+
+    def get_positions(self) -> np.ndarray:
+        out = np.empty((self.n, 3), dtype=np.float32)
+        self._chk(self._lib.mmx_get_positions(self._h, out.ctypes.data))
+        return out
+
+    def set_labels(self, labels):
+        a = np.ascontiguousarray(labels, dtype=np.int8)
+        if a.shape != (self.n,):
+            raise ValueError("labels must be [N]")
+        self._chk(self._lib.mmx_set_labels(self._h, a.ctypes.data))
+
+    def set_backbone(self, chr_ends, r0, k_bond, theta0, k_angle, use_bond=True, use_angle=True):
+        a = np.ascontiguousarray(chr_ends, dtype=np.int32)
+        self._chk(self._lib.mmx_set_backbone(self._h, a.ctypes.data, len(a), r0, k_bond, theta0, k_angle,
+                                             int(use_bond), int(use_angle)))
+
+    def set_backbone_masks(self, flags, r0, k_bond, theta0, k_angle, use_bond=True, use_angle=True):
+        a = np.ascontiguousarray(flags, dtype=np.uint8)
+        if a.shape != (self.n,):
+            raise ValueError("flags must be [N]")
+        self._chk(self._lib.mmx_set_backbone_masks(self._h, a.ctypes.data, r0, k_bond, theta0, k_angle,
+                                                   int(use_bond), int(use_angle)))
+
+    def set_loops(self, m, n, r0, k_loop):
+        m = np.ascontiguousarray(m, dtype=np.int32)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        r0 = _f32(r0)
+        if not (len(m) == len(n) == len(r0)):
+            raise ValueError("loop arrays must have equal length")
+        self._chk(self._lib.mmx_set_loops(self._h, m.ctypes.data, n.ctypes.data, r0.ctypes.data, len(m), k_loop))
+
+    def set_excluded_volume(self, eps, sigma, r_small, power, cutoff_nm):
+        self._chk(self._lib.mmx_set_excluded_volume(self._h, eps, sigma, r_small, power, cutoff_nm))
+
+    def set_compartments(self, mode, E, rc, cutoff_nm):
+        e = _f32(E)
+        if len(e) != (2 if mode == COMP_COB else 4):
+            raise ValueError("COB takes E[2], SCB takes E[4]")
+        self._chk(self._lib.mmx_set_compartments(self._h, mode, e.ctypes.data, rc, cutoff_nm))
+
+    def set_container(self, C_, R1, R2, centre):
+        c = _f32(centre)
+        self._chk(self._lib.mmx_set_container(self._h, C_, R1, R2, c.ctypes.data))
+
+    def set_lamina(self, B, R1, R2, centre):
+        c = _f32(centre)
+        self._chk(self._lib.mmx_set_lamina(self._h, B, R1, R2, c.ctypes.data))
+
+    def set_central(self, G, R1, centre, w):
+        c = _f32(centre)
+        ww = _f32(w)
+        if ww.shape != (self.n,):
+            raise ValueError("w must be [N]")
+        self._chk(self._lib.mmx_set_central(self._h, G, R1, c.ctypes.data, ww.ctypes.data))
+
+    def disable_term(self, term: int):
+        self._chk(self._lib.mmx_disable_term(self._h, term))
+
+    def set_option(self, key: str, value: float):
+        self._chk(self._lib.mmx_set_option(self._h, key.encode(), float(value)))
+
+    def get_option(self, key: str) -> float:
+        v = C.c_double()
+        self._chk(self._lib.mmx_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # -- compute / minimize ----------------------------------------------------------------------
+    def compute(self, forces: bool = True):
+        """Returns (energy_terms[8] float64, forces [N,3] float32 or None) at the current positions."""
+        et = np.zeros(N_TERMS, dtype=np.float64)
+        f = np.empty((self.n, 3), dtype=np.float32) if forces else None
+        self._chk(self._lib.mmx_compute(self._h, f.ctypes.data if forces else None, et.ctypes.data))
+        return et, f
+
+    def minimize(self, tolerance: float = 10.0, max_iters: int = 0) -> MMXStats:
+        st = MMXStats()
+        self._chk(self._lib.mmx_minimize(self._h, float(tolerance), int(max_iters), C.byref(st)))
+        return st
+
+    def time_kernel(self, kernel: int, reps: int = 20):
+        us, by = C.c_double(), C.c_double()
+        self._chk(self._lib.mmx_time_kernel(self._h, kernel, reps, C.byref(us), C.byref(by)))
+        return us.value, by.value
+
+    def nb_census(self) -> dict:
+        nc, mx = C.c_int64(), C.c_int32()
+        edge, cand, within = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self._lib.mmx_nb_census(self._h, C.byref(nc), C.byref(mx), C.byref(edge), C.byref(cand),
+                                          C.byref(within)))
+        return dict(n_cells=nc.value, max_per_cell=mx.value, cell_edge=edge.value, pair_candidates=cand.value,
+                    pairs_within_cutoff=within.value)
+
+    # -- convenience: upload a whole ChromatinSystem the way add_forcefield orders it ---------------
+    def load_system(self, s: ChromatinSystem):
+        """Installs every enabled term of ``s`` in the order of ``add_forcefield`` (model.py:812-857)."""
+        if s.n_beads != self.n:
+            raise ValueError("system size does not match the engine")
+        ff = s.ff
+        R1, R2, r_comp = s.radii
+        centre = s.centre
+        self.set_positions(s.positions)
+        self.set_labels(s.labels)
+        if ff.EV_USE_EXCLUDED_VOLUME:  # sigma is LE_HARMONIC_BOND_R0 (sic), model.py:175
+            self.set_excluded_volume(ff.EV_EPSILON, ff.LE_HARMONIC_BOND_R0, ff.EV_R_SMALL, ff.EV_POWER, ff.NB_CUTOFF)
+        if ff.COB_USE_COMPARTMENT_BLOCKS:
+            self.set_compartments(COMP_COB, [ff.COB_EA, ff.COB_EB], r_comp, ff.NB_CUTOFF)
+        if ff.SCB_USE_SUBCOMPARTMENT_BLOCKS:
+            self.set_compartments(COMP_SCB, [ff.SCB_EA1, ff.SCB_EA2, ff.SCB_EB1, ff.SCB_EB2], r_comp, ff.NB_CUTOFF)
+        if ff.CHB_USE_CHROMOSOMAL_BLOCKS:
+            raise NotImplementedError("CHB chromosomal blocks are not on the MI355X path yet (SURVEY.md 8 f1)")
+        if ff.SC_USE_SPHERICAL_CONTAINER:
+            self.set_container(ff.SC_SCALE, R1, R2, centre)
+        if ff.IBL_USE_B_LAMINA_INTERACTION:
+            self.set_lamina(ff.IBL_SCALE, R1, R2, centre)
+        if ff.CF_USE_CENTRAL_FORCE:
+            if s.chrom_strength is None:
+                raise ValueError("central force needs chrom_strength")
+            self.set_central(ff.CF_STRENGTH, R1, centre, s.chrom_strength)
+        if ff.POL_USE_HARMONIC_BOND or ff.POL_USE_HARMONIC_ANGLE:
+            self.set_backbone(s.chr_ends, ff.POL_HARMONIC_BOND_R0, ff.POL_HARMONIC_BOND_K,
+                              ff.POL_HARMONIC_ANGLE_R0, ff.POL_HARMONIC_ANGLE_CONSTANT_K,
+                              ff.POL_USE_HARMONIC_BOND, ff.POL_USE_HARMONIC_ANGLE)
+        if ff.LE_USE_HARMONIC_BOND and s.n_loops:
+            self.set_loops(s.loop_m, s.loop_n, s.loop_rest_lengths(), ff.LE_HARMONIC_BOND_K)
+        return self
+
+
+def engine_for(system: ChromatinSystem, device: int = 0) -> Engine:
+    return Engine(system.n_beads, device).load_system(system)

@@ -1,0 +1,557 @@
+/*
+ * mmx_oracle.c -- fp64 CPU restatement of the MultiMM force field + OpenMM minimizer semantics.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's shared object.
+ * The product path (multimm_amd/ + libmmx.so) never imports, links or calls it.
+ *
+ * PARITY UNPINNED: the reference (/root/reference, SFGLab/MultiMM v2.0.2) holds no golden
+ * energies/forces/coordinates for this path (its tests assert file existence only,
+ * tests/test_simulations.py:23,41,59-63,83,103-105) and its arithmetic lives in the third-party
+ * dependency OpenMM 8.5.1 (uv.lock:2462-2463) which is not installed here.  This file therefore
+ * restates (a) the energy expressions and index sets written in the reference's
+ * src/multimm/model.py and (b) the published semantics of the OpenMM primitives those
+ * expressions are handed to (HarmonicBondForce / HarmonicAngleForce conventions, NoCutoff /
+ * CutoffNonPeriodic plain truncation, LocalEnergyMinimizer = liblbfgs L-BFGS with backtracking
+ * strong-Wolfe line search).  It is pinned instead by hand-derivable known-answer tests and by
+ * central finite differences of its own energy (tests/test_oracle_*.py).
+ *
+ * Units: nm, kJ/mol, rad.  Force on bead i is F_i = -dE/dx_i.
+ *
+ * Reference call sites followed (all under /root/reference/src/multimm/):
+ *   EV power law            model.py:164-217  (sigma = LE_HARMONIC_BOND_R0, model.py:175)
+ *   compartment Gaussians   model.py:219-294 (COB), 296-384 (SCB)
+ *   spherical container     model.py:453-466
+ *   B-lamina "sin" shell    model.py:468-507
+ *   central force           model.py:552-623 (harmonic form :579-586)
+ *   backbone bonds          model.py:625-636
+ *   loop bonds              model.py:638-659
+ *   angles                  model.py:708-720
+ *   term order / plain sum  model.py:812-857
+ *   minimizeEnergy()        model.py:886  -> OpenMM LocalEnergyMinimizer (liblbfgs)
+ *   Hilbert start           initial_structure_tools.py:157-166 -> hilbertcurve 2.0.5 (uv.lock:1129-1130)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum {
+    ORC_T_EV = 0,
+    ORC_T_GAUSS = 1,
+    ORC_T_BOND = 2,
+    ORC_T_ANGLE = 3,
+    ORC_T_LOOP = 4,
+    ORC_T_CONTAINER = 5,
+    ORC_T_LAMINA = 6,
+    ORC_T_CENTRAL = 7,
+    ORC_N_TERMS = 8
+};
+
+/* Mirrored field-for-field by oracle/oracle.py:OrcSystem (ctypes.Structure). */
+typedef struct {
+    int32_t n;
+    const int8_t *labels;    /* [n] in {-2..2}, may be NULL (all 0) */
+    const uint8_t *bb_flags; /* [n] bit0: bond (i,i+1) present; bit1: angle (i,i+1,i+2) present */
+    int32_t use_bond, use_angle;
+    double bond_r0, bond_k, angle_theta0, angle_k;
+    int32_t n_loops;
+    const int32_t *loop_m;
+    const int32_t *loop_n;
+    const double *loop_r0;
+    double loop_k;
+    int32_t use_ev;
+    double ev_eps, ev_sigma, ev_rsmall, ev_power, ev_cutoff; /* cutoff <= 0: NoCutoff (all pairs) */
+    int32_t use_gauss;
+    double gauss_table[25]; /* amplitude E(s_i+2, s_j+2) >= 0; E_pair = -E*exp(-r^2/(2 rc^2)) */
+    double gauss_rc, gauss_cutoff;
+    int32_t use_container;
+    double sc_C, sc_R1, sc_R2;
+    int32_t use_lamina;
+    double ibl_B, ibl_R1, ibl_R2;
+    int32_t use_central;
+    double cf_G, cf_R1;
+    const double *cf_w; /* [n] chrom_strength */
+    double centre[3];   /* mass_center, model.py:759 */
+} orc_system;
+
+typedef struct {
+    int32_t iterations;  /* accepted L-BFGS iterations (liblbfgs "progress" calls) */
+    int32_t evaluations; /* energy+force evaluations */
+    int32_t status;      /* 0 converged, 1 max iterations, <0 liblbfgs-style line-search error */
+    double e_initial, e_final, gnorm_final, xnorm_final, seconds;
+} orc_min_stats;
+
+int orc_n_terms(void) { return ORC_N_TERMS; }
+int orc_sizeof_system(void) { return (int)sizeof(orc_system); }
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Hilbert curve: hilbertcurve 2.0.5 HilbertCurve(p, n).point_from_distance (Skilling 2004,
+ * "Programming the Hilbert curve"), called at initial_structure_tools.py:158-161 with p=8, n=3.
+ * out[h*n + i] = coordinate i of distance h.
+ * ------------------------------------------------------------------------------------------ */
+void orc_hilbert_points(int64_t n_points, int p, int n, int32_t *out) {
+    for (int64_t h = 0; h < n_points; ++h) {
+        uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        /* _hilbert_integer_to_transpose: MSB-first bit string of length p*n; x[i] takes bits i, i+n, ... */
+        for (int b = 0; b < p * n; ++b) {
+            int bit = (int)((h >> (p * n - 1 - b)) & 1);
+            x[b % n] = (x[b % n] << 1) | (uint32_t)bit;
+        }
+        uint32_t z = 2u << (p - 1);
+        /* Gray decode by H ^ (H/2) */
+        uint32_t t = x[n - 1] >> 1;
+        for (int i = n - 1; i > 0; --i) x[i] ^= x[i - 1];
+        x[0] ^= t;
+        /* undo excess work */
+        for (uint32_t q = 2; q != z; q <<= 1) {
+            uint32_t pm = q - 1;
+            for (int i = n - 1; i >= 0; --i) {
+                if (x[i] & q) {
+                    x[0] ^= pm;
+                } else {
+                    t = (x[0] ^ x[i]) & pm;
+                    x[0] ^= t;
+                    x[i] ^= t;
+                }
+            }
+        }
+        for (int i = 0; i < n; ++i) out[h * n + i] = (int32_t)x[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone masks from chr_ends, reproducing the reference's index quirks exactly:
+ *   bond  (i,i+1)     for i in [0,N-2] unless i in chr_ends                      model.py:628-629
+ *   angle (i,i+1,i+2) for i in [0,N-3] unless i in chr_ends or i in chr_ends-1   model.py:711-712
+ * ------------------------------------------------------------------------------------------ */
+void orc_backbone_flags(int32_t n, const int32_t *chr_ends, int32_t n_ends, uint8_t *flags) {
+    for (int32_t i = 0; i < n; ++i) {
+        int in_ends = 0, in_ends_m1 = 0;
+        for (int32_t k = 0; k < n_ends; ++k) {
+            if (chr_ends[k] == i) in_ends = 1;
+            if (chr_ends[k] - 1 == i) in_ends_m1 = 1;
+        }
+        uint8_t f = 0;
+        if (i <= n - 2 && !in_ends) f |= 1;
+        if (i <= n - 3 && !in_ends && !in_ends_m1) f |= 2;
+        flags[i] = f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pair terms.  d = x_i - x_j, r = |d|.
+ *   EV   (model.py:199): E = eps*(sigma/(r+r_small))^p ; dE/dr = -p*E/(r+r_small)
+ *   Gauss(model.py:246-250, 322-328): E = -Eab*exp(-r^2/(2 rc^2)) ; dE/dr = +Eab*(r/rc^2)*exp(.)
+ * Returns fscale with F_i += fscale*d, F_j -= fscale*d.  Plain truncation at the per-term
+ * cutoff (OpenMM CutoffNonPeriodic: pairs with r >= cutoff are skipped, no shift).
+ * At r == 0 the direction is undefined: energy is counted, force is zero.
+ * ------------------------------------------------------------------------------------------ */
+static inline double pair_terms(const orc_system *s, double r2, int li, int lj, double *e_ev, double *e_g) {
+    double fs = 0.0;
+    double r = sqrt(r2);
+    if (s->use_ev && (s->ev_cutoff <= 0.0 || r < s->ev_cutoff)) {
+        double u = 1.0 / (r + s->ev_rsmall);
+        double E = s->ev_eps * pow(s->ev_sigma * u, s->ev_power);
+        *e_ev += E;
+        if (r > 0.0) fs += s->ev_power * E * u / r;
+    }
+    if (s->use_gauss && (s->gauss_cutoff <= 0.0 || r < s->gauss_cutoff)) {
+        double Eab = s->gauss_table[li * 5 + lj];
+        if (Eab != 0.0) {
+            double inv = 1.0 / (s->gauss_rc * s->gauss_rc);
+            double g = Eab * exp(-0.5 * r2 * inv);
+            *e_g -= g;
+            fs -= g * inv;
+        }
+    }
+    return fs;
+}
+
+/* All pairs, each bead sums over every other bead (pairs visited twice, energies halved):
+ * embarrassingly parallel and summation order independent of the thread count. */
+static void nonbonded_allpairs(const orc_system *s, const double *x, double *F, double *eterms) {
+    const int n = s->n;
+    double e_ev = 0.0, e_g = 0.0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_ev, e_g)
+    for (int i = 0; i < n; ++i) {
+        const int li = s->labels ? s->labels[i] + 2 : 2;
+        double fx = 0, fy = 0, fz = 0, ev = 0, eg = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            double r2 = dx * dx + dy * dy + dz * dz;
+            const int lj = s->labels ? s->labels[j] + 2 : 2;
+            double fs = pair_terms(s, r2, li, lj, &ev, &eg);
+            fx += fs * dx;
+            fy += fs * dy;
+            fz += fs * dz;
+        }
+        F[3 * i] += fx;
+        F[3 * i + 1] += fy;
+        F[3 * i + 2] += fz;
+        e_ev += 0.5 * ev;
+        e_g += 0.5 * eg;
+    }
+    eterms[ORC_T_EV] += e_ev;
+    eterms[ORC_T_GAUSS] += e_g;
+}
+
+/* Cell list with edge >= max cutoff, 27-cell stencil.  Same per-bead full-shell summation. */
+static int nonbonded_cells(const orc_system *s, const double *x, double *F, double *eterms) {
+    const int n = s->n;
+    double rc = 0.0;
+    if (s->use_ev) rc = s->ev_cutoff > rc ? s->ev_cutoff : rc;
+    if (s->use_gauss) rc = s->gauss_cutoff > rc ? s->gauss_cutoff : rc;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (x[3 * i + k] < lo[k]) lo[k] = x[3 * i + k];
+            if (x[3 * i + k] > hi[k]) hi[k] = x[3 * i + k];
+        }
+    double h = rc;
+    int64_t nc[3];
+    for (;;) {
+        for (int k = 0; k < 3; ++k) nc[k] = (int64_t)floor((hi[k] - lo[k]) / h) + 1;
+        if (nc[0] * nc[1] * nc[2] <= 16 * 1024 * 1024) break;
+        h *= 2.0;
+    }
+    const int64_t ncell = nc[0] * nc[1] * nc[2];
+    int32_t *cell_of = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *start = (int32_t *)calloc((size_t)ncell + 1, sizeof(int32_t));
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    if (!cell_of || !start || !order) {
+        free(cell_of);
+        free(start);
+        free(order);
+        return -1;
+    }
+    for (int i = 0; i < n; ++i) {
+        int64_t c[3];
+        for (int k = 0; k < 3; ++k) {
+            c[k] = (int64_t)floor((x[3 * i + k] - lo[k]) / h);
+            if (c[k] < 0) c[k] = 0;
+            if (c[k] >= nc[k]) c[k] = nc[k] - 1;
+        }
+        cell_of[i] = (int32_t)((c[2] * nc[1] + c[1]) * nc[0] + c[0]);
+        start[cell_of[i] + 1]++;
+    }
+    for (int64_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+    {
+        int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncell);
+        memcpy(cur, start, sizeof(int32_t) * (size_t)ncell);
+        for (int i = 0; i < n; ++i) order[cur[cell_of[i]]++] = i; /* stable: ascending bead id per cell */
+        free(cur);
+    }
+    double e_ev = 0.0, e_g = 0.0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e_ev, e_g)
+    for (int i = 0; i < n; ++i) {
+        const int li = s->labels ? s->labels[i] + 2 : 2;
+        int64_t ci = cell_of[i];
+        int64_t cx = ci % nc[0], cy = (ci / nc[0]) % nc[1], cz = ci / (nc[0] * nc[1]);
+        double fx = 0, fy = 0, fz = 0, ev = 0, eg = 0;
+        for (int64_t zz = cz - 1; zz <= cz + 1; ++zz) {
+            if (zz < 0 || zz >= nc[2]) continue;
+            for (int64_t yy = cy - 1; yy <= cy + 1; ++yy) {
+                if (yy < 0 || yy >= nc[1]) continue;
+                int64_t x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= nc[0] ? nc[0] - 1 : cx + 1;
+                int64_t row = (zz * nc[1] + yy) * nc[0];
+                for (int32_t q = start[row + x0]; q < start[row + x1 + 1]; ++q) {
+                    int j = order[q];
+                    if (j == i) continue;
+                    double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1],
+                           dz = x[3 * i + 2] - x[3 * j + 2];
+                    double r2 = dx * dx + dy * dy + dz * dz;
+                    if (r2 >= rc * rc) continue;
+                    const int lj = s->labels ? s->labels[j] + 2 : 2;
+                    double fs = pair_terms(s, r2, li, lj, &ev, &eg);
+                    fx += fs * dx;
+                    fy += fs * dy;
+                    fz += fs * dz;
+                }
+            }
+        }
+        F[3 * i] += fx;
+        F[3 * i + 1] += fy;
+        F[3 * i + 2] += fz;
+        e_ev += 0.5 * ev;
+        e_g += 0.5 * eg;
+    }
+    eterms[ORC_T_EV] += e_ev;
+    eterms[ORC_T_GAUSS] += e_g;
+    free(cell_of);
+    free(start);
+    free(order);
+    return 0;
+}
+
+/* HarmonicBondForce: E = 1/2 k (r-r0)^2 (OpenMM convention).  F_i = -k (r-r0) d/r, d = x_i - x_j. */
+static inline double harmonic_pair(const double *x, double *F, int i, int j, double r0, double k) {
+    double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double dr = r - r0;
+    if (r > 0.0) {
+        double fs = -k * dr / r;
+        F[3 * i] += fs * dx;
+        F[3 * i + 1] += fs * dy;
+        F[3 * i + 2] += fs * dz;
+        F[3 * j] -= fs * dx;
+        F[3 * j + 1] -= fs * dy;
+        F[3 * j + 2] -= fs * dz;
+    }
+    return 0.5 * k * dr * dr;
+}
+
+/* HarmonicAngleForce: E = 1/2 k (theta-theta0)^2, theta at the middle bead j of (i,j,k).
+ * Force form of OpenMM's angle kernels: a = x_i-x_j, b = x_k-x_j, c = a x b, |c| clamped to >= 1e-6,
+ *   F_i = -dEdtheta * (a x c)/(|a|^2 |c|),  F_k = -dEdtheta * (c x b)/(|b|^2 |c|),  F_j = -(F_i+F_k).
+ * (signs fixed by the finite-difference test, tests/test_oracle.py) */
+static inline double harmonic_angle(const double *x, double *F, int i, int j, int k, double th0, double kk) {
+    double a[3], b[3], c[3];
+    for (int q = 0; q < 3; ++q) {
+        a[q] = x[3 * i + q] - x[3 * j + q];
+        b[q] = x[3 * k + q] - x[3 * j + q];
+    }
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+    double cn = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    double dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    double theta = atan2(cn, dot);
+    double rp = cn < 1e-6 ? 1e-6 : cn;
+    double aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    double bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+    double dEdth = kk * (theta - th0);
+    if (aa > 0.0 && bb > 0.0) {
+        double ta = -dEdth / (aa * rp), tc = -dEdth / (bb * rp);
+        double fi[3], fk[3];
+        fi[0] = ta * (a[1] * c[2] - a[2] * c[1]);
+        fi[1] = ta * (a[2] * c[0] - a[0] * c[2]);
+        fi[2] = ta * (a[0] * c[1] - a[1] * c[0]);
+        fk[0] = tc * (c[1] * b[2] - c[2] * b[1]);
+        fk[1] = tc * (c[2] * b[0] - c[0] * b[2]);
+        fk[2] = tc * (c[0] * b[1] - c[1] * b[0]);
+        for (int q = 0; q < 3; ++q) {
+            F[3 * i + q] += fi[q];
+            F[3 * k + q] += fk[q];
+            F[3 * j + q] -= fi[q] + fk[q];
+        }
+    }
+    return 0.5 * kk * (theta - th0) * (theta - th0);
+}
+
+/* Total evaluation.  F[3n] (may be NULL) receives the total force, eterms[ORC_N_TERMS] the per-term
+ * energies in the order of model.py:812-857 collapsed onto the ORC_T_* slots.  Returns 0 / -1. */
+int orc_eval(const orc_system *s, const double *x, double *F_out, double *eterms) {
+    const int n = s->n;
+    double *F = F_out ? F_out : (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    if (!F) return -1;
+    memset(F, 0, sizeof(double) * 3 * (size_t)n);
+    for (int t = 0; t < ORC_N_TERMS; ++t) eterms[t] = 0.0;
+
+    if (s->use_ev || s->use_gauss) {
+        int allpairs = (s->use_ev && s->ev_cutoff <= 0.0) || (s->use_gauss && s->gauss_cutoff <= 0.0);
+        if (allpairs)
+            nonbonded_allpairs(s, x, F, eterms);
+        else if (nonbonded_cells(s, x, F, eterms) != 0) {
+            if (!F_out) free(F);
+            return -1;
+        }
+    }
+    if (s->bb_flags) {
+        if (s->use_bond)
+            for (int i = 0; i + 1 < n; ++i)
+                if (s->bb_flags[i] & 1) eterms[ORC_T_BOND] += harmonic_pair(x, F, i, i + 1, s->bond_r0, s->bond_k);
+        if (s->use_angle)
+            for (int i = 0; i + 2 < n; ++i)
+                if (s->bb_flags[i] & 2)
+                    eterms[ORC_T_ANGLE] += harmonic_angle(x, F, i, i + 1, i + 2, s->angle_theta0, s->angle_k);
+    }
+    for (int l = 0; l < s->n_loops; ++l)
+        eterms[ORC_T_LOOP] += harmonic_pair(x, F, s->loop_m[l], s->loop_n[l], s->loop_r0[l], s->loop_k);
+
+    if (s->use_container || s->use_lamina || s->use_central) {
+        for (int i = 0; i < n; ++i) {
+            double d[3] = {x[3 * i] - s->centre[0], x[3 * i + 1] - s->centre[1], x[3 * i + 2] - s->centre[2]};
+            double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            double dEdr = 0.0;
+            if (s->use_container) { /* model.py:454-456 */
+                double o = r - s->sc_R2 > 0 ? r - s->sc_R2 : 0.0, in = s->sc_R1 - r > 0 ? s->sc_R1 - r : 0.0;
+                eterms[ORC_T_CONTAINER] += s->sc_C * (o * o + in * in);
+                dEdr += 2.0 * s->sc_C * (o - in);
+            }
+            if (s->use_lamina && s->labels && s->labels[i] < 0) { /* model.py:503-505 */
+                double w = M_PI / (s->ibl_R2 - s->ibl_R1);
+                double u = w * (r - s->ibl_R1);
+                double sn = sin(u), cs = cos(u);
+                double s2 = sn * sn, s4 = s2 * s2;
+                eterms[ORC_T_LAMINA] += s->ibl_B * (s4 * s4 - 1.0);
+                dEdr += s->ibl_B * 8.0 * s4 * s2 * sn * cs * w;
+            }
+            if (s->use_central && s->cf_w) { /* model.py:584-586 */
+                double q = r - s->cf_R1;
+                eterms[ORC_T_CENTRAL] += s->cf_G * s->cf_w[i] * q * q;
+                dEdr += 2.0 * s->cf_G * s->cf_w[i] * q;
+            }
+            if (r > 0.0)
+                for (int q = 0; q < 3; ++q) F[3 * i + q] -= dEdr * d[q] / r;
+        }
+    }
+    if (!F_out) free(F);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Minimizer: OpenMM LocalEnergyMinimizer::minimize(context, tolerance, maxIterations) as reached
+ * from model.py:886, i.e. liblbfgs lbfgs() with m = 6, linesearch =
+ * LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE, ftol = 1e-4, wolfe = 0.9, max_linesearch = 40,
+ * min_step = 1e-20, max_step = 1e20, epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2)).
+ * No constraints in this system, so OpenMM's restraint outer loop runs once.
+ * f = total potential energy, gradient = -F.
+ * ------------------------------------------------------------------------------------------ */
+static double dotn(const double *a, const double *b, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+static double eval_fg(const orc_system *s, const double *x, double *g, double *F, int *nev) {
+    double et[ORC_N_TERMS];
+    orc_eval(s, x, F, et);
+    const int64_t n3 = 3 * (int64_t)s->n;
+    for (int64_t i = 0; i < n3; ++i) g[i] = -F[i];
+    double f = 0.0;
+    for (int t = 0; t < ORC_N_TERMS; ++t) f += et[t];
+    ++*nev;
+    return f;
+}
+
+static double now_s(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+int orc_minimize(const orc_system *s, double *x, double tolerance, int max_iterations, orc_min_stats *st) {
+    enum { M = 6, MAX_LS = 40 };
+    const double ftol = 1e-4, wolfe = 0.9, min_step = 1e-20, max_step = 1e20;
+    const int64_t n3 = 3 * (int64_t)s->n;
+    double t0 = now_s();
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n3 * (5 + 2 * M));
+    if (!buf) return -1;
+    double *g = buf, *F = g + n3, *d = F + n3, *xp = d + n3, *gp = xp + n3;
+    double *S = gp + n3, *Y = S + (int64_t)M * n3;
+    double ys_h[M], alpha[M];
+    int nev = 0, status = 1;
+
+    double norm = dotn(x, x, n3) / (double)s->n;
+    norm = norm < 1.0 ? 1.0 : sqrt(norm);
+    const double epsilon = tolerance / norm;
+
+    double fx = eval_fg(s, x, g, F, &nev);
+    st->e_initial = fx;
+    for (int64_t i = 0; i < n3; ++i) d[i] = -g[i];
+    double xnorm = sqrt(dotn(x, x, n3)), gnorm = sqrt(dotn(g, g, n3));
+    if (xnorm < 1.0) xnorm = 1.0;
+    int k = 1, end = 0, iters = 0;
+    if (gnorm / xnorm <= epsilon) {
+        status = 0;
+        goto done;
+    }
+    double step = 1.0 / sqrt(dotn(d, d, n3));
+    for (;;) {
+        memcpy(xp, x, sizeof(double) * (size_t)n3);
+        memcpy(gp, g, sizeof(double) * (size_t)n3);
+        /* line_search_backtracking (strong Wolfe) */
+        int ls = 0, count = 0;
+        {
+            const double dec = 0.5, inc = 2.1;
+            double dginit = dotn(g, d, n3);
+            if (step <= 0.0) ls = -1;
+            else if (dginit > 0.0) ls = -2; /* LBFGSERR_INCREASEGRADIENT */
+            else {
+                double finit = fx, dgtest = ftol * dginit, width;
+                for (;;) {
+                    for (int64_t i = 0; i < n3; ++i) x[i] = xp[i] + step * d[i];
+                    fx = eval_fg(s, x, g, F, &nev);
+                    ++count;
+                    if (fx > finit + step * dgtest) {
+                        width = dec;
+                    } else {
+                        double dg = dotn(g, d, n3);
+                        if (dg < wolfe * dginit) width = inc;
+                        else if (dg > -wolfe * dginit) width = dec;
+                        else { ls = count; break; }
+                    }
+                    if (step < min_step) { ls = -3; break; }
+                    if (step > max_step) { ls = -4; break; }
+                    if (MAX_LS <= count) { ls = -5; break; }
+                    step *= width;
+                }
+            }
+        }
+        if (ls < 0) { /* revert to the previous point, as liblbfgs does */
+            memcpy(x, xp, sizeof(double) * (size_t)n3);
+            memcpy(g, gp, sizeof(double) * (size_t)n3);
+            fx = eval_fg(s, x, g, F, &nev);
+            --nev; /* bookkeeping re-evaluation, not part of the algorithm */
+            status = ls;
+            break;
+        }
+        ++iters;
+        xnorm = sqrt(dotn(x, x, n3));
+        gnorm = sqrt(dotn(g, g, n3));
+        if (xnorm < 1.0) xnorm = 1.0;
+        if (gnorm / xnorm <= epsilon) { status = 0; break; }
+        if (max_iterations != 0 && max_iterations < k + 1) { status = 1; break; }
+        double *sk = S + (int64_t)end * n3, *yk = Y + (int64_t)end * n3;
+        for (int64_t i = 0; i < n3; ++i) {
+            sk[i] = x[i] - xp[i];
+            yk[i] = g[i] - gp[i];
+        }
+        double ys = dotn(yk, sk, n3), yy = dotn(yk, yk, n3);
+        ys_h[end] = ys;
+        int bound = M <= k ? M : k;
+        ++k;
+        end = (end + 1) % M;
+        for (int64_t i = 0; i < n3; ++i) d[i] = -g[i];
+        int j = end;
+        for (int i = 0; i < bound; ++i) {
+            j = (j + M - 1) % M;
+            alpha[j] = dotn(S + (int64_t)j * n3, d, n3) / ys_h[j];
+            const double *yj = Y + (int64_t)j * n3;
+            for (int64_t q = 0; q < n3; ++q) d[q] -= alpha[j] * yj[q];
+        }
+        double sc = ys / yy;
+        for (int64_t q = 0; q < n3; ++q) d[q] *= sc;
+        for (int i = 0; i < bound; ++i) {
+            double beta = dotn(Y + (int64_t)j * n3, d, n3) / ys_h[j];
+            const double *sj = S + (int64_t)j * n3;
+            for (int64_t q = 0; q < n3; ++q) d[q] += (alpha[j] - beta) * sj[q];
+            j = (j + 1) % M;
+        }
+        step = 1.0;
+    }
+done:
+    st->iterations = iters;
+    st->evaluations = nev;
+    st->status = status;
+    st->e_final = fx;
+    st->gnorm_final = gnorm;
+    st->xnorm_final = xnorm;
+    st->seconds = now_s() - t0;
+    free(buf);
+    return 0;
+}

@@ -1,0 +1,176 @@
+"""ctypes wrapper of the fp64 C oracle (oracle/mmx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from multimm_amd/.  PARITY UNPINNED (no reference golden vectors exist and
+OpenMM is not installed): pinned by known-answer tests and finite differences instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libmmx_oracle.so")
+N_TERMS = 8
+TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")
+
+
+class OrcSystem(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("labels", C.c_void_p), ("bb_flags", C.c_void_p),
+        ("use_bond", C.c_int32), ("use_angle", C.c_int32),
+        ("bond_r0", C.c_double), ("bond_k", C.c_double), ("angle_theta0", C.c_double), ("angle_k", C.c_double),
+        ("n_loops", C.c_int32), ("loop_m", C.c_void_p), ("loop_n", C.c_void_p), ("loop_r0", C.c_void_p),
+        ("loop_k", C.c_double),
+        ("use_ev", C.c_int32), ("ev_eps", C.c_double), ("ev_sigma", C.c_double), ("ev_rsmall", C.c_double),
+        ("ev_power", C.c_double), ("ev_cutoff", C.c_double),
+        ("use_gauss", C.c_int32), ("gauss_table", C.c_double * 25), ("gauss_rc", C.c_double),
+        ("gauss_cutoff", C.c_double),
+        ("use_container", C.c_int32), ("sc_C", C.c_double), ("sc_R1", C.c_double), ("sc_R2", C.c_double),
+        ("use_lamina", C.c_int32), ("ibl_B", C.c_double), ("ibl_R1", C.c_double), ("ibl_R2", C.c_double),
+        ("use_central", C.c_int32), ("cf_G", C.c_double), ("cf_R1", C.c_double), ("cf_w", C.c_void_p),
+        ("centre", C.c_double * 3),
+    ]
+
+
+class OrcMinStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("evaluations", C.c_int32), ("status", C.c_int32),
+                ("e_initial", C.c_double), ("e_final", C.c_double), ("gnorm_final", C.c_double),
+                ("xnorm_final", C.c_double), ("seconds", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "mmx_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", HERE, "-s", "-B" if force else "-s"], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.orc_eval.restype = C.c_int
+        _lib.orc_eval.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_minimize.restype = C.c_int
+        _lib.orc_minimize.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_double, C.c_int, C.POINTER(OrcMinStats)]
+        _lib.orc_hilbert_points.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        _lib.orc_backbone_flags.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        assert _lib.orc_sizeof_system() == C.sizeof(OrcSystem), "OrcSystem layout mismatch"
+    return _lib
+
+
+class Oracle:
+    """fp64 CPU evaluation of a multimm_amd.system.ChromatinSystem (duck-typed: only reads attributes)."""
+
+    def __init__(self, system, cutoff=None, as_float32_inputs: bool = True):
+        """``as_float32_inputs``: round positions / rest lengths / constants through fp32 first, so the
+        oracle sees exactly the numbers the fp32 device path receives (arithmetic stays fp64)."""
+        self.s = system
+        ff = system.ff
+        n = system.n_beads
+        r32 = (lambda v: float(np.float32(v))) if as_float32_inputs else float
+        R1, R2, r_comp = system.radii
+        self._keep = {}
+        o = OrcSystem()
+        o.n = n
+        self._keep["labels"] = np.ascontiguousarray(system.labels, dtype=np.int8)
+        o.labels = self._keep["labels"].ctypes.data
+        self._keep["flags"] = np.ascontiguousarray(system.flags, dtype=np.uint8)
+        o.bb_flags = self._keep["flags"].ctypes.data
+        o.use_bond = int(ff.POL_USE_HARMONIC_BOND)
+        o.use_angle = int(ff.POL_USE_HARMONIC_ANGLE)
+        o.bond_r0, o.bond_k = r32(ff.POL_HARMONIC_BOND_R0), r32(ff.POL_HARMONIC_BOND_K)
+        o.angle_theta0, o.angle_k = r32(ff.POL_HARMONIC_ANGLE_R0), r32(ff.POL_HARMONIC_ANGLE_CONSTANT_K)
+        if ff.LE_USE_HARMONIC_BOND and system.n_loops:
+            self._keep["m"] = np.ascontiguousarray(system.loop_m, dtype=np.int32)
+            self._keep["n"] = np.ascontiguousarray(system.loop_n, dtype=np.int32)
+            r0 = np.asarray(system.loop_rest_lengths(), dtype=np.float64)
+            if as_float32_inputs:
+                r0 = r0.astype(np.float32).astype(np.float64)
+            self._keep["r0"] = np.ascontiguousarray(r0)
+            o.n_loops = system.n_loops
+            o.loop_m, o.loop_n, o.loop_r0 = (self._keep[k].ctypes.data for k in ("m", "n", "r0"))
+            o.loop_k = r32(ff.LE_HARMONIC_BOND_K)
+        rc = ff.NB_CUTOFF if cutoff is None else cutoff
+        o.use_ev = int(ff.EV_USE_EXCLUDED_VOLUME)
+        o.ev_eps, o.ev_sigma = r32(ff.EV_EPSILON), r32(ff.LE_HARMONIC_BOND_R0)  # sigma quirk: model.py:175
+        o.ev_rsmall, o.ev_power, o.ev_cutoff = r32(ff.EV_R_SMALL), r32(ff.EV_POWER), r32(rc) if rc > 0 else rc
+        tab = system.gauss_table()
+        o.use_gauss = int(ff.COB_USE_COMPARTMENT_BLOCKS or ff.SCB_USE_SUBCOMPARTMENT_BLOCKS)
+        for i in range(25):
+            o.gauss_table[i] = r32(tab.flat[i])
+        o.gauss_rc, o.gauss_cutoff = r32(r_comp), r32(rc) if rc > 0 else rc
+        o.use_container = int(ff.SC_USE_SPHERICAL_CONTAINER)
+        o.sc_C, o.sc_R1, o.sc_R2 = r32(ff.SC_SCALE), r32(R1), r32(R2)
+        o.use_lamina = int(ff.IBL_USE_B_LAMINA_INTERACTION)
+        o.ibl_B, o.ibl_R1, o.ibl_R2 = r32(ff.IBL_SCALE), r32(R1), r32(R2)
+        o.use_central = int(ff.CF_USE_CENTRAL_FORCE)
+        if o.use_central:
+            w = np.asarray(system.chrom_strength, dtype=np.float64)
+            if as_float32_inputs:
+                w = w.astype(np.float32).astype(np.float64)
+            self._keep["w"] = np.ascontiguousarray(w)
+            o.cf_w = self._keep["w"].ctypes.data
+        o.cf_G, o.cf_R1 = r32(ff.CF_STRENGTH), r32(R1)
+        c = system.centre
+        for k in range(3):
+            o.centre[k] = r32(c[k])
+        self.o = o
+        self.f32 = as_float32_inputs
+
+    def _pos(self, positions=None) -> np.ndarray:
+        p = self.s.positions if positions is None else positions
+        p = np.asarray(p)
+        if self.f32:
+            p = p.astype(np.float32)
+        return np.ascontiguousarray(p, dtype=np.float64).reshape(self.s.n_beads, 3)
+
+    def eval(self, positions=None):
+        """Returns (energy_terms[8], forces [N,3]) in fp64."""
+        x = self._pos(positions)
+        F = np.zeros_like(x)
+        et = np.zeros(N_TERMS)
+        rc = lib().orc_eval(C.byref(self.o), x.ctypes.data, F.ctypes.data, et.ctypes.data)
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+        return et, F
+
+    def energy(self, positions=None) -> float:
+        x = self._pos(positions)
+        et = np.zeros(N_TERMS)
+        lib().orc_eval(C.byref(self.o), x.ctypes.data, None, et.ctypes.data)
+        return float(et.sum())
+
+    def minimize(self, tolerance: float = 10.0, max_iters: int = 0, positions=None):
+        """fp64 liblbfgs restatement.  Returns (positions [N,3], OrcMinStats)."""
+        x = self._pos(positions).copy()
+        st = OrcMinStats()
+        rc = lib().orc_minimize(C.byref(self.o), x.ctypes.data, float(tolerance), int(max_iters), C.byref(st))
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+        return x, st
+
+
+def hilbert_points_c(n_points: int, p: int = 8, n: int = 3) -> np.ndarray:
+    out = np.zeros((n_points, n), dtype=np.int32)
+    lib().orc_hilbert_points(n_points, p, n, out.ctypes.data)
+    return out
+
+
+def backbone_flags_c(n_beads: int, chr_ends) -> np.ndarray:
+    ce = np.ascontiguousarray(chr_ends, dtype=np.int32)
+    out = np.zeros(n_beads, dtype=np.uint8)
+    lib().orc_backbone_flags(n_beads, ce.ctypes.data, len(ce), out.ctypes.data)
+    return out
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())

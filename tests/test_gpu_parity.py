@@ -1,0 +1,140 @@
+"""GPU parity: libmmx.so (HIP, through the C ABI) against the fp64 CPU oracle on identical fp32 inputs.
+
+Tolerances (stated per north_star: "within a stated fp32 tolerance"):
+  energies  : |E_gpu - E_ref| <= 2e-5 * sum_terms|E_ref| + 1e-3 kJ/mol
+  forces    : max_i |F_gpu - F_ref|_inf <= 2e-4 * max_i |F_ref|_inf + 5e-2 kJ/mol/nm
+The absolute force floor covers fp32 round-off of bond lengths: k_bond * ulp(r) ~ 3e5 * 1e-8 nm.
+"""
+import numpy as np
+import pytest
+
+from multimm_amd import synthetic_system
+from multimm_amd.engine import Engine, engine_for, TERM_NAMES
+
+pytestmark = pytest.mark.gpu
+
+E_RTOL, E_ATOL = 2e-5, 1e-3
+F_RTOL, F_ATOL = 2e-4, 5e-2
+
+
+def _check(system, cutoff, label):
+    from oracle.oracle import Oracle
+    s = system.with_ff(NB_CUTOFF=cutoff)
+    et_ref, F_ref = Oracle(s).eval()
+    with engine_for(s) as eng:
+        et, F = eng.compute()
+    scale_e = np.abs(et_ref).sum()
+    for t in range(8):
+        assert abs(et[t] - et_ref[t]) <= E_RTOL * scale_e + E_ATOL, (
+            f"{label}: term {TERM_NAMES[t]} gpu={et[t]!r} ref={et_ref[t]!r}")
+    ferr = np.abs(F.astype(np.float64) - F_ref).max()
+    fmax = np.abs(F_ref).max()
+    assert ferr <= F_RTOL * fmax + F_ATOL, f"{label}: force err {ferr} (max |F| {fmax})"
+    return et, F
+
+
+ALL_ON = dict(SC_USE_SPHERICAL_CONTAINER=True, COB_USE_COMPARTMENT_BLOCKS=True, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
+              IBL_USE_B_LAMINA_INTERACTION=True, CF_USE_CENTRAL_FORCE=True)
+
+
+@pytest.mark.parametrize("n", [64, 512, 4096])
+@pytest.mark.parametrize("cutoff", [0.0, 0.6])
+def test_all_terms_lattice(n, cutoff):
+    """Hilbert lattice start (every angle exactly pi or pi/2, every bond exactly r0)."""
+    _check(synthetic_system("gw_200k", n_beads=n, **ALL_ON), cutoff, f"lattice n={n} rc={cutoff}")
+
+
+@pytest.mark.parametrize("n", [64, 512, 4096, 20000])
+@pytest.mark.parametrize("cutoff", [0.0, 0.6])
+def test_all_terms_jittered(n, cutoff):
+    if n == 20000 and cutoff == 0.0:
+        pytest.skip("all-pairs oracle at 20k is minutes of CPU")
+    _check(synthetic_system("gw_200k", n_beads=n, jitter=0.03, seed=3, **ALL_ON), cutoff, f"jitter n={n} rc={cutoff}")
+
+
+def test_region_preset_circle_start():
+    """BASELINE config 1: EV + bonds + angles + loops, circle start (config_specific_region.ini)."""
+    for n in (500, 5000):
+        _check(synthetic_system("region_5k", n_beads=n, start="circle"), 0.0, f"circle n={n}")
+        _check(synthetic_system("region_5k", n_beads=n, start="circle"), 0.6, f"circle n={n}")
+
+
+def test_single_terms():
+    base = dict(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+                EV_USE_EXCLUDED_VOLUME=False)
+    for on in ("POL_USE_HARMONIC_BOND", "POL_USE_HARMONIC_ANGLE", "LE_USE_HARMONIC_BOND", "EV_USE_EXCLUDED_VOLUME",
+               "SC_USE_SPHERICAL_CONTAINER", "COB_USE_COMPARTMENT_BLOCKS", "SCB_USE_SUBCOMPARTMENT_BLOCKS",
+               "IBL_USE_B_LAMINA_INTERACTION", "CF_USE_CENTRAL_FORCE"):
+        kw = dict(base)
+        kw[on] = True
+        s = synthetic_system("gw_200k", n_beads=3000, jitter=0.02, **kw)
+        et, _ = _check(s, 0.6, on)
+        assert np.count_nonzero(et) <= 1
+
+
+def test_generic_ev_power():
+    for p in (3.0, 4.5):
+        _check(synthetic_system("chr1_50k", n_beads=2000, jitter=0.02, EV_POWER=p), 0.6, f"EV_POWER={p}")
+        _check(synthetic_system("chr1_50k", n_beads=2000, jitter=0.02, EV_POWER=p), 0.0, f"EV_POWER={p}")
+
+
+def test_known_answers_two_and_three_beads():
+    """Hand-derivable values."""
+    from multimm_amd.system import ChromatinSystem, ForceFieldParams
+    ff = ForceFieldParams(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+                          NB_CUTOFF=0.0)
+    s = ChromatinSystem(2, np.array([[0, 0, 0], [0.1, 0, 0.0]]), np.array([0, 2]), np.zeros(2, np.int8), ff=ff)
+    with engine_for(s) as eng:
+        et, F = eng.compute()
+    assert et[0] == pytest.approx(100 * (0.1 / 0.15) ** 6, rel=1e-5)
+    assert abs(F[0, 0]) == pytest.approx(6 * 100 * (0.1 / 0.15) ** 6 / 0.15, rel=1e-5)
+    assert F[0, 0] < 0 < F[1, 0]
+
+
+def test_deterministic_bitwise():
+    s = synthetic_system("gw_200k", n_beads=30000, jitter=0.03, **ALL_ON)
+    outs = []
+    for _ in range(2):
+        with engine_for(s) as eng:
+            et, F = eng.compute()
+            outs.append((et.copy(), F.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_minimize_small_matches_oracle_quality():
+    """Trajectories are not expected to match step for step (fp32 device vs fp64 host L-BFGS); the end
+    state must satisfy the same stop rule and reach a comparable energy."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=2000, jitter=0.01, **ALL_ON)
+    xr, st_ref = Oracle(s).minimize(tolerance=10.0, max_iters=0)
+    with engine_for(s) as eng:
+        st = eng.minimize(tolerance=10.0, max_iters=0)
+        x = eng.get_positions()
+        et, F = eng.compute()
+    assert st.status in (0, -5, -3), st.status
+    assert st.rms_force < 20.0
+    assert st.e_final < st.e_initial
+    # energy reported by the minimizer is the energy of the returned positions
+    assert et.sum() == pytest.approx(st.e_final, rel=1e-5, abs=1e-2)
+    e_ref_at_gpu_x = Oracle(s).energy(x)
+    assert e_ref_at_gpu_x == pytest.approx(st.e_final, rel=2e-5, abs=1e-2)
+    # comparable minimum: within 2 % of the span the oracle covered
+    span = st_ref.e_initial - st_ref.e_final
+    assert st.e_final - st_ref.e_final < 0.02 * span
+
+
+def test_minimize_fixed_iterations_and_errors():
+    s = synthetic_system("chr1_50k", n_beads=5000)
+    with engine_for(s) as eng:
+        st = eng.minimize(tolerance=0.0, max_iters=25)
+        assert st.iterations == 25 and st.status == 1 and st.evaluations >= 26
+        assert st.e_final < st.e_initial
+    from multimm_amd.engine import MMXError
+    with Engine(10) as eng:
+        with pytest.raises(MMXError):
+            eng.compute()  # positions not set
+        with pytest.raises(MMXError):
+            eng.set_loops([0], [0], [0.1], 1.0)  # degenerate loop
+        with pytest.raises(MMXError):
+            eng.set_labels(np.full(10, 3, np.int8))
