@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- minimizer iterations/s on BASELINE.json's genome-wide configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one accepted L-BFGS iteration (liblbfgs "progress" call) of the on-device minimizer
+over a synthetic Hilbert-curve-initialised bead system.  N = 1: BASELINE config 3 (gw_200k: 200 000
+beads, GW preset = EV + compartment blocks + container + lamina + bonds + angles + loops).  N > 1:
+BASELINE config 4, one independent genome-wide replica per GPU with seeds 0..N-1 (the reference's
+ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collective, "weak" scaling.
+`value` is the whole-job rate: total iterations of all ranks / max-over-ranks wall time.
+
+Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
+pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
+"cpu_baseline" = the in-repo fp64 oracle (OpenMM is not installed; kind "port") timed on the host cores
+on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
+NB_BYTES_PER_BEAD = 32.0     # float4 position in + float4 force/energy out
+FLOP_PER_PAIR = 30.0         # SURVEY.md 8(d) per-pair flop count for the VALU view
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="gw_200k")
+    ap.add_argument("--n-beads", type=int, default=0, help="rescale the workload (parity/debug only)")
+    ap.add_argument("--cutoff", type=float, default=0.6, help="pair cutoff in nm; <=0 = NoCutoff all-pairs")
+    ap.add_argument("--jitter", type=float, default=0.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg; 0 disables")
+    ap.add_argument("--profile-every", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(system, budget_s: float) -> dict | None:
+    """fp64 oracle (same cell list, same L-BFGS rule) on all host cores, bounded sample."""
+    if budget_s <= 0:
+        return None
+    from oracle.oracle import Oracle, max_threads
+    orc = Oracle(system)
+    t0 = time.perf_counter()
+    orc.eval()
+    t_eval = time.perf_counter() - t0
+    iters = int(max(2, min(50, budget_s / max(t_eval * 1.3, 1e-3))))
+    t0 = time.perf_counter()
+    _, st = orc.minimize(tolerance=0.0, max_iters=iters)
+    dt = time.perf_counter() - t0
+    return {
+        "value": st.iterations / dt, "unit": "iters/s", "cores": max_threads(), "kind": "port",
+        "sample": f"{st.iterations} L-BFGS iterations ({st.evaluations} evaluations, {dt:.1f} s) of the same "
+                  f"{system.n_beads}-bead system from the same start, fp64 C+OpenMP oracle with the same cutoff "
+                  f"(OpenMM not installed on this box)",
+        "evals_per_s": st.evaluations / dt,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    from multimm_amd import synthetic_system
+    from multimm_amd.engine import K_NONBONDED, K_CELL_BUILD, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE, engine_for
+
+    system = synthetic_system(args.workload, seed=rank, n_beads=args.n_beads or None, jitter=args.jitter,
+                              NB_CUTOFF=args.cutoff)
+    eng = engine_for(system, device=local_rank)
+    eng.set_option("profile", 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: W untimed iterations (also pages in code objects and sizes the pair-kernel grid)
+    if args.warmup > 0:
+        eng.minimize(tolerance=0.0, max_iters=args.warmup)
+    eng.set_option("profile", args.profile_every)
+    barrier()
+    t0 = time.perf_counter()
+    st = eng.minimize(tolerance=0.0, max_iters=args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    iters = st.iterations
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        it = torch.tensor([iters], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        total_iters = float(it.item())
+    else:
+        total_iters = float(iters)
+
+    if rank == 0:
+        d = st.as_dict()
+        n = system.n_beads
+        nb_us = d["kernel_us_mean"]["nonbonded"]
+        census = None
+        try:
+            census = eng.nb_census() if args.cutoff > 0 else None
+        except Exception:
+            census = None
+        roofline = None
+        if nb_us:
+            achieved = NB_BYTES_PER_BEAD * n / (nb_us * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_nb_cells" if args.cutoff > 0 else "k_nb_allpairs",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "launch_us": nb_us,
+                        "samples": int(st.kernel_samples[K_NONBONDED])}
+            if census:
+                pairs = census["pairs_within_cutoff"]  # directed pairs (each pair visited from both ends)
+                tf = pairs * FLOP_PER_PAIR / (nb_us * 1e-6) / 1e12
+                roofline["valu_view"] = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": tf / VALU_PEAK_TFLOPS, "pairs_within_cutoff": pairs,
+                                         "pair_candidates": census["pair_candidates"]}
+        kern = {k: v for k, v in d["kernel_us_mean"].items() if v}
+        ms_per_step = dt * 1e3 / max(iters, 1)
+        out = {
+            "metric": "minimizer iters/sec @ genome-wide N beads",
+            "value": total_iters / dt,
+            "unit": "iters/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{system.name}: {n} beads, Hilbert-curve start, "
+                            f"{'GW preset (EV+COB+container+lamina+bonds+angles+loops)' if 'gw' in args.workload else 'EV+bonds+angles+loops'}, "
+                            f"{system.n_loops} loops, pair cutoff {args.cutoff} nm"
+                            + ("; one independent replica per GPU (seeds 0..N-1), no collective" if world > 1 else ""),
+                "n_beads": n, "cutoff_nm": args.cutoff, "replicas": world,
+            },
+            "iterations": iters, "evaluations": st.evaluations, "evals_per_s": st.evaluations * world / dt,
+            "status": st.status, "e_initial": st.e_initial, "e_final": st.e_final, "rms_force": st.rms_force,
+            "kernel_us_mean": kern,
+            "roofline": roofline,
+        }
+        out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,9 +67,12 @@ def test_single_terms():
                "IBL_USE_B_LAMINA_INTERACTION", "CF_USE_CENTRAL_FORCE"):
         kw = dict(base)
         kw[on] = True
-        s = synthetic_system("gw_200k", n_beads=3000, jitter=0.02, **kw)
+        s = synthetic_system("chr1_50k", n_beads=3000, jitter=0.02, **kw)
+        if on == "CF_USE_CENTRAL_FORCE":
+            from multimm_amd.system import chrom_strength_per_bead, gw_chr_ends
+            s.chrom_strength = chrom_strength_per_bead(gw_chr_ends(3000), 3000)
         et, _ = _check(s, 0.6, on)
-        assert np.count_nonzero(et) <= 1
+        assert np.count_nonzero(et) == 1, (on, et)
 
 
 def test_generic_ev_power():
