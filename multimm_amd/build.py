@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [
         hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-        "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+        "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
         "-o", LIB + ".tmp", SRC,
     ]
     if verbose:

@@ -43,11 +43,16 @@ struct mmx_handle_s {
     uint8_t *flags = nullptr;
     float *cf_w = nullptr;
     // cells
-    int *cell_of = nullptr, *count = nullptr, *cursor = nullptr, *start = nullptr, *istart = nullptr,
+    int *cell_of = nullptr, *count = nullptr, *rank = nullptr, *start = nullptr, *istart = nullptr,
         *perm = nullptr;
     int2 *items = nullptr;
-    GridParams *grid = nullptr;
-    unsigned *bbox = nullptr;
+    int *cstart = nullptr;                       // cluster offsets per cell
+    float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
+    int last_clusters = -1;
+    GridParams *grid = nullptr;  // [2]: grid of this build / of the next one (ping-pong)
+    GridParams *gcur = nullptr;  // grid the last enqueued build used (what the pair kernel reads)
+    int build_idx = 0;
+    float *bbox_part = nullptr;  // [6][ceil(n/256)] per-block bounding boxes of k_pack
     int maxcells = 262144;
     int max_items = 0;
     int last_items = -1;
@@ -167,10 +172,15 @@ void prof_collect(mmx_handle_s *h, mmx_stats *out) {
 template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
-    dim3 b(192), gdim(grid);
 #define NBC(EV, GA)                                                                                         \
-    hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4, h->perm, h->start,    \
-                       h->items, h->grid, h->st, h->g, h->part)
+    do {                                                                                                    \
+        if (h->nb_variant == 1)                                                                             \
+            hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
+                               h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_nb_clusters<PMODE, EV, GA>), dim3(grid), dim3(256), 0, h->stream, P,       \
+                               h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);     \
+    } while (0)
     if (P.use_ev && P.use_gauss) NBC(true, true);
     else if (P.use_ev) NBC(true, false);
     else NBC(false, true);
@@ -191,30 +201,43 @@ void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
 }
 
 int nb_grid(const mmx_handle_s *h) {
-    int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
-    int g = items + items / 4 + 64;
+    if (h->nb_variant == 1) { // v1: one block per {cell, 64-bead chunk}
+        int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
+        int g = items + items / 4 + 64;
+        return std::max(256, std::min(g, kPartStride));
+    }
+    // cluster kernel: 4 clusters (waves) per block, grid-stride beyond the estimate
+    int cl = h->last_clusters > 0 ? h->last_clusters : h->n / 8 + 4096;
+    int g = (cl + cl / 8) / 4 + 64;
     return std::max(256, std::min(g, kPartStride));
 }
 
-void enqueue_build(mmx_handle_s *h, bool move) {
+void enqueue_build(mmx_handle_s *h, bool move, bool init = false) {
     const int n = h->n;
     const int gb = (n + 255) / 256;
     if (move)
         hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
-                           h->pos4, h->bbox, h->st);
+                           h->pos4, h->bbox_part, h->st);
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
-                           h->pos4, h->bbox, h->st);
+                           h->pos4, h->bbox_part, h->st);
     if (has_nb(h) && !all_pairs(h)) {
         const float hm = hmin_of(h);
-        hipLaunchKernelGGL(k_cell_count, dim3(gb), dim3(256), 0, h->stream, n, h->pos4, h->bbox, hm, h->maxcells,
-                           h->cell_of, h->count, h->st);
-        hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox, hm, h->maxcells,
-                           h->count, h->start, h->istart, h->grid, h->st);
-        hipLaunchKernelGGL(k_cell_fill, dim3(gb), dim3(256), 0, h->stream, n, h->cell_of, h->start, h->cursor,
-                           h->perm, h->st);
-        hipLaunchKernelGGL((k_cell_order<kChunk>), dim3(1024), dim3(256), 0, h->stream, h->grid, h->start,
-                           h->istart, h->count, h->cursor, h->perm, h->items, h->deterministic, h->st);
+        GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
+        if (init)
+            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells, cur,
+                               h->st);
+        hipLaunchKernelGGL(k_cell_count, dim3(gb), dim3(256), 0, h->stream, n, h->pos4, cur, h->cell_of, h->rank,
+                           h->count, h->st);
+        hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox_part, gb, hm,
+                           h->maxcells, h->count, h->start, h->istart, h->cstart, cur, next, h->st);
+        hipLaunchKernelGGL(k_cell_fill, dim3(gb), dim3(256), 0, h->stream, n, h->cell_of, h->rank, h->start, h->perm,
+                           h->st);
+        hipLaunchKernelGGL((k_cell_order<kChunk>), dim3(1024), dim3(256), 0, h->stream, cur, h->start, h->istart,
+                           h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
+                           h->deterministic, h->st);
+        h->gcur = cur;
+        h->build_idx++;
     }
 }
 
@@ -275,7 +298,7 @@ void enqueue_eval(mmx_handle_s *h, bool move) {
     A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
 
     on = prof_begin(h, MMX_K_REDUCE, ep);
-    hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, h->stream, A, h->part, h->st);
+    hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
     prof_end(h, on, ep);
 }
 
@@ -286,7 +309,7 @@ void enqueue_accept(mmx_handle_s *h) {
     bool on = prof_begin(h, MMX_K_LBFGS, ep);
     hipLaunchKernelGGL(k_history, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
                        (const float4 *)h->g, (float4 *)h->gp, (float4 *)h->S, (float4 *)h->Y, h->rows, h->st);
-    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(256), 0, h->stream, g4, h->rows, h->st);
+    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, g4, h->rows, h->st);
     hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->g,
                        (const float4 *)h->S, (const float4 *)h->Y, (float4 *)h->d, h->st);
     prof_end(h, on, ep);
@@ -300,6 +323,7 @@ int pull_state(mmx_handle_s *h) {
     HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
+    if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
     return MMX_OK;
 }
 
@@ -323,7 +347,7 @@ int ensure_allpairs_scratch(mmx_handle_s *h) {
 // First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
 int prime_items(mmx_handle_s *h) {
     if (!has_nb(h) || all_pairs(h)) return MMX_OK;
-    enqueue_build(h, false);
+    enqueue_build(h, false, true);
     return pull_state(h);
 }
 
@@ -392,19 +416,21 @@ int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
         HIPCHK(h, dalloc(&h->cell_of, (size_t)h->n));
         HIPCHK(h, dalloc(&h->perm, (size_t)h->n));
         HIPCHK(h, dalloc(&h->count, (size_t)h->maxcells + 1));
-        HIPCHK(h, dalloc(&h->cursor, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->rank, (size_t)h->n));
         HIPCHK(h, dalloc(&h->start, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->istart, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->items, (size_t)h->max_items));
-        HIPCHK(h, dalloc(&h->grid, 1));
-        HIPCHK(h, dalloc(&h->bbox, 8));
+        HIPCHK(h, dalloc(&h->cstart, (size_t)h->maxcells + 1));
+        HIPCHK(h, dalloc(&h->spos4, (size_t)h->n * 8)); // every cluster holds >= 1 bead: <= N clusters
+        HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->cl_hi, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->grid, 2));
+        HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n + 255) / 256)));
         HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
         HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWS * MMX_NBASIS * kPartStride));
         HIPCHK(h, dalloc(&h->st, 1));
         HIPCHK(h, hipHostMalloc((void **)&h->st_host, sizeof(MinState), hipHostMallocDefault));
         std::memset(h->st_host, 0, sizeof(MinState));
-        const unsigned bb[8] = {kEncPosInf, kEncPosInf, kEncPosInf, kEncNegInf, kEncNegInf, kEncNegInf, 0, 0};
-        HIPCHK(h, hipMemcpy(h->bbox, bb, sizeof(bb), hipMemcpyHostToDevice));
         for (int i = 0; i < 256; ++i) {
             EventPair ep{};
             HIPCHK(h, hipEventCreate(&ep.a));
@@ -429,9 +455,9 @@ int mmx_destroy(mmx_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
-                    h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->cursor,   h->start,     h->istart,
-                    h->perm,  h->items,  h->grid,   h->bbox,  h->part,   h->rows,     h->st,        h->row_bead,
-                    h->row_start, h->partner, h->loop_r0, h->fpart, h->epart};
+                    h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank,     h->start,     h->istart,
+                    h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
+                    h->row_start, h->partner, h->loop_r0, h->fpart, h->epart, h->cstart, h->spos4, h->cl_lo, h->cl_hi};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -914,7 +940,7 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
     double *dout = nullptr;
     HIPCHK(h, dalloc(&dout, 2));
     hipLaunchKernelGGL(k_census, dim3(grid_beads(h->n)), dim3(256), 0, h->stream, h->n, h->pos4, h->perm, h->start,
-                       h->cell_of, h->grid, h->P.rc2max, dout);
+                       h->cell_of, h->gcur, h->P.rc2max, dout);
     double res[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

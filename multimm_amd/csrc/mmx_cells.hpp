@@ -10,9 +10,10 @@ namespace mmx {
 template <bool MOVE>
 __global__ __launch_bounds__(256) void k_pack(int n, float *__restrict__ x, const float *__restrict__ xp,
                                               const float *__restrict__ d, const int8_t *__restrict__ labels,
-                                              float4 *__restrict__ pos4, unsigned *__restrict__ bbox,
+                                              float4 *__restrict__ pos4, float *__restrict__ bbox_part,
                                               const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
+    __shared__ float s_bb[6][4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float px = 0.f, py = 0.f, pz = 0.f;
     const bool act = i < n;
@@ -33,116 +34,206 @@ __global__ __launch_bounds__(256) void k_pack(int n, float *__restrict__ x, cons
         const int w = (i << 3) | ((int)labels[i] + 2);
         pos4[i] = make_float4(px, py, pz, __int_as_float(w));
     }
+    // Block bounding box -> bbox_part[k][block] (k = minx,miny,minz,maxx,maxy,maxz); no atomics.
     const float big = 3.0e38f;
-    float mnx = wave_min(act ? px : big), mny = wave_min(act ? py : big), mnz = wave_min(act ? pz : big);
-    float mxx = wave_max(act ? px : -big), mxy = wave_max(act ? py : -big), mxz = wave_max(act ? pz : -big);
-    if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-        atomicMin(&bbox[0], enc_ordered(mnx));
-        atomicMin(&bbox[1], enc_ordered(mny));
-        atomicMin(&bbox[2], enc_ordered(mnz));
-        atomicMax(&bbox[3], enc_ordered(mxx));
-        atomicMax(&bbox[4], enc_ordered(mxy));
-        atomicMax(&bbox[5], enc_ordered(mxz));
+    const float fin = (act && fabsf(px) < big && fabsf(py) < big && fabsf(pz) < big) ? 1.f : 0.f;
+    float v[6] = {fin ? px : big, fin ? py : big, fin ? pz : big, fin ? px : -big, fin ? py : -big, fin ? pz : -big};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = wave_min(v[k]);
+        v[k + 3] = wave_max(v[k + 3]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_bb[k][wave] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float r = s_bb[k][0];
+        for (int w = 1; w < 4; ++w) r = k < 3 ? fminf(r, s_bb[k][w]) : fmaxf(r, s_bb[k][w]);
+        bbox_part[k * gridDim.x + blockIdx.x] = r;
     }
 }
 
-// Cell id per bead + per-cell population.
+// Reduces the per-block bounding boxes of k_pack (nblk blocks) into a grid; called by one block.
+template <int BLOCK>
+__device__ __forceinline__ GridParams grid_from_parts(const float *__restrict__ bbox_part, int nblk, float hmin,
+                                                       int maxcells, float *s_red /* [6][BLOCK/64] */) {
+    const float big = 3.0e38f;
+    float v[6] = {big, big, big, -big, -big, -big};
+    for (int b = threadIdx.x; b < nblk; b += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = fminf(v[k], bbox_part[k * nblk + b]);
+            v[k + 3] = fmaxf(v[k + 3], bbox_part[(k + 3) * nblk + b]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = wave_min(v[k]);
+        v[k + 3] = wave_max(v[k + 3]);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_red[k * (BLOCK / 64) + wave] = v[k];
+    }
+    __syncthreads();
+    float r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        r[k] = s_red[k * (BLOCK / 64)];
+        for (int w = 1; w < BLOCK / 64; ++w)
+            r[k] = k < 3 ? fminf(r[k], s_red[k * (BLOCK / 64) + w]) : fmaxf(r[k], s_red[k * (BLOCK / 64) + w]);
+    }
+    return grid_from_box(r[0], r[1], r[2], r[3], r[4], r[5], hmin, maxcells);
+}
+
+// First build of a call: exact grid for the current positions.
+__global__ __launch_bounds__(256) void k_grid_init(const float *__restrict__ bbox_part, int nblk, float hmin,
+                                                   int maxcells, GridParams *__restrict__ grid,
+                                                   const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float s_red[6 * 4];
+    const GridParams G = grid_from_parts<256>(bbox_part, nblk, hmin, maxcells, s_red);
+    if (threadIdx.x == 0) *grid = G;
+}
+
+// Cell id per bead + per-cell population.  The grid may stem from the previous evaluation's bounding
+// box: coordinates are clamped, which keeps every pair within the cutoff inside the 27-cell stencil
+// (a bead outside the box by more than one cell edge cannot be within the cutoff of an interior cell
+// two layers in).  Lanes of a wave that share a cell issue one atomicAdd (Hilbert-ordered beads: ~3
+// distinct cells per wave) and derive their slot in the cell from the returned base.
 __global__ __launch_bounds__(256) void k_cell_count(int n, const float4 *__restrict__ pos4,
-                                                    const unsigned *__restrict__ bbox, float hmin, int maxcells,
-                                                    int *__restrict__ cell_of, int *__restrict__ count,
+                                                    const GridParams *__restrict__ grid, int *__restrict__ cell_of,
+                                                    int *__restrict__ rank, int *__restrict__ count,
                                                     const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    const GridParams G = grid_from_bbox(bbox, hmin, maxcells);
+    const GridParams G = *grid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pos4[i];
-    const int cx = cell_coord(p.x, G.ox, G.inv_h, G.nx);
-    const int cy = cell_coord(p.y, G.oy, G.inv_h, G.ny);
-    const int cz = cell_coord(p.z, G.oz, G.inv_h, G.nz);
-    const int c = (cz * G.ny + cy) * G.nx + cx;
-    cell_of[i] = c;
-    atomicAdd(&count[c], 1);
+    const int lane = threadIdx.x & 63;
+    bool todo = i < n;
+    int c = 0;
+    if (todo) {
+        const float4 p = pos4[i];
+        const int cx = cell_coord(p.x, G.ox, G.inv_h, G.nx);
+        const int cy = cell_coord(p.y, G.oy, G.inv_h, G.ny);
+        const int cz = cell_coord(p.z, G.oz, G.inv_h, G.nz);
+        c = (cz * G.ny + cy) * G.nx + cx;
+        cell_of[i] = c;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long pending = __ballot(todo);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int c0 = __shfl(c, leader, 64);
+        const unsigned long long same = __ballot(todo && c == c0);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&count[c0], __popcll(same));
+        base = __shfl(base, leader, 64);
+        if (todo && c == c0) {
+            rank[i] = base + __popcll(same & lt);
+            todo = false;
+        }
+        pending &= ~same;
+    }
 }
 
 // Single-block exclusive scan of the cell populations (bead offsets) and of the per-cell chunk
-// counts (work-item offsets); publishes the grid, the item count and resets the bbox.
+// counts (work-item offsets); publishes the item count and the grid of the next build.
 template <int CHUNK>
-__global__ __launch_bounds__(1024) void k_cell_scan(unsigned *__restrict__ bbox, float hmin, int maxcells,
-                                                    const int *__restrict__ count, int *__restrict__ start,
-                                                    int *__restrict__ istart, GridParams *__restrict__ grid,
-                                                    MinState *__restrict__ st) {
+__global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bbox_part, int nblk, float hmin,
+                                                    int maxcells, const int *__restrict__ count,
+                                                    int *__restrict__ start, int *__restrict__ istart,
+                                                    int *__restrict__ cstart,
+                                                    const GridParams *__restrict__ grid,
+                                                    GridParams *__restrict__ grid_next, MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ int s_a[1024], s_b[1024], s_m[16];
-    const GridParams G = grid_from_bbox(bbox, hmin, maxcells);
+    __shared__ int s_a[1024], s_b[1024], s_c[1024], s_m[16];
+    __shared__ float s_red[6 * 16];
+    const GridParams G = *grid;
+    // grid of the NEXT build from this evaluation's bounding box (see k_cell_count on staleness)
+    const GridParams GN = grid_from_parts<1024>(bbox_part, nblk, hmin, maxcells, s_red);
     const int t = threadIdx.x;
     const int per = (G.ncells + 1023) / 1024;
     const int c0 = t * per, c1 = min(c0 + per, G.ncells);
-    int sa = 0, sb = 0, mx = 0;
+    int sa = 0, sb = 0, sc = 0, mx = 0;
     for (int c = c0; c < c1; ++c) {
         const int k = count[c];
         sa += k;
         sb += (k + CHUNK - 1) / CHUNK;
+        sc += (k + 7) >> 3;
         mx = max(mx, k);
     }
     s_a[t] = sa;
     s_b[t] = sb;
+    s_c[t] = sc;
     mx = wave_max_i(mx);
     if ((t & 63) == 0) s_m[t >> 6] = mx;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials.
     for (int o = 1; o < 1024; o <<= 1) {
-        int va = 0, vb = 0;
+        int va = 0, vb = 0, vc = 0;
         if (t >= o) {
             va = s_a[t - o];
             vb = s_b[t - o];
+            vc = s_c[t - o];
         }
         __syncthreads();
         s_a[t] += va;
         s_b[t] += vb;
+        s_c[t] += vc;
         __syncthreads();
     }
-    int ra = s_a[t] - sa, rb = s_b[t] - sb; // exclusive prefixes
+    int ra = s_a[t] - sa, rb = s_b[t] - sb, rcl = s_c[t] - sc; // exclusive prefixes
     for (int c = c0; c < c1; ++c) {
         const int k = count[c];
         start[c] = ra;
         istart[c] = rb;
+        cstart[c] = rcl;
         ra += k;
         rb += (k + CHUNK - 1) / CHUNK;
+        rcl += (k + 7) >> 3;
     }
     if (t == 1023) {
         start[G.ncells] = s_a[1023];
         istart[G.ncells] = s_b[1023];
-        *grid = G;
+        cstart[G.ncells] = s_c[1023];
+        st->n_clusters = s_c[1023];
+        *grid_next = GN;
         int m = 0;
         for (int w = 0; w < 16; ++w) m = max(m, s_m[w]);
         st->n_items = s_b[1023];
         st->ncells = G.ncells;
         st->max_per_cell = m;
         st->cell_edge = (double)G.h;
-        bbox[0] = bbox[1] = bbox[2] = kEncPosInf;
-        bbox[3] = bbox[4] = bbox[5] = kEncNegInf;
     }
 }
 
 // Scatter bead ids into their cell's slice (arrival order; k_cell_order makes it canonical).
 __global__ __launch_bounds__(256) void k_cell_fill(int n, const int *__restrict__ cell_of,
-                                                   const int *__restrict__ start, int *__restrict__ cursor,
+                                                   const int *__restrict__ rank, const int *__restrict__ start,
                                                    int *__restrict__ perm, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int c = cell_of[i];
-    perm[start[c] + atomicAdd(&cursor[c], 1)] = i;
+    perm[start[cell_of[i]] + rank[i]] = i;
 }
 
 // One wave per cell (grid-stride): sorts the cell's bead ids ascending (bitwise reproducible pair
-// summation order), emits the cell's work items {cell, chunk} and clears count/cursor for the next build.
+// summation order), emits the cell's work items {cell, chunk} and clears count for the next build.
 constexpr int kOrderLds = 2048;
 template <int CHUNK>
 __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
                                                     const int *__restrict__ start, const int *__restrict__ istart,
-                                                    int *__restrict__ count, int *__restrict__ cursor,
+                                                    int *__restrict__ count,
                                                     int *__restrict__ perm, int2 *__restrict__ items,
+                                                    const int *__restrict__ cstart,
+                                                    const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
+                                                    float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int deterministic, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ int s_buf[4][kOrderLds];
@@ -152,14 +243,11 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
     int *buf = s_buf[wave];
     for (int c = blockIdx.x * 4 + wave; c < ncells; c += nwaves) {
         const int s = start[c], cnt = start[c + 1] - s;
-        if (lane == 0) {
-            count[c] = 0;
-            cursor[c] = 0;
-        }
+        if (lane == 0) count[c] = 0;
         if (cnt == 0) continue;
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
         for (int k = lane; k < nchunk; k += 64) items[ib + k] = make_int2(c, k);
-        if (!deterministic || cnt == 1) continue;
+        if (deterministic && cnt > 1) {
         if (cnt <= 64) {
             int v = lane < cnt ? perm[s + lane] : 0x7fffffff;
 #pragma unroll
@@ -196,6 +284,33 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             wave_lds_sync();
         }
         // cells above kOrderLds beads keep arrival order (still correct, not bitwise reproducible)
+        }
+        // ---- cluster view of the cell for the cluster-pair kernel: padded, cell-sorted positions and the
+        // bounding box of every 8-bead cluster (lo.w = cell id, hi.w = bead count of the cluster)
+        __threadfence_block(); // the sorted perm[] written above is re-read below by other lanes
+        wave_lds_sync();
+        const int ncl = (cnt + 7) >> 3, cb = cstart[c];
+        for (int e = lane; e < ncl * 8; e += 64) {
+            float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
+            if (e < cnt) p = pos4[perm[s + e]];
+            spos4[(size_t)cb * 8 + e] = p;
+            const float big = 3.0e38f;
+            float lx = e < cnt ? p.x : big, ly = e < cnt ? p.y : big, lz = e < cnt ? p.z : big;
+            float hx = e < cnt ? p.x : -big, hy = e < cnt ? p.y : -big, hz = e < cnt ? p.z : -big;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                lx = fminf(lx, __shfl_xor(lx, o, 64));
+                ly = fminf(ly, __shfl_xor(ly, o, 64));
+                lz = fminf(lz, __shfl_xor(lz, o, 64));
+                hx = fmaxf(hx, __shfl_xor(hx, o, 64));
+                hy = fmaxf(hy, __shfl_xor(hy, o, 64));
+                hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+            }
+            if ((e & 7) == 0) {
+                cl_lo[cb + (e >> 3)] = make_float4(lx, ly, lz, __int_as_float(c));
+                cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float(min(8, cnt - e)));
+            }
+        }
     }
 }
 

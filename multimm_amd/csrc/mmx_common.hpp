@@ -59,7 +59,7 @@ struct MinState {
     int n_items;    // non-bonded work items of the last cell build
     int ncells, max_per_cell;
     int nan_seen;
-    int pad0;
+    int n_clusters; // 8-bead clusters of the last cell build
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;
@@ -122,30 +122,21 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* [BLOCK/64] 
     return r;
 }
 
-// Monotone float <-> uint encoding for atomicMin/atomicMax on floats.
-__device__ __forceinline__ unsigned enc_ordered(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_ordered(unsigned u) {
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-constexpr unsigned kEncPosInf = 0xFF800000u; // enc(+inf)
-constexpr unsigned kEncNegInf = 0x007FFFFFu; // enc(-inf)
-
-// Grid derived from the bounding box; every thread that calls it gets identical values.
-__device__ __forceinline__ GridParams grid_from_bbox(const unsigned *bbox, float hmin, int maxcells) {
+// Grid derived from a bounding box; every thread that calls it gets identical values.
+__device__ __forceinline__ GridParams grid_from_box(float lox, float loy, float loz, float hix, float hiy,
+                                                     float hiz, float hmin, int maxcells) {
     GridParams G;
-    G.ox = dec_ordered(bbox[0]);
-    G.oy = dec_ordered(bbox[1]);
-    G.oz = dec_ordered(bbox[2]);
-    float ex = dec_ordered(bbox[3]) - G.ox, ey = dec_ordered(bbox[4]) - G.oy, ez = dec_ordered(bbox[5]) - G.oz;
-    if (!(ex >= 0.f) || !(ex < 1e30f)) ex = 0.f; // empty / non-finite box: one cell
-    if (!(ey >= 0.f) || !(ey < 1e30f)) ey = 0.f;
-    if (!(ez >= 0.f) || !(ez < 1e30f)) ez = 0.f;
+    G.ox = lox;
+    G.oy = loy;
+    G.oz = loz;
+    float ex = hix - lox, ey = hiy - loy, ez = hiz - loz;
+    if (!(ex >= 0.f) || !(ex < 1e30f)) { ex = 0.f; G.ox = 0.f; } // empty / non-finite box: one cell
+    if (!(ey >= 0.f) || !(ey < 1e30f)) { ey = 0.f; G.oy = 0.f; }
+    if (!(ez >= 0.f) || !(ez < 1e30f)) { ez = 0.f; G.oz = 0.f; }
     float h = hmin;
+    G.nx = G.ny = G.nz = 1;
     for (int it = 0; it < 200; ++it) {
-        float fx = floorf(ex / h) + 1.f, fy = floorf(ey / h) + 1.f, fz = floorf(ez / h) + 1.f;
+        const float fx = floorf(ex / h) + 1.f, fy = floorf(ey / h) + 1.f, fz = floorf(ez / h) + 1.f;
         if (fx * fy * fz <= (float)maxcells) {
             G.nx = (int)fx;
             G.ny = (int)fy;
@@ -153,7 +144,6 @@ __device__ __forceinline__ GridParams grid_from_bbox(const unsigned *bbox, float
             break;
         }
         h *= 1.25f;
-        G.nx = G.ny = G.nz = 1;
     }
     G.h = h;
     G.inv_h = 1.0f / h;

@@ -15,30 +15,61 @@ struct CtlArgs {
     int nblk[P_NSLOTS]; // block partials per slot written by the force kernels of this evaluation
 };
 
-// Deterministic sum of part[slot*stride + 0..n) by one 256-thread block; result on every thread.
-__device__ __forceinline__ double slot_sum(const double *__restrict__ part, int n, double *s_buf /*[256]*/) {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += part[i];
-    __syncthreads();
-    s_buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s_buf[threadIdx.x] += s_buf[threadIdx.x + o];
-        __syncthreads();
+constexpr int kCtlThreads = 1024;
+
+// Deterministic sums of NS partial-sum slots by one 1024-thread block: every thread strides over
+// every slot (independent loads, latency overlapped), wave-shuffle reduce, then a fixed-order fold of
+// the 16 wave partials.  out[s] is valid on all threads after the call.
+template <int NS>
+__device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, int stride, const int *nblk,
+                                               double *s_wave /* [NS][16] */, double *s_out /* [NS] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int s0 = 0; s0 < NS; s0 += 4) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            if (s < NS) {
+                const int n = nblk[s];
+                const double *p = part + (size_t)s * stride;
+                for (int i = threadIdx.x; i < n; i += kCtlThreads) v[u] += p[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            if (s < NS) {
+                const double w = wave_sum(v[u]);
+                if (lane == 0) s_wave[s * 16 + wave] = w;
+            }
+        }
     }
-    return s_buf[0];
+    __syncthreads();
+    if ((int)threadIdx.x < NS) {
+        double r = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) r += s_wave[threadIdx.x * 16 + w];
+        s_out[threadIdx.x] = r;
+    }
+    __syncthreads();
 }
 
 // After every evaluation: fold the block partials, then (thread 0) advance the line search exactly as
 // liblbfgs' line_search_backtracking with LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE does.
-__global__ __launch_bounds__(256) void k_controller(const CtlArgs A, const double *__restrict__ part,
-                                                    MinState *__restrict__ st) {
+__global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
+                                                     MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ double s_buf[256];
+    __shared__ double s_wave[P_NSLOTS * 16];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS];
+    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
+    __syncthreads();
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_wave, s_out);
+    if (threadIdx.x != 0) return;
     double sums[P_NSLOTS];
 #pragma unroll
-    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = slot_sum(part + (size_t)s * kPartStride, A.nblk[s], s_buf);
-    if (threadIdx.x != 0) return;
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
 
     double f = 0.0;
     for (int t = 0; t < 8; ++t) {
@@ -136,7 +167,7 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
                                                  float4 *__restrict__ S, float4 *__restrict__ Y,
                                                  double *__restrict__ rows, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE || !st->accepted) return;
-    __shared__ double s_w[4];
+    __shared__ double s_w[MMX_NROWS * MMX_NBASIS * 4];
     const int slot = st->end;
     const bool store = st->store_hist != 0;
     double acc[MMX_NROWS][MMX_NBASIS];
@@ -180,26 +211,32 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
             acc[2][b] += (double)(G.x * v.x + G.y * v.y) + (double)(G.z * v.z + G.w * v.w);
         }
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < MMX_NROWS; ++r)
 #pragma unroll
         for (int b = 0; b < MMX_NBASIS; ++b) {
-            const double s = block_sum<256>(acc[r][b], s_w);
-            if (threadIdx.x == 0) rows[(size_t)(r * MMX_NBASIS + b) * kPartStride + blockIdx.x] = s;
+            const double s = wave_sum(acc[r][b]);
+            if (lane == 0) s_w[(r * MMX_NBASIS + b) * 4 + wave] = s;
         }
+    __syncthreads();
+    if (threadIdx.x < MMX_NROWS * MMX_NBASIS) {
+        const double *q = s_w + threadIdx.x * 4;
+        rows[(size_t)threadIdx.x * kPartStride + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
 }
 
 // Gram update + two-loop recursion in coefficient space (liblbfgs lbfgs() main-loop tail).
-__global__ __launch_bounds__(256) void k_direction_coef(int nblk, const double *__restrict__ rows,
-                                                        MinState *__restrict__ st) {
+__global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double *__restrict__ rows,
+                                                         MinState *__restrict__ st) {
     if (st->phase == PH_DONE || !st->accepted) return;
-    __shared__ double s_buf[256];
-    __shared__ double s_rows[MMX_NROWS * MMX_NBASIS];
-    for (int q = 0; q < MMX_NROWS * MMX_NBASIS; ++q) {
-        const double v = slot_sum(rows + (size_t)q * kPartStride, nblk, s_buf);
-        if (threadIdx.x == 0) s_rows[q] = v;
-    }
+    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
+    __shared__ double s_wave[NQ * 16];
+    __shared__ double s_rows[NQ];
+    __shared__ int s_n[NQ];
+    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
     __syncthreads();
+    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_wave, s_rows);
     if (threadIdx.x != 0) return;
     constexpr int NB = MMX_NBASIS, M = MMX_M, IG = 2 * MMX_M;
     double *G = st->gram;

@@ -153,6 +153,145 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2 v4: cluster-pair kernel.  Measured on MI355X the pair kernel is VALU-issue bound (v1: ~100 % issue,
+// ~80 cycles per (wave, candidate); packed v_pk_*_f32 issues in 4 cycles, i.e. no gain over two plain
+// ops) and only ~18 % of the 27-cell stencil candidates of a 64-bead home chunk lie inside the cutoff,
+// while 83 % of them are within the cutoff of SOME home bead, so neither wave-uniform skipping nor
+// per-lane bit-mask compaction pays (both were built and measured: see DESIGN.md).  What does pay is
+// making both sides of a tile spatially small: beads are grouped in clusters of 8 consecutive
+// entries of the cell-sorted order (k_cell_order writes their padded positions `spos4` and bounding
+// boxes); one wave owns one i-cluster, its 64 lanes are the 8x8 pairs (ii = lane>>3, jj = lane&7) of
+// an (i-cluster, j-cluster) tile.  Per 64 candidate j-clusters the wave (lanes = clusters) tests
+// box-box distance against the cutoff, compacts the survivors with a ballot, stages their positions
+// through LDS in coalesced 128-B pieces and sweeps them.  Forces of bead ii are accumulated in the 8
+// lanes that share ii and folded with three xor-shuffles; energies leave by wave-shuffle reduction.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCl = 8; // beads per cluster
+
+template <int PMODE, bool EV, bool GAUSS>
+__global__ __launch_bounds__(256) void k_nb_clusters(const FFParams P, const float4 *__restrict__ spos4,
+                                                     const float4 *__restrict__ cl_lo,
+                                                     const float4 *__restrict__ cl_hi,
+                                                     const int *__restrict__ cstart,
+                                                     const GridParams *__restrict__ grid,
+                                                     const MinState *__restrict__ st, float *__restrict__ g,
+                                                     double *__restrict__ part) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float4 s_tile[4][64 * kCl];
+    __shared__ int s_list[4][64];
+    __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
+    __shared__ double s_e[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ii = lane >> 3, jj = lane & 7;
+    if (threadIdx.x < 40)
+        s_tab[threadIdx.x] = (threadIdx.x & 7) < 5 ? P.table[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.f;
+    const GridParams G = *grid;
+    const int ncl = st->n_clusters;
+    __syncthreads();
+    float4 *tile = s_tile[wave];
+    int *list = s_list[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float rc2 = P.rc2max;
+    double acc_ev = 0.0, acc_g = 0.0;
+
+    for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
+        const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
+        const int c = __float_as_int(lo_i.w);
+        const float4 pi = spos4[(size_t)icl * kCl + ii];
+        const int wi = __float_as_int(pi.w);
+        const float *tabrow = s_tab + 8 * (wi & 7);
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+        PairAcc a = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, G.nz - 1); ++zz) {
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.ny - 1); ++yy) {
+                const int row = (zz * G.ny + yy) * G.nx;
+                const int c0 = cstart[row + x0], c1 = cstart[row + x1 + 1];
+                for (int base = c0; base < c1; base += 64) {
+                    // ---- cull: lanes = candidate j-clusters, box-box distance against the cutoff
+                    const int jc = base + lane;
+                    bool ok = false;
+                    if (jc < c1) {
+                        const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
+                        const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
+                        const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
+                        const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
+                        ok = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+                    }
+                    const unsigned long long mask = __ballot(ok);
+                    const int nacc = __popcll(mask);
+                    if (nacc == 0) continue;
+                    wave_lds_sync(); // previous batch fully consumed
+                    if (ok) list[__popcll(mask & lt)] = jc;
+                    wave_lds_sync();
+                    // ---- stage the survivors: 8 clusters (8 x 128 B, coalesced) per pass
+                    for (int e = lane; e < nacc * kCl; e += 64)
+                        tile[e] = spos4[(size_t)list[e >> 3] * kCl + (e & 7)];
+                    wave_lds_sync();
+                    // ---- sweep: lane (ii,jj) handles pair (bead ii of the i-cluster, bead jj of tile t)
+#pragma unroll 2
+                    for (int t = 0; t < nacc; ++t) {
+                        const float4 q = tile[t * kCl + jj];
+                        const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
+                        const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                        const int wj = __float_as_int(q.w);
+                        const bool in = (r2 < rc2) & (wj != wi);
+                        const float r2s = r2 + 1e-20f;
+                        const float rinv = __builtin_amdgcn_rsqf(r2s);
+                        float fs = 0.f;
+                        if (EV) {
+                            const float r = r2s * rinv;
+                            const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
+                            float E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                            E = (in && r2 < P.ev_rc2) ? E : 0.f;
+                            a.eev += E;
+                            fs = P.ev_power * E * u * rinv;
+                        }
+                        if (GAUSS) {
+                            float gg = tabrow[wj & 7] * __builtin_amdgcn_exp2f(r2 * P.g_c2);
+                            gg = (in && r2 < P.g_rc2) ? gg : 0.f;
+                            a.eg -= gg;
+                            fs = fmaf(-gg, P.g_inv_rc2, fs);
+                        }
+                        a.fx = fmaf(fs, dx, a.fx);
+                        a.fy = fmaf(fs, dy, a.fy);
+                        a.fz = fmaf(fs, dz, a.fz);
+                    }
+                }
+            }
+        }
+        // fold the 8 lanes that share bead ii
+#pragma unroll
+        for (int o = 1; o < kCl; o <<= 1) {
+            a.fx += __shfl_xor(a.fx, o, 64);
+            a.fy += __shfl_xor(a.fy, o, 64);
+            a.fz += __shfl_xor(a.fz, o, 64);
+            a.eev += __shfl_xor(a.eev, o, 64);
+            a.eg += __shfl_xor(a.eg, o, 64);
+        }
+        const int bead = wi >> 3; // -1 for padding slots
+        const bool own = (jj == 0) && (bead >= 0);
+        if (own) {
+            g[3 * bead] = -a.fx;
+            g[3 * bead + 1] = -a.fy;
+            g[3 * bead + 2] = -a.fz;
+        }
+        const float sev = wave_sum(own ? a.eev : 0.f), seg = wave_sum(own ? a.eg : 0.f);
+        acc_ev += 0.5 * (double)sev;
+        acc_g += 0.5 * (double)seg;
+    }
+    if (lane == 0) {
+        s_e[0][wave] = acc_ev;
+        s_e[1][wave] = acc_g;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[P_EV * kPartStride + blockIdx.x] = (s_e[0][0] + s_e[0][1]) + (s_e[0][2] + s_e[0][3]);
+        part[P_GAUSS * kPartStride + blockIdx.x] = (s_e[1][0] + s_e[1][1]) + (s_e[1][2] + s_e[1][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2x: exact all-pairs (NoCutoff, what the reference does).  Block = 256 home beads, blockIdx.y = j
 // slice; j tiles of 256 beads are staged in LDS and broadcast-read.  Partial forces per slice go to
 // fpart[slice][bead] and are folded in a fixed order by k_nb_allpairs_fold.
