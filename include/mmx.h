@@ -163,6 +163,11 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
 int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double *cell_edge, double *pair_candidates,
                   double *pairs_within_cutoff);
 
+/* Diagnostics of the cluster-pair kernel at the current positions: number of 8-bead clusters, number of
+ * (i-cluster, j-cluster) tiles in the 27-cell stencils and number of tiles surviving the box-box cull
+ * (each surviving tile = 64 pair lanes). */
+int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted);
+
 #ifdef __cplusplus
 }
 #endif

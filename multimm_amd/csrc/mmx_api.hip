@@ -177,9 +177,12 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
         if (h->nb_variant == 1)                                                                             \
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
+        else if (!(EV && GA) || P.ev_rc2 == P.g_rc2)                                                        \
+            hipLaunchKernelGGL((k_nb_clusters_j<PMODE, EV, GA, true>), dim3(grid), dim3(256), 0, h->stream,  \
+                               P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);  \
         else                                                                                                \
-            hipLaunchKernelGGL((k_nb_clusters<PMODE, EV, GA>), dim3(grid), dim3(256), 0, h->stream, P,       \
-                               h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);     \
+            hipLaunchKernelGGL((k_nb_clusters_j<PMODE, EV, GA, false>), dim3(grid), dim3(256), 0, h->stream, \
+                               P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);  \
     } while (0)
     if (P.use_ev && P.use_gauss) NBC(true, true);
     else if (P.use_ev) NBC(true, false);
@@ -925,6 +928,66 @@ __global__ __launch_bounds__(256) static void k_census(int n, const float4 *__re
         atomicAdd(&out[0], a);
         atomicAdd(&out[1], b);
     }
+}
+
+// Tile census of the cluster-pair kernel: repeats its box-box cull and counts candidate / accepted tiles.
+__global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float4 *__restrict__ cl_lo,
+                                                            const float4 *__restrict__ cl_hi,
+                                                            const int *__restrict__ cstart,
+                                                            const GridParams *__restrict__ grid, float rc2,
+                                                            double *__restrict__ out /* [2] */) {
+    const GridParams G = *grid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double cand = 0.0, acc = 0.0;
+    for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
+        const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
+        const int c = __float_as_int(lo_i.w);
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, G.nz - 1); ++zz)
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.ny - 1); ++yy) {
+                const int row = (zz * G.ny + yy) * G.nx;
+                const int c0 = cstart[row + x0], c1 = cstart[row + x1 + 1];
+                for (int jc = c0 + lane; jc < c1; jc += 64) {
+                    const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
+                    const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
+                    const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
+                    const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
+                    cand += 1.0;
+                    if (dx * dx + dy * dy + dz * dz < rc2) acc += 1.0;
+                }
+            }
+    }
+    cand = wave_sum(cand);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        atomicAdd(&out[0], cand);
+        atomicAdd(&out[1], acc);
+    }
+}
+
+int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    int rc = prepare(h);
+    if (rc) return rc;
+    if (!has_nb(h) || all_pairs(h)) return fail(h, MMX_ERR_STATE, "census needs a cutoff (cell-list mode)");
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if ((rc = prime_items(h))) return rc;
+    double *dout = nullptr;
+    HIPCHK(h, dalloc(&dout, 2));
+    const int ncl = h->st_host->n_clusters;
+    hipLaunchKernelGGL(k_tile_census, dim3(1024), dim3(256), 0, h->stream, ncl, h->cl_lo, h->cl_hi, h->cstart,
+                       h->gcur, h->P.rc2max, dout);
+    double res[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(dout);
+    if (n_clusters) *n_clusters = ncl;
+    if (tiles_candidate) *tiles_candidate = res[0];
+    if (tiles_accepted) *tiles_accepted = res[1];
+    return MMX_OK;
 }
 
 int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double *cell_edge, double *pair_candidates,

@@ -223,9 +223,26 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n, const int *__restrict_
     perm[start[cell_of[i]] + rank[i]] = i;
 }
 
-// One wave per cell (grid-stride): sorts the cell's bead ids ascending (bitwise reproducible pair
-// summation order), emits the cell's work items {cell, chunk} and clears count for the next build.
-constexpr int kOrderLds = 2048;
+// 12-bit Morton code of a position inside its cell (16 sub-cells per axis).
+__device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00d
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+__device__ __forceinline__ unsigned long long order_key(const float4 p, const GridParams &G, int cx, int cy, int cz,
+                                                        int bead) {
+    const float fx = ((p.x - G.ox) * G.inv_h - (float)cx) * 16.f;
+    const float fy = ((p.y - G.oy) * G.inv_h - (float)cy) * 16.f;
+    const float fz = ((p.z - G.oz) * G.inv_h - (float)cz) * 16.f;
+    const unsigned qx = (unsigned)min(max((int)fx, 0), 15), qy = (unsigned)min(max((int)fy, 0), 15),
+                   qz = (unsigned)min(max((int)fz, 0), 15);
+    const unsigned m = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
+    return ((unsigned long long)m << 32) | (unsigned)bead;
+}
+
+// One wave per cell (grid-stride): orders the cell's beads along a Morton curve of 16^3 sub-cells (ties
+// by bead id: bitwise reproducible summation order, and 8 consecutive entries form a spatially compact
+// cluster), emits the cell's work items {cell, chunk}, the padded cluster positions and cluster boxes
+// and clears count for the next build.
+constexpr int kOrderLds = 1024;
 template <int CHUNK>
 __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
                                                     const int *__restrict__ start, const int *__restrict__ istart,
@@ -236,41 +253,55 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int deterministic, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ int s_buf[4][kOrderLds];
+    __shared__ unsigned long long s_buf[4][kOrderLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ncells = grid->ncells;
+    const GridParams G = *grid;
+    const int ncells = G.ncells;
     const int nwaves = gridDim.x * 4;
-    int *buf = s_buf[wave];
+    unsigned long long *buf = s_buf[wave];
+    const unsigned long long kmax = ~0ull;
     for (int c = blockIdx.x * 4 + wave; c < ncells; c += nwaves) {
         const int s = start[c], cnt = start[c + 1] - s;
         if (lane == 0) count[c] = 0;
         if (cnt == 0) continue;
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
         for (int k = lane; k < nchunk; k += 64) items[ib + k] = make_int2(c, k);
-        if (deterministic && cnt > 1) {
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        if (cnt > 1) {
         if (cnt <= 64) {
-            int v = lane < cnt ? perm[s + lane] : 0x7fffffff;
+            unsigned long long v = kmax;
+            if (lane < cnt) {
+                const int b = perm[s + lane];
+                v = order_key(pos4[b], G, cx, cy, cz, b);
+            }
 #pragma unroll
             for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    const int o = __shfl_xor(v, j, 64);
+                    const unsigned long long o = __shfl_xor(v, j, 64);
                     const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-                    v = keep_min ? min(v, o) : max(v, o);
+                    v = keep_min ? (v < o ? v : o) : (v < o ? o : v);
                 }
             }
-            if (lane < cnt) perm[s + lane] = v;
+            if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
         } else if (cnt <= kOrderLds) {
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
-            for (int q = lane; q < n2; q += 64) buf[q] = q < cnt ? perm[s + q] : 0x7fffffff;
+            for (int q = lane; q < n2; q += 64) {
+                unsigned long long v = kmax;
+                if (q < cnt) {
+                    const int b = perm[s + q];
+                    v = order_key(pos4[b], G, cx, cy, cz, b);
+                }
+                buf[q] = v;
+            }
             wave_lds_sync();
             for (int k = 2; k <= n2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int q = lane; q < (n2 >> 1); q += 64) {
                         const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                         const int i1 = i0 | j;
-                        const int a = buf[i0], b = buf[i1];
+                        const unsigned long long a = buf[i0], b = buf[i1];
                         const bool up = (i0 & k) == 0;
                         if ((a > b) == up) {
                             buf[i0] = b;
@@ -280,7 +311,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                     wave_lds_sync();
                 }
             }
-            for (int q = lane; q < cnt; q += 64) perm[s + q] = buf[q];
+            for (int q = lane; q < cnt; q += 64) perm[s + q] = (int)(unsigned)(buf[q] & 0xffffffffull);
             wave_lds_sync();
         }
         // cells above kOrderLds beads keep arrival order (still correct, not bitwise reproducible)

@@ -153,130 +153,180 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2 v4: cluster-pair kernel.  Measured on MI355X the pair kernel is VALU-issue bound (v1: ~100 % issue,
-// ~80 cycles per (wave, candidate); packed v_pk_*_f32 issues in 4 cycles, i.e. no gain over two plain
-// ops) and only ~18 % of the 27-cell stencil candidates of a 64-bead home chunk lie inside the cutoff,
-// while 83 % of them are within the cutoff of SOME home bead, so neither wave-uniform skipping nor
-// per-lane bit-mask compaction pays (both were built and measured: see DESIGN.md).  What does pay is
-// making both sides of a tile spatially small: beads are grouped in clusters of 8 consecutive
-// entries of the cell-sorted order (k_cell_order writes their padded positions `spos4` and bounding
-// boxes); one wave owns one i-cluster, its 64 lanes are the 8x8 pairs (ii = lane>>3, jj = lane&7) of
-// an (i-cluster, j-cluster) tile.  Per 64 candidate j-clusters the wave (lanes = clusters) tests
-// box-box distance against the cutoff, compacts the survivors with a ballot, stages their positions
-// through LDS in coalesced 128-B pieces and sweeps them.  Forces of bead ii are accumulated in the 8
-// lanes that share ii and folded with three xor-shuffles; energies leave by wave-shuffle reduction.
+// K2 (default): cluster-pair kernel.
+// Measured on MI355X the pair arithmetic is VALU-issue bound (v1 below: ~100 % issue; packed
+// v_pk_*_f32 issues in 4 cycles, i.e. no gain over two plain ops; v_cmp/v_cndmask/VOP3 integer ops cost
+// ~4.3 cycles, transcendentals ~9.3) and only ~18 % of the 27-cell stencil candidates of a 64-bead home
+// chunk lie inside the cutoff while 83 % of them are within the cutoff of SOME home bead, so neither
+// wave-uniform skipping nor per-lane bit-mask compaction pays (both were built and measured, see
+// DESIGN.md).  What pays is making both sides of a tile spatially small: beads are grouped in clusters
+// of 8 consecutive entries of the cell-sorted, Morton-ordered list (k_cell_order writes their padded
+// positions `spos4` and bounding boxes).  One wave owns one i-cluster: it tests the candidate
+// j-clusters of the 27-cell stencil box-against-box (lanes = candidate clusters), compacts the
+// survivors with a ballot into an LDS list, keeps its 8 i beads in scalar registers (v_readlane once)
+// and lets its 64 lanes hold the beads of EIGHT accepted j-clusters at a time (lane -> cluster
+// t*8 + lane/8, slot lane%8: one coalesced 128-B piece per cluster, loaded straight into registers,
+// prefetched one step ahead and reused for all 8 i beads).  The inner loop over the 8 i beads is pure
+// VALU with scalar i operands: no LDS tile, no staging pass, no barrier.  The 8x5 per-i accumulators
+// are folded over the wave by shuffles once per i-cluster; energies leave as one double per block.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCl = 8; // beads per cluster
+constexpr int kCl = 8;        // beads per cluster
+constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
-template <int PMODE, bool EV, bool GAUSS>
-__global__ __launch_bounds__(256) void k_nb_clusters(const FFParams P, const float4 *__restrict__ spos4,
-                                                     const float4 *__restrict__ cl_lo,
-                                                     const float4 *__restrict__ cl_hi,
-                                                     const int *__restrict__ cstart,
-                                                     const GridParams *__restrict__ grid,
-                                                     const MinState *__restrict__ st, float *__restrict__ g,
-                                                     double *__restrict__ part) {
+template <int PMODE, bool EV, bool GAUSS, bool SAMECUT>
+__global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+                                                       const float4 *__restrict__ cl_lo,
+                                                       const float4 *__restrict__ cl_hi,
+                                                       const int *__restrict__ cstart,
+                                                       const GridParams *__restrict__ grid,
+                                                       const MinState *__restrict__ st, float *__restrict__ g,
+                                                       double *__restrict__ part) {
     if (st->phase == PH_DONE) return;
-    __shared__ float4 s_tile[4][64 * kCl];
-    __shared__ int s_list[4][64];
+    __shared__ int s_list[4][kListCap + 72];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ double s_e[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ii = lane >> 3, jj = lane & 7;
+    const int sub = lane >> 3, slot = lane & 7;
     if (threadIdx.x < 40)
         s_tab[threadIdx.x] = (threadIdx.x & 7) < 5 ? P.table[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.f;
     const GridParams G = *grid;
     const int ncl = st->n_clusters;
     __syncthreads();
-    float4 *tile = s_tile[wave];
     int *list = s_list[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float rc2 = P.rc2max;
+    const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8));
     double acc_ev = 0.0, acc_g = 0.0;
 
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
         const int c = __float_as_int(lo_i.w);
-        const float4 pi = spos4[(size_t)icl * kCl + ii];
-        const int wi = __float_as_int(pi.w);
-        const float *tabrow = s_tab + 8 * (wi & 7);
+        // i-cluster -> scalar registers
+        const float4 pv = spos4[(size_t)icl * kCl + slot];
+        float xi[kCl], yi[kCl], zi[kCl];
+        int wi[kCl];
+#pragma unroll
+        for (int s = 0; s < kCl; ++s) {
+            xi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), s));
+            yi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), s));
+            zi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), s));
+            wi[s] = __builtin_amdgcn_readlane(__float_as_int(pv.w), s);
+        }
+        float fx[kCl], fy[kCl], fz[kCl], ee[kCl], eg[kCl];
+#pragma unroll
+        for (int s = 0; s < kCl; ++s) fx[s] = fy[s] = fz[s] = ee[s] = eg[s] = 0.f;
+
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
-        PairAcc a = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, G.nz - 1); ++zz) {
-            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.ny - 1); ++yy) {
-                const int row = (zz * G.ny + yy) * G.nx;
-                const int c0 = cstart[row + x0], c1 = cstart[row + x1 + 1];
-                for (int base = c0; base < c1; base += 64) {
-                    // ---- cull: lanes = candidate j-clusters, box-box distance against the cutoff
-                    const int jc = base + lane;
-                    bool ok = false;
-                    if (jc < c1) {
-                        const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
-                        const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
-                        const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
-                        const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
-                        ok = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.nz - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, G.ny - 1);
+        const int nrows = (z1 - z0 + 1) * (y1 - y0 + 1);
+        int nlist = 0;
+        int row_i = 0, base = 0, c1 = 0;
+        bool more = true;
+        while (more) {
+            // ---- cull: fill the list with accepted j-clusters (lanes = candidate clusters)
+            while (nlist <= kListCap - 64) {
+                if (base >= c1) {
+                    if (row_i >= nrows) {
+                        more = false;
+                        break;
                     }
-                    const unsigned long long mask = __ballot(ok);
-                    const int nacc = __popcll(mask);
-                    if (nacc == 0) continue;
-                    wave_lds_sync(); // previous batch fully consumed
-                    if (ok) list[__popcll(mask & lt)] = jc;
-                    wave_lds_sync();
-                    // ---- stage the survivors: 8 clusters (8 x 128 B, coalesced) per pass
-                    for (int e = lane; e < nacc * kCl; e += 64)
-                        tile[e] = spos4[(size_t)list[e >> 3] * kCl + (e & 7)];
-                    wave_lds_sync();
-                    // ---- sweep: lane (ii,jj) handles pair (bead ii of the i-cluster, bead jj of tile t)
-#pragma unroll 2
-                    for (int t = 0; t < nacc; ++t) {
-                        const float4 q = tile[t * kCl + jj];
-                        const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
-                        const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                        const int wj = __float_as_int(q.w);
-                        const bool in = (r2 < rc2) & (wj != wi);
-                        const float r2s = r2 + 1e-20f;
-                        const float rinv = __builtin_amdgcn_rsqf(r2s);
-                        float fs = 0.f;
-                        if (EV) {
-                            const float r = r2s * rinv;
-                            const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
-                            float E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
-                            E = (in && r2 < P.ev_rc2) ? E : 0.f;
-                            a.eev += E;
-                            fs = P.ev_power * E * u * rinv;
-                        }
-                        if (GAUSS) {
-                            float gg = tabrow[wj & 7] * __builtin_amdgcn_exp2f(r2 * P.g_c2);
-                            gg = (in && r2 < P.g_rc2) ? gg : 0.f;
-                            a.eg -= gg;
-                            fs = fmaf(-gg, P.g_inv_rc2, fs);
-                        }
-                        a.fx = fmaf(fs, dx, a.fx);
-                        a.fy = fmaf(fs, dy, a.fy);
-                        a.fz = fmaf(fs, dz, a.fz);
+                    const int zz = z0 + row_i / (y1 - y0 + 1), yy = y0 + row_i % (y1 - y0 + 1);
+                    const int row = (zz * G.ny + yy) * G.nx;
+                    base = cstart[row + x0];
+                    c1 = cstart[row + x1 + 1];
+                    ++row_i;
+                    continue;
+                }
+                const int jc = base + lane;
+                bool ok = false;
+                if (jc < c1) {
+                    const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
+                    const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
+                    const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
+                    const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
+                    ok = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+                }
+                const unsigned long long mask = __ballot(ok);
+                if (ok) list[nlist + __popcll(mask & lt)] = jc;
+                nlist += __popcll(mask);
+                base += 64;
+            }
+            if (nlist == 0) break;
+            // pad to a multiple of 8 clusters with "no cluster"
+            if (lane < 8) list[nlist + lane] = -1;
+            wave_lds_sync();
+            const int nsteps = (nlist + 7) >> 3;
+            // ---- sweep: 8 j-clusters (64 j beads) per step against the 8 scalar i beads
+            int jn = list[sub];
+            float4 qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
+            for (int t = 0; t < nsteps; ++t) {
+                const float4 q = qn;
+                if (t + 1 < nsteps) { // prefetch the next 8 clusters
+                    jn = list[(t + 1) * 8 + sub];
+                    qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
+                }
+                const int ljo = __float_as_int(q.w) & 7;
+#pragma unroll
+                for (int s = 0; s < kCl; ++s) {
+                    const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
+                    const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                    const bool in = r2 < rc2;
+                    const float r2s = r2 + 1e-20f;
+                    const float rinv = __builtin_amdgcn_rsqf(r2s);
+                    float fs = 0.f;
+                    if (EV) {
+                        const float r = r2s * rinv;
+                        const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
+                        float E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                        E = (in && (SAMECUT || r2 < P.ev_rc2)) ? E : 0.f;
+                        ee[s] += E;
+                        fs = P.ev_power * E * u * rinv;
                     }
+                    if (GAUSS) {
+                        float gg = s_tab[(wi[s] & 7) * 8 + ljo] * __builtin_amdgcn_exp2f(r2 * P.g_c2);
+                        gg = (in && (SAMECUT || r2 < P.g_rc2)) ? gg : 0.f;
+                        eg[s] -= gg;
+                        fs = fmaf(-gg, P.g_inv_rc2, fs);
+                    }
+                    fx[s] = fmaf(fs, dx, fx[s]);
+                    fy[s] = fmaf(fs, dy, fy[s]);
+                    fz[s] = fmaf(fs, dz, fz[s]);
                 }
             }
+            nlist = 0;
+            wave_lds_sync();
         }
-        // fold the 8 lanes that share bead ii
+        // ---- fold over the wave; lane s (< 8) ends up owning bead s of the i-cluster
+        float ofx = 0.f, ofy = 0.f, ofz = 0.f, oee = 0.f, oeg = 0.f;
+        int ow = -8;
 #pragma unroll
-        for (int o = 1; o < kCl; o <<= 1) {
-            a.fx += __shfl_xor(a.fx, o, 64);
-            a.fy += __shfl_xor(a.fy, o, 64);
-            a.fz += __shfl_xor(a.fz, o, 64);
-            a.eev += __shfl_xor(a.eev, o, 64);
-            a.eg += __shfl_xor(a.eg, o, 64);
+        for (int s = 0; s < kCl; ++s) {
+            const float a0 = wave_sum(fx[s]), a1 = wave_sum(fy[s]), a2 = wave_sum(fz[s]);
+            const float a3 = wave_sum(ee[s]), a4 = wave_sum(eg[s]);
+            if (lane == s) {
+                ofx = a0;
+                ofy = a1;
+                ofz = a2;
+                oee = a3;
+                oeg = a4;
+                ow = wi[s];
+            }
         }
-        const int bead = wi >> 3; // -1 for padding slots
-        const bool own = (jj == 0) && (bead >= 0);
+        const int bead = ow >> 3; // -1 for padding slots and for lanes >= 8
+        const bool own = bead >= 0;
         if (own) {
-            g[3 * bead] = -a.fx;
-            g[3 * bead + 1] = -a.fy;
-            g[3 * bead + 2] = -a.fz;
+            // the self pair (r = 0, zero force) was swept with everything else: remove its energy
+            if (EV) {
+                const float u = __builtin_amdgcn_rcpf(1e-20f * __builtin_amdgcn_rsqf(1e-20f) + P.ev_rs);
+                oee -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+            }
+            if (GAUSS) oeg += s_tab[(ow & 7) * 8 + (ow & 7)];
+            g[3 * bead] = -ofx;
+            g[3 * bead + 1] = -ofy;
+            g[3 * bead + 2] = -ofz;
         }
-        const float sev = wave_sum(own ? a.eev : 0.f), seg = wave_sum(own ? a.eg : 0.f);
+        const float sev = wave_sum(own ? oee : 0.f), seg = wave_sum(own ? oeg : 0.f);
         acc_ev += 0.5 * (double)sev;
         acc_g += 0.5 * (double)seg;
     }
