@@ -172,22 +172,38 @@ void prof_collect(mmx_handle_s *h, mmx_stats *out) {
 template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
+    const bool rank2 = h->has_cob && !h->has_scb; // amplitude table = Ea*[A][A] + Eb*[B][B] only
+#define NBJ(PM, EV, GA, SC, OPT)                                                                            \
+    hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
+                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part)
 #define NBC(EV, GA)                                                                                         \
     do {                                                                                                    \
         if (h->nb_variant == 1)                                                                             \
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
-        else if (!(EV && GA) || P.ev_rc2 == P.g_rc2)                                                        \
-            hipLaunchKernelGGL((k_nb_clusters_j<PMODE, EV, GA, true>), dim3(grid), dim3(256), 0, h->stream,  \
-                               P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);  \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_nb_clusters_j<PMODE, EV, GA, false>), dim3(grid), dim3(256), 0, h->stream, \
-                               P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part);  \
+        else if (!(EV && GA) || P.ev_rc2 == P.g_rc2) {                                                      \
+            /* default: cutoff by v_fma clamp + one energy accumulator pair per lane (measured best);       \
+               nb_variant bits 16/32/64 toggle rank-2 amplitudes / compare-select cutoff / per-i energies */ \
+            const int opt = ((GA && rank2 && (h->nb_variant & 16)) ? 1 : 0) | ((h->nb_variant & 32) ? 0 : 2) | \
+                            ((h->nb_variant & 64) ? 0 : 4);                                                 \
+            switch (opt) {                                                                                  \
+            case 0: NBJ(PMODE, EV, GA, true, 0); break;                                                     \
+            case 1: NBJ(PMODE, EV, GA, true, 1); break;                                                     \
+            case 2: NBJ(PMODE, EV, GA, true, 2); break;                                                     \
+            case 3: NBJ(PMODE, EV, GA, true, 3); break;                                                     \
+            case 4: NBJ(PMODE, EV, GA, true, 4); break;                                                     \
+            case 5: NBJ(PMODE, EV, GA, true, 5); break;                                                     \
+            case 6: NBJ(PMODE, EV, GA, true, 6); break;                                                     \
+            default: NBJ(PMODE, EV, GA, true, 7); break;                                                    \
+            }                                                                                               \
+        } else                                                                                              \
+            NBJ(PMODE, EV, GA, false, 0);                                                                   \
     } while (0)
     if (P.use_ev && P.use_gauss) NBC(true, true);
     else if (P.use_ev) NBC(true, false);
     else NBC(false, true);
 #undef NBC
+#undef NBJ
 }
 
 template <int PMODE>

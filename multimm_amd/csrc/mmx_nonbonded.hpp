@@ -170,10 +170,18 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
 // VALU with scalar i operands: no LDS tile, no staging pass, no barrier.  The 8x5 per-i accumulators
 // are folded over the wave by shuffles once per i-cluster; energies leave as one double per block.
 // ------------------------------------------------------------------------------------------------
+// sat(a*b + c) in ONE VALU issue (clamp output modifier).  hipcc lowers __saturatef(fmaf()) to two
+// v_cmp/v_cndmask pairs (~17 cycles on gfx950, measured); v_fma_f32 ... clamp is a plain 2-cycle op.
+__device__ __forceinline__ float fma_sat(float a, float b_sgpr, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "s"(b_sgpr), "v"(c));
+    return r;
+}
+
 constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
-template <int PMODE, bool EV, bool GAUSS, bool SAMECUT>
+template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT>
 __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
@@ -182,6 +190,9 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                                                        const MinState *__restrict__ st, float *__restrict__ g,
                                                        double *__restrict__ part) {
     if (st->phase == PH_DONE) return;
+    constexpr bool RANK2 = (OPT & 1) != 0;  // amplitude = aA_i*alpha_j + aB_i*beta_j instead of an LDS lookup
+    constexpr bool SATMASK = (OPT & 2) != 0; // cutoff by v_fma clamp instead of v_cmp + v_cndmask
+    constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
     __shared__ int s_list[4][kListCap + 72];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ double s_e[2][4];
@@ -195,14 +206,23 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
     int *list = s_list[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float rc2 = P.rc2max;
-    const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8));
+    const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
+    const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
+    const float ev_c = P.ev_eps * s3 * s3; // eps*sigma^6 (PMODE 6)
+    // step(rc^2 - r^2) = sat(1e30*(rc^2 - r^2)): exact for every representable r^2 (1 ulp of 0.36 * 1e30 >> 1)
+    const float nbig = -1e30f;
+    const float cut_all = 1e30f * fminf(rc2, 1e6f), cut_ev = 1e30f * fminf(P.ev_rc2, 1e6f),
+                cut_g = 1e30f * fminf(P.g_rc2, 1e6f);
     double acc_ev = 0.0, acc_g = 0.0;
 
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
         const int c = __float_as_int(lo_i.w);
         // i-cluster -> scalar registers
-        const float4 pv = spos4[(size_t)icl * kCl + slot];
+        float4 pv = spos4[(size_t)icl * kCl + slot];
+        // padding slots sit at +1e18 in spos4 (they are also j entries of this very cluster): as i beads
+        // move them elsewhere so that pad-pad pairs are outside the cutoff as well
+        if (__float_as_int(pv.w) < 0) pv.x = pv.y = pv.z = 3e18f;
         float xi[kCl], yi[kCl], zi[kCl];
         int wi[kCl];
 #pragma unroll
@@ -212,9 +232,14 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
             zi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), s));
             wi[s] = __builtin_amdgcn_readlane(__float_as_int(pv.w), s);
         }
-        float fx[kCl], fy[kCl], fz[kCl], ee[kCl], eg[kCl];
+        float fx[kCl], fy[kCl], fz[kCl], ee[kCl], eg[kCl], aA[kCl], aB[kCl];
 #pragma unroll
-        for (int s = 0; s < kCl; ++s) fx[s] = fy[s] = fz[s] = ee[s] = eg[s] = 0.f;
+        for (int s = 0; s < kCl; ++s) {
+            fx[s] = fy[s] = fz[s] = ee[s] = eg[s] = 0.f;
+            const int li = wi[s] & 7; // label + 2: A compartments are 3,4; B compartments are 0,1
+            aA[s] = (li == 3 || li == 4) ? P.table[3 * 5 + 3] : 0.f;
+            aB[s] = (li == 0 || li == 1) ? P.table[0 * 5 + 0] : 0.f;
+        }
 
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
@@ -266,27 +291,40 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                     jn = list[(t + 1) * 8 + sub];
                     qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
                 }
-                const int ljo = __float_as_int(q.w) & 7;
+                const int lj = __float_as_int(q.w) & 7;
+                // rank-2 amplitude (compartment blocks only): A(s_i,s_j) = aA_i*alpha_j + aB_i*beta_j
+                const float alpha_j = (lj == 3 || lj == 4) ? 1.f : 0.f, beta_j = (lj == 0 || lj == 1) ? 1.f : 0.f;
 #pragma unroll
                 for (int s = 0; s < kCl; ++s) {
                     const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
                     const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                    const bool in = r2 < rc2;
+                    // exact step function of the cutoff without v_cmp/v_cndmask: sat(BIG*(rc^2 - r^2))
+                    const float in = SATMASK ? fma_sat(r2, nbig, cut_all) : (r2 < rc2 ? 1.f : 0.f);
                     const float r2s = r2 + 1e-20f;
                     const float rinv = __builtin_amdgcn_rsqf(r2s);
                     float fs = 0.f;
                     if (EV) {
-                        const float r = r2s * rinv;
-                        const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
-                        float E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
-                        E = (in && (SAMECUT || r2 < P.ev_rc2)) ? E : 0.f;
-                        ee[s] += E;
-                        fs = P.ev_power * E * u * rinv;
+                        const float u = __builtin_amdgcn_rcpf(fmaf(r2s, rinv, P.ev_rs));
+                        float E;
+                        if (PMODE == 6) {
+                            const float u2 = u * u;
+                            E = (u2 * u2) * (u2 * ev_c);
+                        } else {
+                            E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                        }
+                        if (SATMASK) E *= SAMECUT ? in : fma_sat(r2, nbig, cut_ev);
+                        else E = (r2 < (SAMECUT ? rc2 : P.ev_rc2)) ? E : 0.f;
+                        ee[ESPLIT ? s : 0] += E;
+                        fs = (P.ev_power * E) * (u * rinv);
                     }
                     if (GAUSS) {
-                        float gg = s_tab[(wi[s] & 7) * 8 + ljo] * __builtin_amdgcn_exp2f(r2 * P.g_c2);
-                        gg = (in && (SAMECUT || r2 < P.g_rc2)) ? gg : 0.f;
-                        eg[s] -= gg;
+                        float A;
+                        if (RANK2) A = fmaf(aA[s], alpha_j, aB[s] * beta_j);
+                        else A = s_tab[(wi[s] & 7) * 8 + lj];
+                        float gg = A * __builtin_amdgcn_exp2f(r2 * P.g_c2);
+                        if (SATMASK) gg *= SAMECUT ? in : fma_sat(r2, nbig, cut_g);
+                        else gg = (r2 < (SAMECUT ? rc2 : P.g_rc2)) ? gg : 0.f;
+                        eg[ESPLIT ? s : 0] -= gg;
                         fs = fmaf(-gg, P.g_inv_rc2, fs);
                     }
                     fx[s] = fmaf(fs, dx, fx[s]);
@@ -298,35 +336,43 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
             wave_lds_sync();
         }
         // ---- fold over the wave; lane s (< 8) ends up owning bead s of the i-cluster
-        float ofx = 0.f, ofy = 0.f, ofz = 0.f, oee = 0.f, oeg = 0.f;
+        float ofx = 0.f, ofy = 0.f, ofz = 0.f;
         int ow = -8;
 #pragma unroll
         for (int s = 0; s < kCl; ++s) {
             const float a0 = wave_sum(fx[s]), a1 = wave_sum(fy[s]), a2 = wave_sum(fz[s]);
-            const float a3 = wave_sum(ee[s]), a4 = wave_sum(eg[s]);
             if (lane == s) {
                 ofx = a0;
                 ofy = a1;
                 ofz = a2;
-                oee = a3;
-                oeg = a4;
                 ow = wi[s];
             }
+        }
+        float tev = 0.f, teg = 0.f;
+#pragma unroll
+        for (int s = 0; s < (ESPLIT ? kCl : 1); ++s) {
+            tev += ee[s];
+            teg += eg[s];
         }
         const int bead = ow >> 3; // -1 for padding slots and for lanes >= 8
         const bool own = bead >= 0;
         if (own) {
             // the self pair (r = 0, zero force) was swept with everything else: remove its energy
             if (EV) {
-                const float u = __builtin_amdgcn_rcpf(1e-20f * __builtin_amdgcn_rsqf(1e-20f) + P.ev_rs);
-                oee -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                const float u = __builtin_amdgcn_rcpf(fmaf(1e-20f, __builtin_amdgcn_rsqf(1e-20f), P.ev_rs));
+                if (PMODE == 6) {
+                    const float u2 = u * u;
+                    tev -= (u2 * u2) * (u2 * ev_c);
+                } else {
+                    tev -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                }
             }
-            if (GAUSS) oeg += s_tab[(ow & 7) * 8 + (ow & 7)];
+            if (GAUSS) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
             g[3 * bead] = -ofx;
             g[3 * bead + 1] = -ofy;
             g[3 * bead + 2] = -ofz;
         }
-        const float sev = wave_sum(own ? oee : 0.f), seg = wave_sum(own ? oeg : 0.f);
+        const float sev = wave_sum(tev), seg = wave_sum(teg);
         acc_ev += 0.5 * (double)sev;
         acc_g += 0.5 * (double)seg;
     }
