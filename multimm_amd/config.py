@@ -1,0 +1,141 @@
+"""config.ini reader for the minimizer path.
+
+Accepts the same ``[Main]`` keys as the reference (``run.py:334-376`` upper-cases every key,
+``config.py:94-312`` gives types/defaults) for everything the path consumes, applies the
+``MODELLING_LEVEL`` presets of ``ArgumentChanger.convenient_argument_changer`` (``run.py:128-213``)
+and adds ``PLATFORM = MI355X`` plus the engine-only key ``NB_CUTOFF``.  Quantity strings such as
+``"0.1 nanometer"`` (``config.py:24-49``) reduce to floats in nm / kJ/mol / rad.
+"""
+from __future__ import annotations
+
+import configparser
+import dataclasses
+import re
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+from .system import ForceFieldParams
+
+_BOOL_TRUE = {"true", "1", "yes", "on"}
+_BOOL_FALSE = {"false", "0", "no", "off", "", "none"}
+
+
+def parse_quantity(text: Any) -> float:
+    """'300000.0 kilojoules_per_mole/nanometer**2' -> 300000.0 (leading number, OpenMM base units)."""
+    if isinstance(text, (int, float)):
+        return float(text)
+    m = re.match(r"\s*([-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?)", str(text))
+    if not m:
+        raise ValueError(f"cannot parse quantity {text!r}")
+    val = float(m.group(1))
+    unit = str(text)[m.end():].strip().lower()
+    if unit.startswith("angstrom"):
+        val *= 0.1
+    elif unit.startswith("degree"):
+        val *= 3.141592653589793 / 180.0
+    return val
+
+
+def parse_bool(text: Any) -> bool:
+    if isinstance(text, bool):
+        return text
+    t = str(text).strip().lower()
+    if t in _BOOL_TRUE:
+        return True
+    if t in _BOOL_FALSE:
+        return False
+    raise ValueError(f"cannot parse boolean {text!r}")
+
+
+@dataclass
+class SimulationConfig:
+    """Subset of the reference's SimulationConfig that the minimizer path reads."""
+
+    PLATFORM: str = "MI355X"
+    DEVICE: int = 0
+    MODELLING_LEVEL: str = ""
+    N_BEADS: int = 50000
+    OUT_PATH: str = "results"
+    INITIAL_STRUCTURE_TYPE: str = "hilbert"
+    INITIAL_STRUCTURE_PATH: Optional[str] = None
+    BUILD_INITIAL_STRUCTURE: bool = True
+    LOOPS_PATH: str = ""
+    COMPARTMENT_PATH: Optional[str] = None
+    CHROM: Optional[str] = None
+    LOC_START: Optional[int] = None
+    LOC_END: Optional[int] = None
+    SHUFFLING_SEED: int = 0
+    N_ENSEMBLE: Optional[int] = None
+    SIM_RUN_MD: bool = False
+    MIN_TOLERANCE: float = 10.0        # OpenMM minimizeEnergy() default, kJ/mol/nm
+    MIN_MAX_ITERATIONS: int = 0        # 0 = until converged
+    ff: ForceFieldParams = field(default_factory=ForceFieldParams)
+
+    def apply_modelling_level(self) -> None:
+        """Presets of run.py:137-213 (only the keys on this path)."""
+        level = str(self.MODELLING_LEVEL).lower()
+        has_comp = bool(self.COMPARTMENT_PATH)
+        ff = self.ff
+        if level == "gene":
+            self.N_BEADS = 1000
+            ff.SC_USE_SPHERICAL_CONTAINER = ff.CHB_USE_CHROMOSOMAL_BLOCKS = False
+            ff.SCB_USE_SUBCOMPARTMENT_BLOCKS = ff.COB_USE_COMPARTMENT_BLOCKS = False
+            ff.IBL_USE_B_LAMINA_INTERACTION = ff.CF_USE_CENTRAL_FORCE = False
+            self.SIM_RUN_MD = True
+        elif level in ("region", "loc", "chromosome", "chrom"):
+            self.N_BEADS = 5000 if level in ("region", "loc") else 20000
+            ff.SC_USE_SPHERICAL_CONTAINER = ff.CHB_USE_CHROMOSOMAL_BLOCKS = False
+            ff.SCB_USE_SUBCOMPARTMENT_BLOCKS = False
+            ff.COB_USE_COMPARTMENT_BLOCKS = has_comp
+            ff.IBL_USE_B_LAMINA_INTERACTION = ff.CF_USE_CENTRAL_FORCE = False
+            self.SIM_RUN_MD = True
+        elif level in ("gw", "genome"):
+            self.N_BEADS = 200000
+            ff.SC_USE_SPHERICAL_CONTAINER = True
+            ff.CHB_USE_CHROMOSOMAL_BLOCKS = ff.SCB_USE_SUBCOMPARTMENT_BLOCKS = False
+            ff.COB_USE_COMPARTMENT_BLOCKS = has_comp
+            ff.IBL_USE_B_LAMINA_INTERACTION = has_comp
+            ff.CF_USE_CENTRAL_FORCE = False
+            self.SIM_RUN_MD = False
+        elif level:
+            raise ValueError(f"unknown MODELLING_LEVEL {self.MODELLING_LEVEL!r}")
+
+
+_FF_FIELDS = {f.name: f.type for f in dataclasses.fields(ForceFieldParams)}
+
+
+def load_config(path_or_dict) -> SimulationConfig:
+    """Reads ``[Main]`` of an ini file (or a flat dict) into a SimulationConfig; unknown keys that belong
+    to parts of MultiMM outside this path (plots, MD, nucleosomes, ...) are ignored."""
+    if isinstance(path_or_dict, dict):
+        raw = {str(k).upper(): v for k, v in path_or_dict.items()}
+    else:
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        if not cp.read(path_or_dict):
+            raise FileNotFoundError(path_or_dict)
+        raw = {k.upper(): v for k, v in cp["Main"].items()}
+    cfg = SimulationConfig()
+    ffkw = {}
+    for key, val in raw.items():
+        if key in _FF_FIELDS:
+            cur = getattr(cfg.ff, key)
+            ffkw[key] = parse_bool(val) if isinstance(cur, bool) else parse_quantity(val)
+        elif hasattr(cfg, key) and key != "ff":
+            cur = getattr(cfg, key)
+            sval = None if (isinstance(val, str) and val.strip().lower() in ("", "none")) else val
+            if isinstance(cur, bool):
+                setattr(cfg, key, parse_bool(val))
+            elif key in ("N_BEADS", "SHUFFLING_SEED", "MIN_MAX_ITERATIONS", "DEVICE"):
+                setattr(cfg, key, int(float(sval)) if sval is not None else getattr(cfg, key))
+            elif key in ("LOC_START", "LOC_END", "N_ENSEMBLE"):
+                setattr(cfg, key, int(float(sval)) if sval is not None else None)
+            elif key == "MIN_TOLERANCE":
+                setattr(cfg, key, parse_quantity(val))
+            else:
+                setattr(cfg, key, sval if sval is None else str(sval))
+    cfg.ff = dataclasses.replace(cfg.ff, **ffkw)
+    cfg.apply_modelling_level()
+    if cfg.ff.CHB_USE_CHROMOSOMAL_BLOCKS:
+        raise NotImplementedError("CHB_USE_CHROMOSOMAL_BLOCKS is not on the MI355X path yet (SURVEY.md section 8 f1)")
+    return cfg

@@ -1,0 +1,131 @@
+"""``MultiMM`` for ``PLATFORM = MI355X``: the reference's simulation entry point with OpenMM replaced.
+
+Mirrors the part of ``src/multimm/model.py`` that sits on the minimizer path -- same method names,
+same order, same outputs:
+
+    run() = set_radiuses -> initialize_simulation -> add_forcefield -> min_energy -> save_chromosomes
+
+(model.py:1216-1248).  What is NOT rebuilt: MD, plots, nucleosome interpolation, file parsers
+(SURVEY.md section 2).  Inputs that the reference parses from .bedpe/.bed files are taken as arrays
+(``ms, ns, ds, chr_ends, Cs``) or generated synthetically with the same tensor contracts.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Optional
+
+import numpy as np
+
+from . import cif
+from .config import SimulationConfig, load_config
+from .engine import Engine, MMXError
+from .hilbert import hilbert_points
+from .system import ChromatinSystem, set_radiuses, synthetic_system
+
+logger = logging.getLogger("multimm_amd")
+
+
+class MultiMM:
+    def __init__(self, args: SimulationConfig | str | dict, ms=None, ns=None, ds=None, chr_ends=None, Cs=None,
+                 chrom_strength=None):
+        """``args``: SimulationConfig, ini path or flat dict.  ``ms, ns, ds, chr_ends, Cs`` are the tensors
+        ``MultiMM.__init__`` (model.py:105-132) obtains from import_bed / import_mns_from_bedpe; when
+        omitted they are generated synthetically (seed = SHUFFLING_SEED)."""
+        self.args = args if isinstance(args, SimulationConfig) else load_config(args)
+        if str(self.args.PLATFORM).upper() not in ("MI355X", "GFX950"):
+            raise ValueError(f"PLATFORM={self.args.PLATFORM!r}: this package only provides the MI355X platform")
+        n = int(self.args.N_BEADS)
+        if ms is None:
+            preset = "gw_200k" if str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") else "chr1_50k"
+            syn = synthetic_system(preset, seed=int(self.args.SHUFFLING_SEED), n_beads=n)
+            ms, ns, ds = syn.loop_m, syn.loop_n, syn.loop_r0
+            chr_ends = syn.chr_ends if chr_ends is None else chr_ends
+            Cs = syn.labels if Cs is None else Cs
+        self.ms, self.ns, self.ds = np.asarray(ms), np.asarray(ns), np.asarray(ds)
+        self.chr_ends = np.asarray(chr_ends if chr_ends is not None else [0, n], dtype=np.int32)
+        self.Cs = np.zeros(n, np.int8) if Cs is None else np.asarray(Cs, dtype=np.int8)
+        self.chrom_strength = chrom_strength
+        self.save_path = os.path.join(self.args.OUT_PATH, "")
+        for sub in ("metadata", "model", os.path.join("model", "chromosomes")):
+            os.makedirs(os.path.join(self.args.OUT_PATH, sub), exist_ok=True)
+        self.engine: Optional[Engine] = None
+        self.system: Optional[ChromatinSystem] = None
+        self.stats = None
+
+    # --- model.py:1016-1067 -------------------------------------------------------------------------
+    def set_radiuses(self):
+        self.radius1, self.radius2, self.r_comp = set_radiuses(int(self.args.N_BEADS), self.args.ff.POL_HARMONIC_BOND_R0)
+        logger.info("[Radiuses] b0=%.4f nm | N=%d | R1=%.4f nm | R2=%.4f nm | r_comp=%.4f nm",
+                    self.args.ff.POL_HARMONIC_BOND_R0, self.args.N_BEADS, self.radius1, self.radius2, self.r_comp)
+
+    # --- model.py:722-810 (structure + particles; integrators are MD-only and out of scope) ------------
+    def initialize_simulation(self):
+        n = int(self.args.N_BEADS)
+        init_cif = os.path.join(self.args.OUT_PATH, "metadata", "MultiMM_init.cif")
+        if self.args.BUILD_INITIAL_STRUCTURE or not self.args.INITIAL_STRUCTURE_PATH:
+            kind = str(self.args.INITIAL_STRUCTURE_TYPE).lower()
+            if kind == "hilbert":
+                pts_angstrom = hilbert_points(n).astype(np.float64)
+            elif kind == "circle":
+                th = 2.0 * np.pi * np.arange(n) / n
+                pts_angstrom = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), 50.0 * (np.arange(n) + 1) / n], axis=1)
+            else:
+                raise NotImplementedError(f"INITIAL_STRUCTURE_TYPE={kind!r}: only hilbert and circle are on this path")
+            cif.write_structure(init_cif, pts_angstrom * 0.1, self.chr_ends)
+            positions = cif.read_positions(init_cif)      # %.3f Angstrom round trip, as the reference does
+        else:
+            positions = cif.read_positions(self.args.INITIAL_STRUCTURE_PATH)
+        if len(positions) != n:
+            raise ValueError(f"structure has {len(positions)} beads, N_BEADS={n}")
+        self.positions = positions
+        self.mass_center = positions.mean(axis=0)
+        self.system = ChromatinSystem(n_beads=n, positions=positions, chr_ends=self.chr_ends, labels=self.Cs,
+                                      loop_m=self.ms, loop_n=self.ns, loop_r0=self.ds, ff=self.args.ff,
+                                      chrom_strength=self.chrom_strength, seed=int(self.args.SHUFFLING_SEED))
+
+    # --- model.py:812-857 -----------------------------------------------------------------------------
+    def add_forcefield(self):
+        """Installs the enabled terms in the reference's order on the device engine."""
+        try:
+            self.engine = Engine(self.system.n_beads, int(self.args.DEVICE))
+        except MMXError as e:
+            # the analogue of model.py:862-871's platform fallback, except that there is no CPU platform here
+            raise MMXError(e.code, f"MI355X platform unavailable ({e}); choose another PLATFORM in the reference "
+                                   "MultiMM to run on OpenMM") from e
+        self.engine.load_system(self.system)
+
+    # --- model.py:859-897 -----------------------------------------------------------------------------
+    def min_energy(self):
+        logger.info("Energy minimization...")
+        t0 = time.time()
+        self.stats = self.engine.minimize(tolerance=float(self.args.MIN_TOLERANCE),
+                                          max_iters=int(self.args.MIN_MAX_ITERATIONS))
+        self.state_positions = self.engine.get_positions().astype(np.float64)
+        cif.write_structure(os.path.join(self.args.OUT_PATH, "model", "MultiMM_minimized.cif"), self.state_positions,
+                            self.chr_ends)
+        dt = time.time() - t0
+        logger.info("--- Energy minimization done!! %d iterations, %d evaluations, E %.6g -> %.6g kJ/mol, "
+                    "RMS force %.3g kJ/mol/nm in %.2f s ---", self.stats.iterations, self.stats.evaluations,
+                    self.stats.e_initial, self.stats.e_final, self.stats.rms_force, dt)
+
+    # --- model.py:899-905 -----------------------------------------------------------------------------
+    def save_chromosomes(self):
+        for i in range(len(self.chr_ends) - 1):
+            seg = self.state_positions[self.chr_ends[i]:self.chr_ends[i + 1]]
+            if len(seg):
+                cif.write_chromosome(os.path.join(self.args.OUT_PATH, "model", "chromosomes",
+                                                  f"MultiMM_minimized_chr{i + 1}.cif"), seg)
+
+    # --- model.py:1216-1248 ---------------------------------------------------------------------------
+    def run(self):
+        self.set_radiuses()
+        self.initialize_simulation()
+        self.add_forcefield()
+        self.min_energy()
+        if self.args.LOC_START is None:
+            self.save_chromosomes()
+        if self.args.SIM_RUN_MD:
+            logger.warning("SIM_RUN_MD is set but MD is outside the MI355X path (SURVEY.md section 2, row 8): skipped")
+        return self.stats

@@ -1,0 +1,96 @@
+"""Host-side logic: ini config + presets, mmCIF layout, synthetic tensor contracts, MultiMM plumbing."""
+import os
+
+import numpy as np
+import pytest
+
+from multimm_amd import synthetic_system
+from multimm_amd import cif
+from multimm_amd.config import load_config, parse_bool, parse_quantity
+
+
+def test_quantity_and_bool_parsing():
+    assert parse_quantity("0.1 nanometer") == pytest.approx(0.1)
+    assert parse_quantity("300000.0 kilojoules_per_mole/nanometer**2") == 300000.0
+    assert parse_quantity("3.141592653589793 radian") == pytest.approx(np.pi)
+    assert parse_quantity("1 angstrom") == pytest.approx(0.1)
+    assert parse_quantity(2) == 2.0
+    assert parse_bool("True") and not parse_bool("false") and not parse_bool("")
+    with pytest.raises(ValueError):
+        parse_quantity("nanometer")
+
+
+def test_gw_preset_matches_reference_argument_changer(tmp_path):
+    ini = tmp_path / "c.ini"
+    ini.write_text("[Main]\nplatform = MI355X\nmodelling_level = GW\ncompartment_path = comps.bed\n"
+                   "n_beads = 123\nsc_use_spherical_container = False\ncf_use_central_force = True\n")
+    c = load_config(str(ini))
+    # run.py:202-212: the preset overrides the file
+    assert c.N_BEADS == 200000 and c.ff.SC_USE_SPHERICAL_CONTAINER and c.ff.COB_USE_COMPARTMENT_BLOCKS
+    assert c.ff.IBL_USE_B_LAMINA_INTERACTION and not c.ff.CF_USE_CENTRAL_FORCE and not c.SIM_RUN_MD
+    c2 = load_config(dict(MODELLING_LEVEL="region", N_BEADS=77))
+    assert c2.N_BEADS == 5000 and not c2.ff.COB_USE_COMPARTMENT_BLOCKS and not c2.ff.SC_USE_SPHERICAL_CONTAINER
+    with pytest.raises(NotImplementedError):
+        load_config(dict(CHB_USE_CHROMOSOMAL_BLOCKS=True))
+    with pytest.raises(ValueError):
+        load_config(dict(MODELLING_LEVEL="nonsense"))
+
+
+def test_region_ini_like_reference_example(tmp_path):
+    ini = tmp_path / "r.ini"
+    ini.write_text("[Main]\nPLATFORM = MI355X\nINITIAL_STRUCTURE_TYPE = circle\nN_BEADS = 500\n"
+                   "SC_USE_SPHERICAL_CONTAINER = False\nEV_POWER = 3.0\nLE_HARMONIC_BOND_K = 30000.0 kilojoules_per_mole/nanometer**2\n"
+                   "SAVE_PLOTS = True\nNUC_DO_INTERPOLATION = True\n")
+    c = load_config(str(ini))
+    assert c.N_BEADS == 500 and c.INITIAL_STRUCTURE_TYPE == "circle" and c.ff.EV_POWER == 3.0
+
+
+def test_mmcif_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(50, 3))
+    p = tmp_path / "s.cif"
+    cif.write_structure(str(p), x, [0, 20, 50])
+    y = cif.read_positions(str(p))
+    assert y.shape == (50, 3) and np.abs(x - y).max() <= 5.1e-5        # %.3f Angstrom
+    rows = [l.split() for l in p.read_text().splitlines() if l.startswith(("ATOM", "HETATM"))]
+    assert all(len(r) == 13 for r in rows)
+    assert rows[0][0] == "HETATM" and rows[0][5] == "ALB" and rows[5][0] == "ATOM" and rows[5][5] == "ALA"
+    assert rows[19][0] == "HETATM" and rows[20][0] == "HETATM" and rows[20][6] != rows[18][6]   # new chain letter
+    pc = tmp_path / "c.cif"
+    cif.write_chromosome(str(pc), x[:20])
+    assert np.abs(cif.read_positions(str(pc)) - x[:20]).max() <= 5.1e-5
+
+
+def test_synthetic_contracts():
+    s = synthetic_system("gw_200k", n_beads=20000, seed=3)
+    assert len(s.chr_ends) == 23 and s.chr_ends[-1] == 20000
+    assert np.all(s.loop_n > s.loop_m + 2)                                     # utils.py:515-519
+    assert len(set(zip(s.loop_m.tolist(), s.loop_n.tolist()))) == s.n_loops   # unique pairs, utils.py:507
+    assert s.loop_r0.min() >= 0.1 and s.loop_r0.max() <= 0.2
+    k = np.searchsorted(s.chr_ends, s.loop_m, side="right")
+    assert np.all(s.loop_n < s.chr_ends[k])                                    # loops stay inside a chromosome
+    assert set(np.unique(s.labels)) <= {-2, -1, 0, 1, 2}
+    assert np.allclose(np.linalg.norm(np.diff(s.positions, axis=0), axis=1), 0.1)
+    s2 = synthetic_system("gw_200k", n_beads=20000, seed=4)
+    assert not np.array_equal(s.labels, s2.labels)                             # ensemble seeds differ
+    c = synthetic_system("region_5k", n_beads=500, start="circle")
+    assert np.allclose(np.hypot(c.positions[:, 0], c.positions[:, 1]), 0.5)    # radius 5 Angstrom
+
+
+def test_multimm_plumbing_until_the_engine(tmp_path):
+    """run() order of model.py:1216-1248; without a GPU add_forcefield must raise (no CPU platform here)."""
+    import torch
+    from multimm_amd.engine import MMXError
+    from multimm_amd.model import MultiMM
+    cfg = load_config(dict(PLATFORM="MI355X", N_BEADS=300, OUT_PATH=str(tmp_path / "out"), NB_CUTOFF=0.6))
+    m = MultiMM(cfg)
+    m.set_radiuses()
+    assert m.radius2 == pytest.approx(0.1 * 300 ** (1 / 3)) and m.r_comp == pytest.approx(0.15)
+    m.initialize_simulation()
+    assert os.path.exists(tmp_path / "out" / "metadata" / "MultiMM_init.cif")
+    assert m.system.n_beads == 300 and np.allclose(m.mass_center, m.system.centre)
+    if not torch.cuda.is_available():
+        with pytest.raises(MMXError):
+            m.add_forcefield()
+    with pytest.raises(ValueError):
+        MultiMM(load_config(dict(PLATFORM="CUDA", N_BEADS=10, OUT_PATH=str(tmp_path / "o2"))))

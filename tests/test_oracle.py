@@ -1,0 +1,162 @@
+"""CPU tests of the oracle itself: hand-derivable known answers, finite differences
+of its own energy, C vs numpy restatement, reference index quirks, Hilbert start, L-BFGS restatement.
+The reference holds no golden vectors for this path ("parity unpinned"): these tests are what pins it."""
+import numpy as np
+import pytest
+
+from multimm_amd import synthetic_system, hilbert_points, backbone_flags
+from multimm_amd.system import ChromatinSystem, ForceFieldParams, chrom_strength_per_bead, gw_chr_ends, set_radiuses
+
+OFF = dict(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+           EV_USE_EXCLUDED_VOLUME=False, NB_CUTOFF=0.0)
+
+
+def _sys(pos, labels=None, chr_ends=None, loops=None, **ff):
+    pos = np.asarray(pos, dtype=np.float64)
+    n = len(pos)
+    kw = dict(OFF)
+    kw.update(ff)
+    m, nn, r0 = loops if loops else ([], [], [])
+    return ChromatinSystem(n, pos, np.array(chr_ends if chr_ends is not None else [n + 5], np.int32),
+                           np.zeros(n, np.int8) if labels is None else np.asarray(labels, np.int8),
+                           loop_m=m, loop_n=nn, loop_r0=r0, ff=ForceFieldParams(**kw))
+
+
+def _eval(s, **kw):
+    from oracle.oracle import Oracle
+    return Oracle(s, as_float32_inputs=False, **kw).eval()
+
+
+def test_kat_excluded_volume_two_beads(oracle_lib):
+    et, F = _eval(_sys([[0, 0, 0], [0.1, 0, 0]], EV_USE_EXCLUDED_VOLUME=True))
+    e = 100.0 * (0.1 / 0.15) ** 6
+    assert et[0] == pytest.approx(e, rel=1e-12) and e == pytest.approx(8.77915, rel=1e-5)
+    assert F[1, 0] == pytest.approx(6 * e / 0.15, rel=1e-12) and F[0, 0] == pytest.approx(-351.166, rel=1e-5)
+
+
+def test_kat_compartment_gaussian(oracle_lib):
+    pos = [[0, 0, 0], [0.15, 0, 0]]
+    for la, lb, want in ((1, 2, -np.exp(-0.5)), (-1, -2, -2 * np.exp(-0.5)), (1, -1, 0.0), (0, 1, 0.0)):
+        et, _ = _eval(_sys(pos, labels=[la, lb], COB_USE_COMPARTMENT_BLOCKS=True))
+        assert et[1] == pytest.approx(want, abs=1e-12)
+    # SCB: only identical labels interact, amplitudes Ea1(2), Ea2(1), Eb1(-1), Eb2(-2) = 1, 1.33, 1.66, 2
+    for lab, amp in ((2, 1.0), (1, 1.33), (-1, 1.66), (-2, 2.0)):
+        et, _ = _eval(_sys(pos, labels=[lab, lab], SCB_USE_SUBCOMPARTMENT_BLOCKS=True))
+        assert et[1] == pytest.approx(-amp * np.exp(-0.5), rel=1e-12)
+    et, _ = _eval(_sys(pos, labels=[1, 2], SCB_USE_SUBCOMPARTMENT_BLOCKS=True))
+    assert et[1] == 0.0
+
+
+def test_kat_angle_and_bond(oracle_lib):
+    straight = [[0, 0, 0], [0.1, 0, 0], [0.2, 0, 0]]
+    right = [[0, 0, 0], [0.1, 0, 0], [0.1, 0.1, 0]]
+    et, F = _eval(_sys(straight, POL_USE_HARMONIC_ANGLE=True))
+    assert et[3] == pytest.approx(0.0, abs=1e-20) and np.abs(F).max() == 0.0
+    et, F = _eval(_sys(right, POL_USE_HARMONIC_ANGLE=True))
+    assert et[3] == pytest.approx(0.5 * 100 * (np.pi / 2) ** 2, rel=1e-12)  # 123.370
+    # the angle wants to open: end beads are pushed away from each other, |F| = k*(pi/2)/0.1
+    assert F[0, 1] == pytest.approx(-100 * (np.pi / 2) / 0.1, rel=1e-9) and F[2, 0] == pytest.approx(1570.796, rel=1e-6)
+    assert np.abs(F.sum(0)).max() < 1e-9
+    et, F = _eval(_sys([[0, 0, 0], [0.12, 0, 0]], POL_USE_HARMONIC_BOND=True))
+    assert et[2] == pytest.approx(0.5 * 3e5 * 0.02 ** 2) and F[0, 0] == pytest.approx(3e5 * 0.02)
+
+
+def test_kat_container_lamina_central(oracle_lib):
+    n = 1001
+    R1, R2, _ = set_radiuses(n, 0.1)
+    # the other 1000 beads: antipodal pairs on the mid-shell sphere (force-free annulus, mean exactly 0)
+    half = np.random.default_rng(0).normal(size=(500, 3))
+    half *= (0.5 * (R1 + R2)) / np.linalg.norm(half, axis=1, keepdims=True)
+    rest = np.concatenate([half, -half])
+
+    def at_r(r, label, **ff):
+        p = np.zeros((n, 3))
+        p[1:] = rest
+        p[0, 0] = r * n / (n - 1)              # centre = p0/n  =>  |p0 - centre| = r
+        s = _sys(p, labels=[label] + [0] * (n - 1), **ff)
+        assert np.linalg.norm(s.positions[0] - s.centre) == pytest.approx(r, rel=1e-9)
+        return s
+
+    sc = dict(SC_USE_SPHERICAL_CONTAINER=True)
+    et_all, _ = _eval(at_r(R2 + 0.1, 0, **sc))
+    et_in, _ = _eval(at_r(0.5 * (R1 + R2), 0, **sc))
+    assert et_all[5] - et_in[5] == pytest.approx(1000 * 0.01, rel=1e-6)       # C*(r-R2)^2 = 10
+    ibl = dict(IBL_USE_B_LAMINA_INTERACTION=True)
+    assert _eval(at_r(0.5 * (R1 + R2), -1, **ibl))[0][6] == pytest.approx(0.0, abs=1e-9)   # sin^8 = 1
+    assert _eval(at_r(R1, -2, **ibl))[0][6] == pytest.approx(-400.0, rel=1e-9)
+    assert _eval(at_r(R1, 2, **ibl))[0][6] == 0.0
+
+
+def test_finite_difference_gradient_all_terms(oracle_lib):
+    from oracle import oracle_np
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=300, jitter=0.02, NB_CUTOFF=0.0, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
+                         CF_USE_CENTRAL_FORCE=True)
+    et, F = Oracle(s, as_float32_inputs=False).eval()
+    en = oracle_np.energy_terms(s)
+    for i, k in enumerate(("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")):
+        assert et[i] == pytest.approx(en[k], rel=1e-11, abs=1e-9), k
+        assert et[i] != 0.0, k
+    beads = [0, 1, 2, 5, 150, 298, 299] + list(np.unique(np.r_[s.loop_m, s.loop_n])[:3])
+    fd = oracle_np.fd_forces(s, beads=beads)
+    assert np.abs(fd - F[beads]).max() < 1e-3 * np.abs(F).max() * 1e-3 + 1e-3
+
+
+def test_cutoff_cells_match_bruteforce(oracle_lib):
+    from oracle import oracle_np
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=700, jitter=0.03, NB_CUTOFF=0.6)
+    et, F = Oracle(s, as_float32_inputs=False).eval()
+    en = oracle_np.energy_terms(s, cutoff=0.6)
+    assert et[0] == pytest.approx(en["ev"], rel=1e-11) and et[1] == pytest.approx(en["gauss"], rel=1e-11)
+    et0, _ = Oracle(s, cutoff=0.0, as_float32_inputs=False).eval()
+    assert et0[0] > et[0]  # the truncated tail is repulsive energy
+
+
+def test_backbone_quirks_follow_reference(oracle_lib):
+    """bond (i,i+1) missing iff i in chr_ends; angle missing iff i in chr_ends or chr_ends-1 (model.py:629,712)."""
+    from oracle.oracle import backbone_flags_c
+    n = 40
+    ce = np.array([0, 11, 25, n])
+    f = backbone_flags(n, ce)
+    assert np.array_equal(f, backbone_flags_c(n, ce))
+    bonds = [i for i in range(n - 1) if i not in ce]
+    angles = [i for i in range(n - 2) if (i not in ce) and (i not in ce - 1)]
+    assert [i for i in range(n) if f[i] & 1] == bonds and [i for i in range(n) if f[i] & 2] == angles
+    assert not (f[0] & 1) and (f[10] & 1) and not (f[11] & 1) and (f[12] & 1)   # boundary shifted by one bead
+    assert not (f[10] & 2) and not (f[11] & 2) and (f[9] & 2)
+
+
+def test_hilbert_curve_properties(oracle_lib):
+    from oracle.oracle import hilbert_points_c
+    p = hilbert_points(5000)
+    assert p[:10].tolist() == [[0, 0, 0], [0, 1, 0], [1, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [0, 1, 1], [0, 0, 1],
+                               [0, 0, 2], [0, 0, 3]]
+    assert np.array_equal(p, hilbert_points_c(5000))
+    assert np.all(np.abs(np.diff(p, axis=0)).sum(1) == 1)          # consecutive beads are lattice neighbours
+    assert len({tuple(r) for r in p}) == len(p)
+    for k in (1, 2, 3, 4):                                           # first 8^k points tile a 2^k cube
+        assert p[:8 ** k].max() == 2 ** k - 1
+
+
+def test_gw_chr_ends_and_strength():
+    ce = gw_chr_ends(200000)
+    assert len(ce) == 23 and ce[0] == 0 and ce[-1] == 200000 and np.all(np.diff(ce) > 0)
+    w = chrom_strength_per_bead(ce, 200000)
+    assert w.min() >= 0 and w.max() <= 1 and w[0] == pytest.approx(0.0)
+
+
+def test_lbfgs_restatement_converges(oracle_lib):
+    from oracle.oracle import Oracle
+    s = synthetic_system("region_5k", n_beads=400, jitter=0.01, NB_CUTOFF=0.6)
+    orc = Oracle(s, as_float32_inputs=False)
+    x, st = orc.minimize(tolerance=10.0, max_iters=0)
+    assert st.status == 0 and st.iterations > 5 and st.e_final < st.e_initial
+    _, F = orc.eval(x)
+    # OpenMM stop rule: |g| / max(1,|x|) <= tol / max(1, rms|x_i|)
+    xr = np.asarray(s.positions)
+    eps = 10.0 / max(1.0, np.sqrt((xr * xr).sum() / len(xr)))
+    assert np.linalg.norm(F) / max(1.0, np.linalg.norm(x)) <= eps * (1 + 1e-9)
+    # fixed iteration budget is honoured exactly
+    _, st2 = orc.minimize(tolerance=0.0, max_iters=7)
+    assert st2.iterations == 7 and st2.status == 1 and st2.evaluations >= 8
