@@ -182,19 +182,16 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
         else if (!(EV && GA) || P.ev_rc2 == P.g_rc2) {                                                      \
-            /* default: cutoff by v_fma clamp + one energy accumulator pair per lane (measured best);       \
-               nb_variant bits 16/32/64 toggle rank-2 amplitudes / compare-select cutoff / per-i energies */ \
-            const int opt = ((GA && rank2 && (h->nb_variant & 16)) ? 1 : 0) | ((h->nb_variant & 32) ? 0 : 2) | \
-                            ((h->nb_variant & 64) ? 0 : 4);                                                 \
+            /* default: cutoff by v_fma clamp + one energy accumulator pair per lane + per-bead cull;       \
+               nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
+            const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) |               \
+                            ((h->nb_variant & 128) ? 0 : 8);                                                \
             switch (opt) {                                                                                  \
-            case 0: NBJ(PMODE, EV, GA, true, 0); break;                                                     \
-            case 1: NBJ(PMODE, EV, GA, true, 1); break;                                                     \
-            case 2: NBJ(PMODE, EV, GA, true, 2); break;                                                     \
-            case 3: NBJ(PMODE, EV, GA, true, 3); break;                                                     \
-            case 4: NBJ(PMODE, EV, GA, true, 4); break;                                                     \
-            case 5: NBJ(PMODE, EV, GA, true, 5); break;                                                     \
+            case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
             case 6: NBJ(PMODE, EV, GA, true, 6); break;                                                     \
-            default: NBJ(PMODE, EV, GA, true, 7); break;                                                    \
+            case 12: NBJ(PMODE, EV, GA, true, 12); break;                                                   \
+            case 10: NBJ(PMODE, EV, GA, true, 10); break;                                                   \
+            default: NBJ(PMODE, EV, GA, true, 0); break;                                                    \
             }                                                                                               \
         } else                                                                                              \
             NBJ(PMODE, EV, GA, false, 0);                                                                   \

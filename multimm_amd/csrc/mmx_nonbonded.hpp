@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
     constexpr bool RANK2 = (OPT & 1) != 0;  // amplitude = aA_i*alpha_j + aB_i*beta_j instead of an LDS lookup
     constexpr bool SATMASK = (OPT & 2) != 0; // cutoff by v_fma clamp instead of v_cmp + v_cndmask
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
+    constexpr bool BEADCULL = (OPT & 8) != 0; // per-bead second-level cull + LDS ring compaction
     __shared__ int s_list[4][kListCap + 72];
+    __shared__ float4 s_ring[4][BEADCULL ? 128 : 1];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ double s_e[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
     const int ncl = st->n_clusters;
     __syncthreads();
     int *list = s_list[wave];
+    float4 *ring = s_ring[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float rc2 = P.rc2max;
     const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
         const int nrows = (z1 - z0 + 1) * (y1 - y0 + 1);
         int nlist = 0;
         int row_i = 0, base = 0, c1 = 0;
+        int rcount = 0, rhead = 0; // LDS ring of compacted j beads (BEADCULL)
         bool more = true;
         while (more) {
             // ---- cull: fill the list with accepted j-clusters (lanes = candidate clusters)
@@ -277,19 +281,40 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                 nlist += __popcll(mask);
                 base += 64;
             }
-            if (nlist == 0) break;
-            // pad to a multiple of 8 clusters with "no cluster"
+            if (nlist == 0 && (!BEADCULL || rcount == 0)) break;
+            // pad to a multiple of 8 clusters with "no cluster" (also gives the ring its flush step)
             if (lane < 8) list[nlist + lane] = -1;
             wave_lds_sync();
-            const int nsteps = (nlist + 7) >> 3;
+            const int nsteps = max((nlist + 7) >> 3, 1);
             // ---- sweep: 8 j-clusters (64 j beads) per step against the 8 scalar i beads
             int jn = list[sub];
             float4 qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
             for (int t = 0; t < nsteps; ++t) {
-                const float4 q = qn;
+                float4 q = qn;
                 if (t + 1 < nsteps) { // prefetch the next 8 clusters
                     jn = list[(t + 1) * 8 + sub];
                     qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
+                }
+                if (BEADCULL) {
+                    // second-level cull per j BEAD against the i-cluster box; survivors are compacted
+                    // through a 128-entry LDS ring so that every swept lane holds a useful neighbour
+                    const float bx = fmaxf(fmaxf(lo_i.x - q.x, q.x - hi_i.x), 0.f);
+                    const float by = fmaxf(fmaxf(lo_i.y - q.y, q.y - hi_i.y), 0.f);
+                    const float bz = fmaxf(fmaxf(lo_i.z - q.z, q.z - hi_i.z), 0.f);
+                    const bool okb = fmaf(bx, bx, fmaf(by, by, bz * bz)) < rc2;
+                    const unsigned long long mb = __ballot(okb);
+                    if (okb) ring[(rhead + rcount + __popcll(mb & lt)) & 127] = q;
+                    rcount += __popcll(mb);
+                }
+                const bool last = !more && (t + 1 == nsteps);
+                // BEADCULL: drain the ring 64 beads at a time (everything at the very last step)
+                for (int pass = 0; BEADCULL ? (rcount >= 64 || (last && rcount > 0)) : (pass == 0); ++pass) {
+                if (BEADCULL) {
+                    wave_lds_sync();
+                    q = lane < rcount ? ring[(rhead + lane) & 127] : far4;
+                    const int took = min(rcount, 64);
+                    rhead = (rhead + took) & 127;
+                    rcount -= took;
                 }
                 const int lj = __float_as_int(q.w) & 7;
                 // rank-2 amplitude (compartment blocks only): A(s_i,s_j) = aA_i*alpha_j + aB_i*beta_j
@@ -331,6 +356,7 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                     fy[s] = fmaf(fs, dy, fy[s]);
                     fz[s] = fmaf(fs, dz, fz[s]);
                 }
+                } // drain passes
             }
             nlist = 0;
             wave_lds_sync();
