@@ -323,11 +323,14 @@ void enqueue_accept(mmx_handle_s *h) {
     EventPair ep{};
     const int g4 = std::min((h->n4 + 255) / 256, 1024);
     bool on = prof_begin(h, MMX_K_LBFGS, ep);
-    hipLaunchKernelGGL(k_history, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
-                       (const float4 *)h->g, (float4 *)h->gp, (float4 *)h->S, (float4 *)h->Y, h->rows, h->st);
-    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, g4, h->rows, h->st);
-    hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->g,
-                       (const float4 *)h->S, (const float4 *)h->Y, (float4 *)h->d, h->st);
+    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
+    hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
+                       (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (float4 *)h->S,
+                       (float4 *)h->Y, h->rows, h->st);
+    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
+    hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
+                       (const float4 *)h->g, (float4 *)h->gp, (const float4 *)h->S, (const float4 *)h->Y,
+                       (float4 *)h->d, h->st);
     prof_end(h, on, ep);
 }
 
@@ -804,8 +807,8 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     }
     HIPCHK(h, hipGetLastError());
     const MinState &s = *h->st_host;
-    if (s.status < 0 && s.evals > 1) {
-        // line search failed: liblbfgs reverts to the last accepted point
+    if (s.status <= MMX_MIN_LS_MIN_STEP && s.evals > 1) {
+        // line search failed (-3..-6): liblbfgs reverts to the last accepted point
         const int g4 = std::min((h->n4 + 255) / 256, 1024);
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->xp, (float4 *)h->x);
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->gp, (float4 *)h->g);

@@ -238,11 +238,42 @@ __device__ __forceinline__ unsigned long long order_key(const float4 p, const Gr
     return ((unsigned long long)m << 32) | (unsigned)bead;
 }
 
-// One wave per cell (grid-stride): orders the cell's beads along a Morton curve of 16^3 sub-cells (ties
-// by bead id: bitwise reproducible summation order, and 8 consecutive entries form a spatially compact
-// cluster), emits the cell's work items {cell, chunk}, the padded cluster positions and cluster boxes
-// and clears count for the next build.
-constexpr int kOrderLds = 1024;
+// Orders every cell's beads along a Morton curve of 16^3 sub-cells (ties by bead id: bitwise
+// reproducible summation order, and 8 consecutive entries form a spatially compact cluster), emits the
+// cell's work items {cell, chunk}, the padded cluster positions and cluster boxes and clears count for
+// the next build.  Two grid-stride passes in one launch: cells of <= 64 beads are sorted by ONE WAVE in
+// registers (bitonic over __shfl_xor); larger cells by the WHOLE BLOCK in LDS (bitonic, <= 4096 beads).
+constexpr int kOrderLds = 4096;
+
+// padded cluster positions + boxes of one sorted cell; `nthr` cooperating threads, thread index `tid`
+__device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, const int *__restrict__ perm,
+                                              const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
+                                              float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
+                                              int nthr) {
+    const int ncl = (cnt + 7) >> 3;
+    for (int e = tid; e < ncl * 8; e += nthr) {
+        float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
+        if (e < cnt) p = pos4[perm[s + e]];
+        spos4[(size_t)cb * 8 + e] = p;
+        const float big = 3.0e38f;
+        float lx = e < cnt ? p.x : big, ly = e < cnt ? p.y : big, lz = e < cnt ? p.z : big;
+        float hx = e < cnt ? p.x : -big, hy = e < cnt ? p.y : -big, hz = e < cnt ? p.z : -big;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            lx = fminf(lx, __shfl_xor(lx, o, 64));
+            ly = fminf(ly, __shfl_xor(ly, o, 64));
+            lz = fminf(lz, __shfl_xor(lz, o, 64));
+            hx = fmaxf(hx, __shfl_xor(hx, o, 64));
+            hy = fmaxf(hy, __shfl_xor(hy, o, 64));
+            hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+        }
+        if ((e & 7) == 0) {
+            cl_lo[cb + (e >> 3)] = make_float4(lx, ly, lz, __int_as_float(c));
+            cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float(min(8, cnt - e)));
+        }
+    }
+}
+
 template <int CHUNK>
 __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
                                                     const int *__restrict__ start, const int *__restrict__ istart,
@@ -253,22 +284,21 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int deterministic, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ unsigned long long s_buf[4][kOrderLds];
+    __shared__ unsigned long long s_buf[kOrderLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
     const int ncells = G.ncells;
-    const int nwaves = gridDim.x * 4;
-    unsigned long long *buf = s_buf[wave];
     const unsigned long long kmax = ~0ull;
-    for (int c = blockIdx.x * 4 + wave; c < ncells; c += nwaves) {
+
+    // ---- pass A: one wave per small cell
+    for (int c = blockIdx.x * 4 + wave; c < ncells; c += gridDim.x * 4) {
         const int s = start[c], cnt = start[c + 1] - s;
+        if (cnt > 64) continue;
         if (lane == 0) count[c] = 0;
         if (cnt == 0) continue;
-        const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
-        for (int k = lane; k < nchunk; k += 64) items[ib + k] = make_int2(c, k);
+        if (lane == 0) items[istart[c]] = make_int2(c, 0);
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         if (cnt > 1) {
-        if (cnt <= 64) {
             unsigned long long v = kmax;
             if (lane < cnt) {
                 const int b = perm[s + lane];
@@ -284,64 +314,53 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                 }
             }
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
-        } else if (cnt <= kOrderLds) {
+            __threadfence_block(); // the sorted perm[] is re-read below by other lanes
+        }
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64);
+    }
+
+    // ---- pass B: the whole block per large cell
+    for (int c = blockIdx.x; c < ncells; c += gridDim.x) {
+        const int s = start[c], cnt = start[c + 1] - s;
+        if (cnt <= 64) continue; // block-uniform
+        if (threadIdx.x == 0) count[c] = 0;
+        const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
+        for (int k = threadIdx.x; k < nchunk; k += 256) items[ib + k] = make_int2(c, k);
+        const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
+        if (cnt <= kOrderLds) {
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
-            for (int q = lane; q < n2; q += 64) {
+            __syncthreads(); // s_buf free
+            for (int q = threadIdx.x; q < n2; q += 256) {
                 unsigned long long v = kmax;
                 if (q < cnt) {
                     const int b = perm[s + q];
                     v = order_key(pos4[b], G, cx, cy, cz, b);
                 }
-                buf[q] = v;
+                s_buf[q] = v;
             }
-            wave_lds_sync();
+            __syncthreads();
             for (int k = 2; k <= n2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int q = lane; q < (n2 >> 1); q += 64) {
+                    for (int q = threadIdx.x; q < (n2 >> 1); q += 256) {
                         const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                         const int i1 = i0 | j;
-                        const unsigned long long a = buf[i0], b = buf[i1];
+                        const unsigned long long a = s_buf[i0], b = s_buf[i1];
                         const bool up = (i0 & k) == 0;
                         if ((a > b) == up) {
-                            buf[i0] = b;
-                            buf[i1] = a;
+                            s_buf[i0] = b;
+                            s_buf[i1] = a;
                         }
                     }
-                    wave_lds_sync();
+                    __syncthreads();
                 }
             }
-            for (int q = lane; q < cnt; q += 64) perm[s + q] = (int)(unsigned)(buf[q] & 0xffffffffull);
-            wave_lds_sync();
+            for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
+            __threadfence_block();
+            __syncthreads();
         }
         // cells above kOrderLds beads keep arrival order (still correct, not bitwise reproducible)
-        }
-        // ---- cluster view of the cell for the cluster-pair kernel: padded, cell-sorted positions and the
-        // bounding box of every 8-bead cluster (lo.w = cell id, hi.w = bead count of the cluster)
-        __threadfence_block(); // the sorted perm[] written above is re-read below by other lanes
-        wave_lds_sync();
-        const int ncl = (cnt + 7) >> 3, cb = cstart[c];
-        for (int e = lane; e < ncl * 8; e += 64) {
-            float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
-            if (e < cnt) p = pos4[perm[s + e]];
-            spos4[(size_t)cb * 8 + e] = p;
-            const float big = 3.0e38f;
-            float lx = e < cnt ? p.x : big, ly = e < cnt ? p.y : big, lz = e < cnt ? p.z : big;
-            float hx = e < cnt ? p.x : -big, hy = e < cnt ? p.y : -big, hz = e < cnt ? p.z : -big;
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                lx = fminf(lx, __shfl_xor(lx, o, 64));
-                ly = fminf(ly, __shfl_xor(ly, o, 64));
-                lz = fminf(lz, __shfl_xor(lz, o, 64));
-                hx = fmaxf(hx, __shfl_xor(hx, o, 64));
-                hy = fmaxf(hy, __shfl_xor(hy, o, 64));
-                hz = fmaxf(hz, __shfl_xor(hz, o, 64));
-            }
-            if ((e & 7) == 0) {
-                cl_lo[cb + (e >> 3)] = make_float4(lx, ly, lz, __int_as_float(c));
-                cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float(min(8, cnt - e)));
-            }
-        }
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256);
     }
 }
 

@@ -17,39 +17,46 @@ struct CtlArgs {
 
 constexpr int kCtlThreads = 1024;
 
-// Deterministic sums of NS partial-sum slots by one 1024-thread block: every thread strides over
-// every slot (independent loads, latency overlapped), wave-shuffle reduce, then a fixed-order fold of
-// the 16 wave partials.  out[s] is valid on all threads after the call.
+// Deterministic sums of NS partial-sum slots by one 1024-thread block.  Work is cut in tasks of
+// (slot, 1024-entry segment); each of the 16 waves takes tasks round-robin, issues its 16 loads per lane
+// back to back and shuffle-reduces; thread s then folds the task results of slot s in task order.
+// out[s] is valid on all threads after the call.
+constexpr int kMaxTasks = 16 * 4 + 48; // segments of the few large slots + one per small slot
 template <int NS>
 __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, int stride, const int *nblk,
-                                               double *s_wave /* [NS][16] */, double *s_out /* [NS] */) {
+                                               double *s_task /* [kMaxTasks] */, int *s_first /* [NS+1] */,
+                                               double *s_out /* [NS] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int s0 = 0; s0 < NS; s0 += 4) {
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + u;
-            if (s < NS) {
-                const int n = nblk[s];
-                const double *p = part + (size_t)s * stride;
-                for (int i = threadIdx.x; i < n; i += kCtlThreads) v[u] += p[i];
-            }
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int s = 0; s < NS; ++s) {
+            s_first[s] = t;
+            t += (nblk[s] + 1023) >> 10;
         }
+        s_first[NS] = min(t, kMaxTasks);
+    }
+    __syncthreads();
+    const int ntask = s_first[NS];
+    for (int task = wave; task < ntask; task += 16) {
+        int s = 0;
+        while (s + 1 < NS && s_first[s + 1] <= task) ++s;
+        const int seg = task - s_first[s];
+        const int n = nblk[s];
+        const double *p = part + (size_t)s * stride + (size_t)seg * 1024;
+        const int m = min(1024, n - seg * 1024);
+        double v = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + u;
-            if (s < NS) {
-                const double w = wave_sum(v[u]);
-                if (lane == 0) s_wave[s * 16 + wave] = w;
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int i = lane + 64 * k;
+            v += i < m ? p[i] : 0.0;
         }
+        v = wave_sum(v);
+        if (lane == 0) s_task[task] = v;
     }
     __syncthreads();
     if ((int)threadIdx.x < NS) {
         double r = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) r += s_wave[threadIdx.x * 16 + w];
+        for (int t = s_first[threadIdx.x]; t < min(s_first[threadIdx.x + 1], kMaxTasks); ++t) r += s_task[t];
         s_out[threadIdx.x] = r;
     }
     __syncthreads();
@@ -60,12 +67,12 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
 __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
                                                      MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ double s_wave[P_NSLOTS * 16];
+    __shared__ double s_task[kMaxTasks];
     __shared__ double s_out[P_NSLOTS];
-    __shared__ int s_n[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
     if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
     __syncthreads();
-    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_wave, s_out);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
     if (threadIdx.x != 0) return;
     double sums[P_NSLOTS];
 #pragma unroll
@@ -159,22 +166,43 @@ __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const doub
     st->store_hist = 1;
 }
 
-// Accepted step: s = x - xp, y = g - gp into slot `end`; xp <- x, gp <- g; and the Gram rows of
-// {s_new, y_new, g} against the whole basis as block partials rows[(r*13 + b)*stride + block].
-// Streams 4+2m vectors once: (4 + 12) * 4 B reads + 4*4 B writes per float.
-__global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                                 const float4 *__restrict__ g, float4 *__restrict__ gp,
+// Accepted step: s = x - xp, y = g - gp into slot `end`, and the Gram rows of {s_new, y_new, g}
+// against the whole basis as block partials rows[(r*13 + b)*stride + blockIdx.x].
+// 2-D grid: blockIdx.y picks a group of <= 4 basis columns (12 fp64 accumulators per thread instead of
+// 39: full occupancy); every group re-reads x, xp, g, gp (L2/MALL resident), only the last group
+// stores the new pair.  xp <- x and gp <- g are done afterwards by k_direction (no intra-kernel race).
+constexpr int kHistGroups = 4;
+__global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restrict__ x, const float4 *__restrict__ xp,
+                                                 const float4 *__restrict__ g, const float4 *__restrict__ gp,
                                                  float4 *__restrict__ S, float4 *__restrict__ Y,
                                                  double *__restrict__ rows, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE || !st->accepted) return;
-    __shared__ double s_w[MMX_NROWS * MMX_NBASIS * 4];
+    __shared__ double s_w[MMX_NROWS * 4 * 4];
     const int slot = st->end;
     const bool store = st->store_hist != 0;
-    double acc[MMX_NROWS][MMX_NBASIS];
+    const int cg = blockIdx.y, col0 = cg * 4, ncol = min(4, MMX_NBASIS - col0);
+    const float4 *colp[4];
+    int colkind[4]; // 0: stored vector, 1: s_new, 2: y_new, 3: g
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = col0 + k;
+        colp[k] = x;
+        colkind[k] = 0;
+        if (b < MMX_M) {
+            colp[k] = S + (size_t)b * n4;
+            if (store && b == slot) colkind[k] = 1;
+        } else if (b < 2 * MMX_M) {
+            colp[k] = Y + (size_t)(b - MMX_M) * n4;
+            if (store && b - MMX_M == slot) colkind[k] = 2;
+        } else {
+            colkind[k] = 3;
+        }
+    }
+    double acc[MMX_NROWS][4];
 #pragma unroll
     for (int r = 0; r < MMX_NROWS; ++r)
 #pragma unroll
-        for (int b = 0; b < MMX_NBASIS; ++b) acc[r][b] = 0.0;
+        for (int k = 0; k < 4; ++k) acc[r][k] = 0.0;
 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
         const float4 X = x[i], XP = xp[i], G = g[i], GP = gp[i];
@@ -184,45 +212,39 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
             sn = make_float4(0.f, 0.f, 0.f, 0.f);
             yn = sn;
         }
-        xp[i] = X;
-        gp[i] = G;
-        float4 B[MMX_NBASIS];
-#pragma unroll
-        for (int a = 0; a < MMX_M; ++a) {
-            B[a] = S[(size_t)a * n4 + i];
-            B[MMX_M + a] = Y[(size_t)a * n4 + i];
-        }
-        B[2 * MMX_M] = G;
-        if (store) {
-#pragma unroll
-            for (int a = 0; a < MMX_M; ++a)
-                if (a == slot) {
-                    B[a] = sn;
-                    B[MMX_M + a] = yn;
-                }
+        if (store && cg == kHistGroups - 1) {
             S[(size_t)slot * n4 + i] = sn;
             Y[(size_t)slot * n4 + i] = yn;
         }
 #pragma unroll
-        for (int b = 0; b < MMX_NBASIS; ++b) {
-            const float4 v = B[b];
-            acc[0][b] += (double)(sn.x * v.x + sn.y * v.y) + (double)(sn.z * v.z + sn.w * v.w);
-            acc[1][b] += (double)(yn.x * v.x + yn.y * v.y) + (double)(yn.z * v.z + yn.w * v.w);
-            acc[2][b] += (double)(G.x * v.x + G.y * v.y) + (double)(G.z * v.z + G.w * v.w);
+        for (int k = 0; k < 4; ++k) {
+            if (k < ncol) {
+                float4 v;
+                if (colkind[k] == 0) v = colp[k][i];
+                else if (colkind[k] == 1) v = sn;
+                else if (colkind[k] == 2) v = yn;
+                else v = G;
+                acc[0][k] += (double)(sn.x * v.x + sn.y * v.y) + (double)(sn.z * v.z + sn.w * v.w);
+                acc[1][k] += (double)(yn.x * v.x + yn.y * v.y) + (double)(yn.z * v.z + yn.w * v.w);
+                acc[2][k] += (double)(G.x * v.x + G.y * v.y) + (double)(G.z * v.z + G.w * v.w);
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < MMX_NROWS; ++r)
 #pragma unroll
-        for (int b = 0; b < MMX_NBASIS; ++b) {
-            const double s = wave_sum(acc[r][b]);
-            if (lane == 0) s_w[(r * MMX_NBASIS + b) * 4 + wave] = s;
+        for (int k = 0; k < 4; ++k) {
+            const double sm = wave_sum(acc[r][k]);
+            if (lane == 0) s_w[(r * 4 + k) * 4 + wave] = sm;
         }
     __syncthreads();
-    if (threadIdx.x < MMX_NROWS * MMX_NBASIS) {
-        const double *q = s_w + threadIdx.x * 4;
-        rows[(size_t)threadIdx.x * kPartStride + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+    if (threadIdx.x < MMX_NROWS * 4) {
+        const int r = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (k < ncol) {
+            const double *q = s_w + threadIdx.x * 4;
+            rows[(size_t)(r * MMX_NBASIS + col0 + k) * kPartStride + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
     }
 }
 
@@ -231,12 +253,12 @@ __global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double 
                                                          MinState *__restrict__ st) {
     if (st->phase == PH_DONE || !st->accepted) return;
     constexpr int NQ = MMX_NROWS * MMX_NBASIS;
-    __shared__ double s_wave[NQ * 16];
+    __shared__ double s_task[kMaxTasks];
     __shared__ double s_rows[NQ];
-    __shared__ int s_n[NQ];
+    __shared__ int s_n[NQ], s_first[NQ + 1];
     if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
     __syncthreads();
-    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_wave, s_rows);
+    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
     if (threadIdx.x != 0) return;
     constexpr int NB = MMX_NBASIS, M = MMX_M, IG = 2 * MMX_M;
     double *G = st->gram;
@@ -299,15 +321,27 @@ __global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double 
 }
 
 // d = sum_a coef[a] * B_a.  Streams 13 vectors in, one out.
-__global__ __launch_bounds__(256) void k_direction(int n4, const float4 *__restrict__ g,
+__global__ __launch_bounds__(256) void k_direction(int n4, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                                   const float4 *__restrict__ g, float4 *__restrict__ gp,
                                                    const float4 *__restrict__ S, const float4 *__restrict__ Y,
                                                    float4 *__restrict__ d, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || !st->accepted) return;
+    // runs whenever a step was accepted (also when k_direction_coef then stopped the minimizer): the accepted
+    // point becomes the previous point of the next line search
+    if (!st->accepted || st->phase == PH_IDLE) return;
+    if (st->phase == PH_DONE) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+            xp[i] = x[i];
+            gp[i] = g[i];
+        }
+        return;
+    }
     float c[MMX_NBASIS];
 #pragma unroll
     for (int b = 0; b < MMX_NBASIS; ++b) c[b] = (float)st->coef[b];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
         const float4 G = g[i];
+        xp[i] = x[i];
+        gp[i] = G;
         float4 o = make_float4(c[2 * MMX_M] * G.x, c[2 * MMX_M] * G.y, c[2 * MMX_M] * G.z, c[2 * MMX_M] * G.w);
 #pragma unroll
         for (int a = 0; a < MMX_M; ++a) {
