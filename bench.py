@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg; 0 disables")
     ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--nb-traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the pair kernel from a separate rocprofv3 --pmc run "
+                         "(profiles/): copied into roofline.traffic")
     return ap.parse_args()
 
 
@@ -131,9 +134,9 @@ def main():
         roofline = None
         if nb_us:
             achieved = NB_BYTES_PER_BEAD * n / (nb_us * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_nb_cells" if args.cutoff > 0 else "k_nb_allpairs",
+            roofline = {"bound": "hbm", "kernel": "k_nb_clusters_j" if args.cutoff > 0 else "k_nb_allpairs",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "launch_us": nb_us,
+                        "traffic": args.nb_traffic_bytes, "launch_us": nb_us,
                         "samples": int(st.kernel_samples[K_NONBONDED])}
             if census:
                 pairs = census["pairs_within_cutoff"]  # directed pairs (each pair visited from both ends)
@@ -142,6 +145,9 @@ def main():
                                          "frac": tf / VALU_PEAK_TFLOPS, "pairs_within_cutoff": pairs,
                                          "pair_candidates": census["pair_candidates"]}
         kern = {k: v for k, v in d["kernel_us_mean"].items() if v}
+        alg_bytes = {"cell_build": 56.0 * n, "backbone": 25.0 * n, "loops": 64.0 * system.n_loops,
+                     "confine": 25.0 * n, "lbfgs": 384.0 * n}
+        kernel_gbs = {k: alg_bytes[k] / (kern[k] * 1e-6) / 1e9 for k in alg_bytes if k in kern}
         ms_per_step = dt * 1e3 / max(iters, 1)
         out = {
             "metric": "minimizer iters/sec @ genome-wide N beads",
@@ -166,6 +172,7 @@ def main():
             "iterations": iters, "evaluations": st.evaluations, "evals_per_s": st.evaluations * world / dt,
             "status": st.status, "e_initial": st.e_initial, "e_final": st.e_final, "rms_force": st.rms_force,
             "kernel_us_mean": kern,
+            "kernel_algorithmic_GBps": kernel_gbs,
             "roofline": roofline,
         }
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
