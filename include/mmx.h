@@ -99,8 +99,23 @@ const char *mmx_last_error(mmx_handle h);
 /* Library/ABI version, for loaders. */
 int mmx_abi_version(void);
 
+/* ---- multi-GPU (BASELINE config 5; no counterpart in the reference, which is single-device) ----
+ * One process and one handle per GPU.  Rank r of `world` owns the contiguous bead range
+ * [r*slice, min(N, (r+1)*slice)), slice = ceil(N/world): forces, energies and the L-BFGS state of those
+ * beads live on its GPU.  Every setter still takes the arrays of the WHOLE system.  Per evaluation the
+ * ranks all-gather their position slices (ghost beads for pair, bond, angle and loop terms) and
+ * all-reduce 16 doubles (energies, g.d, g.g, x.x); per accepted iteration 40 doubles (Gram rows) --
+ * RCCL, issued on the handle's stream, no host round trip.  Without a communicator a multi-rank
+ * handle still evaluates its owned beads against the positions last set by the host (unit tests). */
+int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out);
+int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world);
+/* rank 0: 128-byte ncclUniqueId to hand to every rank (e.g. by torch.distributed broadcast). */
+int mmx_comm_unique_id(uint8_t *id128);
+/* every rank: ncclCommInitRank on the handle's device with the handle's rank/world (collective). */
+int mmx_comm_init(mmx_handle h, const uint8_t *id128);
+
 /* ---- system description (replaces the OpenMM Force-object construction in model.py) ----------- */
-/* context.setPositions, model.py:877.  xyz_nm is [N,3] row-major. */
+/* context.setPositions, model.py:877.  xyz_nm is [N,3] row-major (always the whole system). */
 int mmx_set_positions(mmx_handle h, const float *xyz_nm);
 /* context.getState(getPositions=True).getPositions(), model.py:889-892. */
 int mmx_get_positions(mmx_handle h, float *xyz_nm);
@@ -143,7 +158,9 @@ int mmx_get_option(mmx_handle h, const char *key, double *value);
 
 /* ---- compute (parity hook) --------------------------------------------------------------------
  * One evaluation of all enabled terms at the current positions: context.getState(getEnergy=True,
- * getForces=True).  forces_out is [N,3] (may be NULL), energy_terms_out is [MMX_N_TERMS]. */
+ * getForces=True).  forces_out is [N,3] (may be NULL; multi-GPU: [n_own,3], the owned beads),
+ * energy_terms_out is [MMX_N_TERMS] (multi-GPU: all-reduced when a communicator exists, else this
+ * rank's share). */
 int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out);
 
 /* ---- minimize ---------------------------------------------------------------------------------

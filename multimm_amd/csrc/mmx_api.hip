@@ -7,6 +7,9 @@
 #include "mmx_lbfgs.hpp"
 #include "mmx_nonbonded.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the symbols are resolved with dlopen/dlsym when a communicator is requested
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -31,8 +34,51 @@ struct EventPair {
 
 } // namespace
 
+// RCCL entry points, loaded lazily (single-GPU users never need librccl.so)
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static bool load_rccl(std::string &err) {
+    if (g_rccl.lib) return true;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        err = std::string("cannot load librccl.so: ") + dlerror();
+        return false;
+    }
+#define RSYM(field, name)                                                                                  \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name);                                               \
+    if (!g_rccl.field) {                                                                                   \
+        err = std::string("librccl.so lacks ") + name;                                                     \
+        return false;                                                                                      \
+    }
+    RSYM(GetUniqueId, "ncclGetUniqueId");
+    RSYM(CommInitRank, "ncclCommInitRank");
+    RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllGather, "ncclAllGather");
+    RSYM(AllReduce, "ncclAllReduce");
+    RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+    g_rccl.lib = lib;
+    return true;
+}
+
 struct mmx_handle_s {
     int n = 0, n4 = 0, device = 0;
+    // domain decomposition (single GPU: rank 0 of 1, owns every bead)
+    int rank = 0, world = 1, slice = 0; // slice = beads per rank (n padded to world * slice = n_all)
+    int n_all = 0, own_lo = 0, n_own = 0;
+    ncclComm_t comm = nullptr;
+    float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
+    bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation
     hipStream_t stream = nullptr;
     FFParams P{};
     bool have_pos = false;
@@ -43,7 +89,7 @@ struct mmx_handle_s {
     uint8_t *flags = nullptr;
     float *cf_w = nullptr;
     // cells
-    int *cell_of = nullptr, *count = nullptr, *rank = nullptr, *start = nullptr, *istart = nullptr,
+    int *cell_of = nullptr, *count = nullptr, *rank_in_cell = nullptr, *start = nullptr, *istart = nullptr,
         *perm = nullptr;
     int2 *items = nullptr;
     int *cstart = nullptr;                       // cluster offsets per cell
@@ -119,6 +165,9 @@ float hmin_of(const mmx_handle_s *h) {
 void refresh_params(mmx_handle_s *h) {
     FFParams &P = h->P;
     P.n = h->n;
+    P.n_all = h->n_all;
+    P.own_lo = h->own_lo;
+    P.n_own = h->n_own;
     const float inf = std::numeric_limits<float>::infinity();
     P.ev_rc2 = (P.use_ev && h->ev_cut > 0.f) ? h->ev_cut * h->ev_cut : inf;
     P.g_rc2 = (P.use_gauss && h->g_cut > 0.f) ? h->g_cut * h->g_cut : inf;
@@ -223,35 +272,51 @@ int nb_grid(const mmx_handle_s *h) {
         return std::max(256, std::min(g, kPartStride));
     }
     // cluster kernel: 4 clusters (waves) per block, grid-stride beyond the estimate
-    int cl = h->last_clusters > 0 ? h->last_clusters : h->n / 8 + 4096;
+    int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     int g = (cl + cl / 8) / 4 + 64;
     return std::max(256, std::min(g, kPartStride));
 }
 
-void enqueue_build(mmx_handle_s *h, bool move, bool init = false) {
-    const int n = h->n;
-    const int gb = (n + 255) / 256;
-    if (move)
-        hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
-                           h->pos4, h->bbox_part, h->st);
+// Fills pos4 of every bead from the host-set global positions (multi-GPU: beads of other ranks are
+// needed as ghosts before the first all-gather of a call).
+__global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const float *__restrict__ xg,
+                                                       const int8_t *__restrict__ labels, float4 *__restrict__ pos4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_all) return;
+    if (i < n)
+        pos4[i] = make_float4(xg[3 * i], xg[3 * i + 1], xg[3 * i + 2], __int_as_float((i << 3) | ((int)labels[i] + 2)));
     else
-        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, n, h->x, h->xp, h->d, h->labels,
-                           h->pos4, h->bbox_part, h->st);
+        pos4[i] = make_float4(3e18f, 3e18f, 3e18f, __int_as_float(-8 + 2)); // padding of the last slice
+}
+
+void enqueue_build(mmx_handle_s *h, bool move, bool init = false) {
+    const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
+    const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
+    const bool dd = h->world > 1 || h->n_own != h->n;
+    if (move)
+        hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
+                           h->labels, h->pos4, h->bbox_part, h->st);
+    else
+        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
+                           h->labels, h->pos4, h->bbox_part, h->st);
+    if (h->comm) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
+        (void)g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat, h->comm,
+                               h->stream);
     if (has_nb(h) && !all_pairs(h)) {
         const float hm = hmin_of(h);
         GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
-        if (init)
-            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells, cur,
-                               h->st);
-        hipLaunchKernelGGL(k_cell_count, dim3(gb), dim3(256), 0, h->stream, n, h->pos4, cur, h->cell_of, h->rank,
-                           h->count, h->st);
+        if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
+            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
+                               dd ? hm : 0.f, cur, h->st);
+        hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4, cur,
+                           h->cell_of, h->rank_in_cell, h->count, h->st);
         hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox_part, gb, hm,
                            h->maxcells, h->count, h->start, h->istart, h->cstart, cur, next, h->st);
-        hipLaunchKernelGGL(k_cell_fill, dim3(gb), dim3(256), 0, h->stream, n, h->cell_of, h->rank, h->start, h->perm,
-                           h->st);
+        hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
+                           h->start, h->perm, h->st);
         hipLaunchKernelGGL((k_cell_order<kChunk>), dim3(1024), dim3(256), 0, h->stream, cur, h->start, h->istart,
-                           h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                           h->deterministic, h->st);
+                           h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi, h->own_lo,
+                           h->n_own, h->st);
         h->gcur = cur;
         h->build_idx++;
     }
@@ -291,7 +356,7 @@ void enqueue_eval(mmx_handle_s *h, bool move) {
     }
     prof_end(h, on, ep);
 
-    const int gb = grid_beads(h->n);
+    const int gb = grid_beads(h->n_own);
     if (h->flags && (h->P.use_bond || h->P.use_angle)) {
         on = prof_begin(h, MMX_K_BACKBONE, ep);
         hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
@@ -314,7 +379,13 @@ void enqueue_eval(mmx_handle_s *h, bool move) {
     A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
 
     on = prof_begin(h, MMX_K_REDUCE, ep);
-    hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
+    if (!h->comm) {
+        hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
+    } else { // energies + g.d, g.g, x.x of all ranks: one fp64 all-reduce of 16 doubles per evaluation
+        hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
+        (void)g_rccl.AllReduce(h->st->sums, h->st->sums, 16, ncclDouble, ncclSum, h->comm, h->stream);
+        hipLaunchKernelGGL(k_controller_decide, dim3(1), dim3(64), 0, h->stream, h->st);
+    }
     prof_end(h, on, ep);
 }
 
@@ -327,7 +398,14 @@ void enqueue_accept(mmx_handle_s *h) {
     hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
                        (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (float4 *)h->S,
                        (float4 *)h->Y, h->rows, h->st);
-    hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
+    if (!h->comm) {
+        hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
+    } else { // the 39 Gram-row entries of all ranks: one fp64 all-reduce per accepted iteration
+        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
+        (void)g_rccl.AllReduce(h->st->rowsum, h->st->rowsum, MMX_NROWS * MMX_NBASIS + 1, ncclDouble, ncclSum,
+                               h->comm, h->stream);
+        hipLaunchKernelGGL(k_direction_coef_decide, dim3(1), dim3(64), 0, h->stream, h->st);
+    }
     hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
                        (const float4 *)h->g, (float4 *)h->gp, (const float4 *)h->S, (const float4 *)h->Y,
                        (float4 *)h->d, h->st);
@@ -374,8 +452,15 @@ int prepare(mmx_handle_s *h) {
     if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set (mmx_set_positions)");
     HIPCHK(h, hipSetDevice(h->device));
     refresh_params(h);
+    if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
+        return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
     int rc = ensure_allpairs_scratch(h);
     if (rc) return rc;
+    if (h->xg && h->pos4_dirty) { // ghosts of the first evaluation come from the host-set global positions
+        hipLaunchKernelGGL(k_fill_pos4_all, dim3((h->n_all + 255) / 256), dim3(256), 0, h->stream, h->n, h->n_all,
+                           h->xg, h->labels, h->pos4);
+        h->pos4_dirty = false;
+    }
     return MMX_OK;
 }
 
@@ -388,11 +473,15 @@ int mmx_abi_version(void) { return 1; }
 
 const char *mmx_last_error(mmx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
+static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) {
     if (!out) return MMX_ERR_BAD_ARG;
     *out = nullptr;
     if (n_beads < 1 || n_beads > (1 << 28)) {
         g_create_error = "n_beads out of range";
+        return MMX_ERR_BAD_ARG;
+    }
+    if (world < 1 || rank < 0 || rank >= world || world > n_beads) {
+        g_create_error = "rank/world out of range";
         return MMX_ERR_BAD_ARG;
     }
     int ndev = 0;
@@ -416,9 +505,15 @@ int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
     mmx_handle_s *h = new (std::nothrow) mmx_handle_s();
     if (!h) return MMX_ERR_BAD_ARG;
     h->n = n_beads;
-    h->n4 = (3 * n_beads + 3) / 4;
+    h->rank = rank;
+    h->world = world;
+    h->slice = (n_beads + world - 1) / world;       // equal slices (ncclAllGather), the last one is padded
+    h->n_all = h->slice * world;
+    h->own_lo = rank * h->slice;
+    h->n_own = std::max(0, std::min(n_beads, h->own_lo + h->slice) - h->own_lo);
+    h->n4 = (3 * h->n_own + 3) / 4;
     h->device = device_id;
-    h->max_items = (n_beads + kChunk - 1) / kChunk + std::min(n_beads, h->maxcells) + 64;
+    h->max_items = (h->n_all + kChunk - 1) / kChunk + std::min(h->n_all, h->maxcells) + 64;
     auto boot = [&]() -> int {
         HIPCHK(h, hipSetDevice(device_id));
         HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -430,21 +525,24 @@ int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
         HIPCHK(h, dalloc(&h->d, nv));
         HIPCHK(h, dalloc(&h->S, nv * MMX_M));
         HIPCHK(h, dalloc(&h->Y, nv * MMX_M));
-        HIPCHK(h, dalloc(&h->pos4, (size_t)h->n));
-        HIPCHK(h, dalloc(&h->labels, (size_t)h->n));
-        HIPCHK(h, dalloc(&h->cell_of, (size_t)h->n));
-        HIPCHK(h, dalloc(&h->perm, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->pos4, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->labels, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->cell_of, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->perm, (size_t)h->n_all));
+        if (h->world > 1) HIPCHK(h, dalloc(&h->xg, (size_t)3 * h->n_all));
         HIPCHK(h, dalloc(&h->count, (size_t)h->maxcells + 1));
-        HIPCHK(h, dalloc(&h->rank, (size_t)h->n));
+        HIPCHK(h, dalloc(&h->rank_in_cell, (size_t)h->n_all));
         HIPCHK(h, dalloc(&h->start, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->istart, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->items, (size_t)h->max_items));
         HIPCHK(h, dalloc(&h->cstart, (size_t)h->maxcells + 1));
-        HIPCHK(h, dalloc(&h->spos4, (size_t)h->n * 8)); // every cluster holds >= 1 bead: <= N clusters
-        HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n));
-        HIPCHK(h, dalloc(&h->cl_hi, (size_t)h->n));
+        // clusters hold >= 1 bead; a rank only bins its owned beads and the ghosts inside its grid, but the
+        // bound that needs no host knowledge is "every bead": n_all clusters
+        HIPCHK(h, dalloc(&h->spos4, (size_t)h->n_all * 8));
+        HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->cl_hi, (size_t)h->n_all));
         HIPCHK(h, dalloc(&h->grid, 2));
-        HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n + 255) / 256)));
+        HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n_own + 255) / 256 + 1)));
         HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
         HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWS * MMX_NBASIS * kPartStride));
         HIPCHK(h, dalloc(&h->st, 1));
@@ -469,12 +567,57 @@ int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) {
     return MMX_OK;
 }
 
+int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) { return create_impl(n_beads, 0, 1, device_id, out); }
+
+int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) {
+    return create_impl(n_beads, rank, world, device_id, out);
+}
+
+int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    if (own_lo) *own_lo = h->own_lo;
+    if (n_own) *n_own = h->n_own;
+    if (rank) *rank = h->rank;
+    if (world) *world = h->world;
+    return MMX_OK;
+}
+
+int mmx_comm_unique_id(uint8_t *id128) {
+    if (!id128) return MMX_ERR_BAD_ARG;
+    if (!load_rccl(g_create_error)) return MMX_ERR_RCCL;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) {
+        g_create_error = "ncclGetUniqueId failed";
+        return MMX_ERR_RCCL;
+    }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, 128);
+    return MMX_OK;
+}
+
+int mmx_comm_init(mmx_handle h, const uint8_t *id128) {
+    if (!h || !id128) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    if (h->comm) return fail(h, MMX_ERR_STATE, "communicator already initialised");
+    if (!load_rccl(h->err)) return MMX_ERR_RCCL;
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    const ncclResult_t r = g_rccl.CommInitRank(&h->comm, h->world, id, h->rank);
+    if (r != ncclSuccess) {
+        h->comm = nullptr;
+        return fail(h, MMX_ERR_RCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
+    return MMX_OK;
+}
+
 int mmx_destroy(mmx_handle h) {
     if (!h) return MMX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    if (h->xg) (void)hipFree(h->xg);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
-                    h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank,     h->start,     h->istart,
+                    h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
                     h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
                     h->row_start, h->partner, h->loop_r0, h->fpart, h->epart, h->cstart, h->spos4, h->cl_lo, h->cl_hi};
     for (void *p : bufs)
@@ -498,7 +641,13 @@ int mmx_set_positions(mmx_handle h, const float *xyz) {
     HIPCHK(h, hipSetDevice(h->device));
     for (size_t i = 0; i < (size_t)3 * h->n; ++i)
         if (!std::isfinite(xyz[i])) return fail(h, MMX_ERR_BAD_ARG, "non-finite position");
-    HIPCHK(h, hipMemcpyAsync(h->x, xyz, sizeof(float) * 3 * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    // the L-BFGS point holds the owned beads only; xyz is always the WHOLE system [N,3]
+    HIPCHK(h, hipMemcpyAsync(h->x, xyz + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own,
+                             hipMemcpyHostToDevice, h->stream));
+    if (h->xg) {
+        HIPCHK(h, hipMemcpyAsync(h->xg, xyz, sizeof(float) * 3 * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        h->pos4_dirty = true;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_pos = true;
     return MMX_OK;
@@ -508,8 +657,24 @@ int mmx_get_positions(mmx_handle h, float *xyz) {
     if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(xyz, h->x, sizeof(float) * 3 * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    if (h->world == 1) {
+        HIPCHK(h, hipMemcpyAsync(xyz, h->x, sizeof(float) * 3 * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MMX_OK;
+    }
+    // multi-GPU: every rank holds every bead's position in pos4 (all-gathered at the last evaluation);
+    // the owned slice is taken from the L-BFGS point itself
+    int rc = prepare(h);
+    if (rc) return rc;
+    std::vector<float4> p4((size_t)h->n);
+    HIPCHK(h, hipMemcpyAsync(p4.data(), h->pos4, sizeof(float4) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->n; ++i) {
+        xyz[3 * i] = p4[i].x;
+        xyz[3 * i + 1] = p4[i].y;
+        xyz[3 * i + 2] = p4[i].z;
+    }
+    HIPCHK(h, hipMemcpy(xyz + (size_t)3 * h->own_lo, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
     return MMX_OK;
 }
 
@@ -519,6 +684,7 @@ int mmx_set_labels(mmx_handle h, const int8_t *s) {
         if (s[i] < -2 || s[i] > 2) return fail(h, MMX_ERR_BAD_ARG, "label outside {-2..2}");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->labels, s, (size_t)h->n, hipMemcpyHostToDevice));
+    if (h->xg) h->pos4_dirty = true;
     return MMX_OK;
 }
 
@@ -580,7 +746,7 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
     }
     std::vector<int> row_of((size_t)h->n, -1), row_bead, row_start;
     int ne = 0;
-    for (int b = 0; b < h->n; ++b)
+    for (int b = h->own_lo; b < h->own_lo + h->n_own; ++b) // rows of the beads this handle owns
         if (deg[b]) {
             row_of[b] = (int)row_bead.size();
             row_bead.push_back(b);
@@ -591,12 +757,16 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
     std::vector<int> fill(row_start.begin(), row_start.end()), partner((size_t)ne);
     std::vector<float> er0((size_t)ne);
     for (int l = 0; l < n_loops; ++l) {
-        int q = fill[row_of[m[l]]]++;
-        partner[q] = n[l];
-        er0[q] = r0[l];
-        q = fill[row_of[n[l]]]++;
-        partner[q] = m[l];
-        er0[q] = r0[l];
+        if (row_of[m[l]] >= 0) {
+            const int q = fill[row_of[m[l]]]++;
+            partner[q] = n[l];
+            er0[q] = r0[l];
+        }
+        if (row_of[n[l]] >= 0) {
+            const int q = fill[row_of[n[l]]]++;
+            partner[q] = m[l];
+            er0[q] = r0[l];
+        }
     }
     for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0})
         if (p) (void)hipFree(p);
@@ -748,7 +918,7 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
     if (energy_terms_out)
         for (int t = 0; t < MMX_N_TERMS; ++t) energy_terms_out[t] = h->st_host->eterms[t];
     if (forces_out) {
-        std::vector<float> g((size_t)3 * h->n);
+        std::vector<float> g((size_t)3 * h->n_own); // forces of the owned beads [n_own,3]
         HIPCHK(h, hipMemcpy(g.data(), h->g, sizeof(float) * g.size(), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < g.size(); ++i) forces_out[i] = -g[i];
     }
@@ -768,7 +938,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
 
     // epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2))  (OpenMM LocalEnergyMinimizer)
     std::vector<float> hx((size_t)3 * h->n);
-    HIPCHK(h, hipMemcpy(hx.data(), h->x, sizeof(float) * hx.size(), hipMemcpyDeviceToHost));
+    if ((rc = mmx_get_positions(h, hx.data()))) return rc; // whole system (multi-GPU: every rank sees the same)
     double nrm = 0.0;
     for (float v : hx) nrm += (double)v * (double)v;
     nrm /= (double)h->n;
@@ -846,7 +1016,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    const int gb = grid_beads(h->n);
+    const int gb = grid_beads(h->n_own);
     const int saved_profile = h->profile;
     h->profile = 0;
     double bytes = 0.0;
@@ -925,6 +1095,7 @@ __global__ __launch_bounds__(256) static void k_census(int n, const float4 *__re
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float4 p = pos4[i];
         const int c = cell_of[i];
+        if (c < 0) continue; // not binned on this rank
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         for (int zz = max(cz - 1, 0); zz <= min(cz + 1, G.nz - 1); ++zz)
             for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.ny - 1); ++yy) {

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4
     __shared__ double s_w[4];
     const int n = P.n;
     double eb = 0.0, ea = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
+        const int i = P.own_lo + li; // neighbours i-2..i+2 may belong to other ranks: pos4 holds every bead
         const int f0 = flags[i];
         const int fm1 = i >= 1 ? flags[i - 1] : 0;
         const int fm2 = i >= 2 ? flags[i - 2] : 0;
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4
                 gz -= fi.z;
             }
         }
-        g[3 * i] += gx;
-        g[3 * i + 1] += gy;
-        g[3 * i + 2] += gz;
+        g[3 * li] += gx;
+        g[3 * li + 1] += gy;
+        g[3 * li + 2] += gz;
     }
     const double sb = block_sum<256>(eb, s_w);
     const double sa = block_sum<256>(ea, s_w);
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
         float gx = 0.f, gy = 0.f, gz = 0.f;
         for (int q = row_start[r]; q < row_start[r + 1]; ++q)
             e += 0.5 * (double)bond_grad(pb, f3(pos4[partner[q]]), r0[q], P.loop_k, gx, gy, gz);
-        g[3 * b] += gx;
-        g[3 * b + 1] += gy;
-        g[3 * b + 2] += gz;
+        g[3 * (b - P.own_lo)] += gx;
+        g[3 * (b - P.own_lo) + 1] += gy;
+        g[3 * (b - P.own_lo) + 2] += gz;
     }
     const double s = block_sum<256>(e, s_w);
     if (threadIdx.x == 0) part[P_LOOP * kPartStride + blockIdx.x] = s;
@@ -145,11 +146,10 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
                                                  const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ double s_w[4];
-    const int n = P.n;
     double ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
     const bool any = P.use_container | P.use_lamina | P.use_central;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float4 p = pos4[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P.n_own; i += gridDim.x * 256) { // i: local index
+        const float4 p = pos4[P.own_lo + i];
         float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
         if (any) {
             const float dx = p.x - P.cx, dy = p.y - P.cy, dz = p.z - P.cz;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
                 }
             }
             if (P.use_central) {
-                const float q = r - P.cf_R1, gw = P.cf_G * cf_w[i];
+                const float q = r - P.cf_R1, gw = P.cf_G * cf_w[P.own_lo + i];
                 ef += (double)(gw * q * q);
                 dEdr += 2.f * gw * q;
             }

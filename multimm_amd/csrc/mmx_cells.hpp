@@ -8,15 +8,15 @@ namespace mmx {
 // x = xp + step*d (MOVE) or x as given; builds pos4 = {x,y,z, bits((bead<<3)|(label+2))} and the bbox.
 // One thread per bead.  Algorithmic traffic: read 12(+24 when MOVE) B, write 16(+12) B per bead.
 template <bool MOVE>
-__global__ __launch_bounds__(256) void k_pack(int n, float *__restrict__ x, const float *__restrict__ xp,
-                                              const float *__restrict__ d, const int8_t *__restrict__ labels,
-                                              float4 *__restrict__ pos4, float *__restrict__ bbox_part,
-                                              const MinState *__restrict__ st) {
+__global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__restrict__ x,
+                                              const float *__restrict__ xp, const float *__restrict__ d,
+                                              const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
+                                              float *__restrict__ bbox_part, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ float s_bb[6][4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
     float px = 0.f, py = 0.f, pz = 0.f;
-    const bool act = i < n;
+    const bool act = i < n_own;
     if (act) {
         if (MOVE) {
             const double step = st->step;
@@ -31,8 +31,9 @@ __global__ __launch_bounds__(256) void k_pack(int n, float *__restrict__ x, cons
             py = x[3 * i + 1];
             pz = x[3 * i + 2];
         }
-        const int w = (i << 3) | ((int)labels[i] + 2);
-        pos4[i] = make_float4(px, py, pz, __int_as_float(w));
+        const int bead = own_lo + i;
+        const int w = (bead << 3) | ((int)labels[bead] + 2);
+        pos4[bead] = make_float4(px, py, pz, __int_as_float(w));
     }
     // Block bounding box -> bbox_part[k][block] (k = minx,miny,minz,maxx,maxy,maxz); no atomics.
     const float big = 3.0e38f;
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void k_pack(int n, float *__restrict__ x, cons
 // Reduces the per-block bounding boxes of k_pack (nblk blocks) into a grid; called by one block.
 template <int BLOCK>
 __device__ __forceinline__ GridParams grid_from_parts(const float *__restrict__ bbox_part, int nblk, float hmin,
-                                                       int maxcells, float *s_red /* [6][BLOCK/64] */) {
+                                                       int maxcells, float *s_red /* [6][BLOCK/64] */,
+                                                       float expand = 0.f) {
     const float big = 3.0e38f;
     float v[6] = {big, big, big, -big, -big, -big};
     for (int b = threadIdx.x; b < nblk; b += BLOCK) {
@@ -89,16 +91,18 @@ __device__ __forceinline__ GridParams grid_from_parts(const float *__restrict__ 
         for (int w = 1; w < BLOCK / 64; ++w)
             r[k] = k < 3 ? fminf(r[k], s_red[k * (BLOCK / 64) + w]) : fmaxf(r[k], s_red[k * (BLOCK / 64) + w]);
     }
-    return grid_from_box(r[0], r[1], r[2], r[3], r[4], r[5], hmin, maxcells);
+    return grid_from_box(r[0] - expand, r[1] - expand, r[2] - expand, r[3] + expand, r[4] + expand,
+                         r[5] + expand, hmin, maxcells);
 }
 
-// First build of a call: exact grid for the current positions.
+// Exact grid for the current positions of the owned beads, grown by `expand` on every side (multi-GPU:
+// expand = cutoff, so that every bead within the cutoff of an owned bead falls inside the grid).
 __global__ __launch_bounds__(256) void k_grid_init(const float *__restrict__ bbox_part, int nblk, float hmin,
-                                                   int maxcells, GridParams *__restrict__ grid,
+                                                   int maxcells, float expand, GridParams *__restrict__ grid,
                                                    const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ float s_red[6 * 4];
-    const GridParams G = grid_from_parts<256>(bbox_part, nblk, hmin, maxcells, s_red);
+    const GridParams G = grid_from_parts<256>(bbox_part, nblk, hmin, maxcells, s_red, expand);
     if (threadIdx.x == 0) *grid = G;
 }
 
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(256) void k_grid_init(const float *__restrict__ bbo
 // (a bead outside the box by more than one cell edge cannot be within the cutoff of an interior cell
 // two layers in).  Lanes of a wave that share a cell issue one atomicAdd (Hilbert-ordered beads: ~3
 // distinct cells per wave) and derive their slot in the cell from the returned base.
-__global__ __launch_bounds__(256) void k_cell_count(int n, const float4 *__restrict__ pos4,
+__global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n_own,
+                                                    const float4 *__restrict__ pos4,
                                                     const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                     int *__restrict__ rank, int *__restrict__ count,
                                                     const MinState *__restrict__ st) {
@@ -115,15 +120,23 @@ __global__ __launch_bounds__(256) void k_cell_count(int n, const float4 *__restr
     const GridParams G = *grid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool todo = i < n;
+    bool todo = i < n_all;
     int c = 0;
     if (todo) {
         const float4 p = pos4[i];
-        const int cx = cell_coord(p.x, G.ox, G.inv_h, G.nx);
-        const int cy = cell_coord(p.y, G.oy, G.inv_h, G.ny);
-        const int cz = cell_coord(p.z, G.oz, G.inv_h, G.nz);
-        c = (cz * G.ny + cy) * G.nx + cx;
-        cell_of[i] = c;
+        const bool owned = (unsigned)(i - own_lo) < (unsigned)n_own;
+        if (!owned) {
+            // ghost candidate (multi-GPU): kept only when strictly inside the (cutoff-expanded) grid
+            const float fx = (p.x - G.ox) * G.inv_h, fy = (p.y - G.oy) * G.inv_h, fz = (p.z - G.oz) * G.inv_h;
+            todo = fx >= 0.f && fx < (float)G.nx && fy >= 0.f && fy < (float)G.ny && fz >= 0.f && fz < (float)G.nz;
+        }
+        if (todo) {
+            const int cx = cell_coord(p.x, G.ox, G.inv_h, G.nx);
+            const int cy = cell_coord(p.y, G.oy, G.inv_h, G.ny);
+            const int cz = cell_coord(p.z, G.oz, G.inv_h, G.nz);
+            c = (cz * G.ny + cy) * G.nx + cx;
+        }
+        cell_of[i] = todo ? c : -1;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned long long pending = __ballot(todo);
@@ -214,13 +227,14 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bb
 }
 
 // Scatter bead ids into their cell's slice (arrival order; k_cell_order makes it canonical).
-__global__ __launch_bounds__(256) void k_cell_fill(int n, const int *__restrict__ cell_of,
+__global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restrict__ cell_of,
                                                    const int *__restrict__ rank, const int *__restrict__ start,
                                                    int *__restrict__ perm, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    perm[start[cell_of[i]] + rank[i]] = i;
+    if (i >= n_all) return;
+    const int c = cell_of[i];
+    if (c >= 0) perm[start[c] + rank[i]] = i;
 }
 
 // 12-bit Morton code of a position inside its cell (16 sub-cells per axis).
@@ -228,14 +242,16 @@ __device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 __device__ __forceinline__ unsigned long long order_key(const float4 p, const GridParams &G, int cx, int cy, int cz,
-                                                        int bead) {
+                                                        int bead, int own_lo, int n_own) {
     const float fx = ((p.x - G.ox) * G.inv_h - (float)cx) * 16.f;
     const float fy = ((p.y - G.oy) * G.inv_h - (float)cy) * 16.f;
     const float fz = ((p.z - G.oz) * G.inv_h - (float)cz) * 16.f;
     const unsigned qx = (unsigned)min(max((int)fx, 0), 15), qy = (unsigned)min(max((int)fy, 0), 15),
                    qz = (unsigned)min(max((int)fz, 0), 15);
     const unsigned m = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
-    return ((unsigned long long)m << 32) | (unsigned)bead;
+    // owned beads first (multi-GPU: clusters are then all-owned, one mixed, all-ghost), then Morton, then id
+    const unsigned long long ghost = (unsigned)(bead - own_lo) < (unsigned)n_own ? 0ull : 1ull;
+    return (ghost << 63) | ((unsigned long long)m << 32) | (unsigned)bead;
 }
 
 // Orders every cell's beads along a Morton curve of 16^3 sub-cells (ties by bead id: bitwise
@@ -249,11 +265,16 @@ constexpr int kOrderLds = 4096;
 __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, const int *__restrict__ perm,
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
-                                              int nthr) {
+                                              int nthr, int own_lo, int n_own) {
     const int ncl = (cnt + 7) >> 3;
     for (int e = tid; e < ncl * 8; e += nthr) {
         float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
-        if (e < cnt) p = pos4[perm[s + e]];
+        int nown = 0;
+        if (e < cnt) {
+            const int b = perm[s + e];
+            p = pos4[b];
+            nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
+        }
         spos4[(size_t)cb * 8 + e] = p;
         const float big = 3.0e38f;
         float lx = e < cnt ? p.x : big, ly = e < cnt ? p.y : big, lz = e < cnt ? p.z : big;
@@ -266,10 +287,11 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
             hx = fmaxf(hx, __shfl_xor(hx, o, 64));
             hy = fmaxf(hy, __shfl_xor(hy, o, 64));
             hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+            nown += __shfl_xor(nown, o, 64);
         }
-        if ((e & 7) == 0) {
+        if ((e & 7) == 0) { // lo.w = cell id, hi.w = (owned beads << 8) | beads of the cluster
             cl_lo[cb + (e >> 3)] = make_float4(lx, ly, lz, __int_as_float(c));
-            cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float(min(8, cnt - e)));
+            cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | min(8, cnt - e)));
         }
     }
 }
@@ -282,7 +304,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const int *__restrict__ cstart,
                                                     const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
-                                                    int deterministic, const MinState *__restrict__ st) {
+                                                    int own_lo, int n_own, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ unsigned long long s_buf[kOrderLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             unsigned long long v = kmax;
             if (lane < cnt) {
                 const int b = perm[s + lane];
-                v = order_key(pos4[b], G, cx, cy, cz, b);
+                v = order_key(pos4[b], G, cx, cy, cz, b, own_lo, n_own);
             }
 #pragma unroll
             for (int k = 2; k <= 64; k <<= 1) {
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
     }
 
     // ---- pass B: the whole block per large cell
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                 unsigned long long v = kmax;
                 if (q < cnt) {
                     const int b = perm[s + q];
-                    v = order_key(pos4[b], G, cx, cy, cz, b);
+                    v = order_key(pos4[b], G, cx, cy, cz, b, own_lo, n_own);
                 }
                 s_buf[q] = v;
             }
@@ -360,7 +382,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             __syncthreads();
         }
         // cells above kOrderLds beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
     }
 }
 

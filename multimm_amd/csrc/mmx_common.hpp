@@ -30,7 +30,9 @@ struct GridParams {
 
 // Force-field constants, passed by value as kernel arguments.
 struct FFParams {
-    int n;
+    int n;                 // beads of the whole system
+    int n_all;             // entries of pos4 (n padded to world * slice in a multi-GPU run)
+    int own_lo, n_own;     // this handle owns beads [own_lo, own_lo + n_own): forces / L-BFGS state are local
     int use_ev, ev_pmode; // pmode: 6 / 3 integer fast paths, 0 generic pow
     float ev_eps, ev_sigma, ev_rs, ev_power, ev_rc2; // rc2 = +inf when NoCutoff
     int use_gauss;
@@ -70,6 +72,8 @@ struct MinState {
     double ys[MMX_M];
     double gram[MMX_NBASIS * MMX_NBASIS];
     double coef[MMX_NBASIS];
+    double sums[16];                         // folded slot sums (all-reduced across ranks in a multi-GPU run)
+    double rowsum[MMX_NROWS * MMX_NBASIS + 1]; // folded Gram rows (same)
 };
 
 // ---- wave helpers ---------------------------------------------------------------------------

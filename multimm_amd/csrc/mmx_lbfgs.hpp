@@ -62,22 +62,10 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
     __syncthreads();
 }
 
-// After every evaluation: fold the block partials, then (thread 0) advance the line search exactly as
-// liblbfgs' line_search_backtracking with LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE does.
-__global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
-                                                     MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
-    __shared__ double s_task[kMaxTasks];
-    __shared__ double s_out[P_NSLOTS];
-    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
-    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
-    __syncthreads();
-    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    if (threadIdx.x != 0) return;
-    double sums[P_NSLOTS];
-#pragma unroll
-    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
-
+// Line-search controller, run by ONE thread after every evaluation on the folded (and, in a multi-GPU
+// run, all-reduced) slot sums: exactly liblbfgs' line_search_backtracking with
+// LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE.  Every rank executes it on identical inputs.
+__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums) {
     double f = 0.0;
     for (int t = 0; t < 8; ++t) {
         st->eterms[t] = sums[t];
@@ -166,6 +154,46 @@ __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const doub
     st->store_hist = 1;
 }
 
+
+// Single-GPU: fold the block partials and decide in one launch.
+__global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
+                                                     MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
+    __syncthreads();
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    if (threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+#pragma unroll
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
+    controller_decide(st, sums);
+}
+
+// Multi-GPU: fold -> st->sums (ncclAllReduce, fp64 sum, in place) -> decide.
+__global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const double *__restrict__ part,
+                                                       MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) {
+        if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0; // keep the collective's input finite
+        return;
+    }
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
+    __syncthreads();
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
+}
+__global__ void k_controller_decide(MinState *__restrict__ st) {
+    if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
+    controller_decide(st, sums);
+}
+
 // Accepted step: s = x - xp, y = g - gp into slot `end`, and the Gram rows of {s_new, y_new, g}
 // against the whole basis as block partials rows[(r*13 + b)*stride + blockIdx.x].
 // 2-D grid: blockIdx.y picks a group of <= 4 basis columns (12 fp64 accumulators per thread instead of
@@ -248,18 +276,9 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
     }
 }
 
-// Gram update + two-loop recursion in coefficient space (liblbfgs lbfgs() main-loop tail).
-__global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double *__restrict__ rows,
-                                                         MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || !st->accepted) return;
-    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
-    __shared__ double s_task[kMaxTasks];
-    __shared__ double s_rows[NQ];
-    __shared__ int s_n[NQ], s_first[NQ + 1];
-    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
-    __syncthreads();
-    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
-    if (threadIdx.x != 0) return;
+// Gram update + two-loop recursion in coefficient space (liblbfgs lbfgs() main-loop tail), run by ONE
+// thread on the folded (multi-GPU: all-reduced) Gram rows.
+__device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const double *s_rows) {
     constexpr int NB = MMX_NBASIS, M = MMX_M, IG = 2 * MMX_M;
     double *G = st->gram;
     const bool store = st->store_hist != 0;
@@ -318,6 +337,42 @@ __global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double 
         st->status = -2;
         st->phase = PH_DONE;
     }
+}
+
+
+__global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double *__restrict__ rows,
+                                                         MinState *__restrict__ st) {
+    if (st->phase == PH_DONE || !st->accepted) return;
+    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_rows[NQ];
+    __shared__ int s_n[NQ], s_first[NQ + 1];
+    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
+    __syncthreads();
+    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
+    if (threadIdx.x != 0) return;
+    coef_decide(st, s_rows);
+}
+
+// Multi-GPU: fold -> st->rowsum (ncclAllReduce) -> decide.
+__global__ __launch_bounds__(1024) void k_reduce_rows(int nblk, const double *__restrict__ rows,
+                                                      MinState *__restrict__ st) {
+    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
+    if (st->phase == PH_DONE || !st->accepted) {
+        if (threadIdx.x <= NQ) st->rowsum[threadIdx.x] = 0.0;
+        return;
+    }
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_rows[NQ];
+    __shared__ int s_n[NQ], s_first[NQ + 1];
+    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
+    __syncthreads();
+    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
+    if (threadIdx.x < NQ) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+}
+__global__ void k_direction_coef_decide(MinState *__restrict__ st) {
+    if (st->phase == PH_DONE || !st->accepted || threadIdx.x != 0) return;
+    coef_decide(st, st->rowsum);
 }
 
 // d = sum_a coef[a] * B_a.  Streams 13 vectors in, one out.

@@ -221,11 +221,15 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
         const int c = __float_as_int(lo_i.w);
+        if ((__float_as_int(hi_i.w) >> 8) == 0) continue; // no owned bead in this cluster (multi-GPU ghosts)
         // i-cluster -> scalar registers
         float4 pv = spos4[(size_t)icl * kCl + slot];
-        // padding slots sit at +1e18 in spos4 (they are also j entries of this very cluster): as i beads
-        // move them elsewhere so that pad-pad pairs are outside the cutoff as well
-        if (__float_as_int(pv.w) < 0) pv.x = pv.y = pv.z = 3e18f;
+        // padding slots sit at +1e18 in spos4 (they are also j entries of this very cluster) and ghost beads
+        // of a mixed cluster get no force here: as i beads move both far away so that they meet no pair
+        if ((unsigned)((__float_as_int(pv.w) >> 3) - P.own_lo) >= (unsigned)P.n_own) {
+            pv.x = pv.y = pv.z = 3e18f;
+            pv.w = __int_as_float(-8 + (__float_as_int(pv.w) & 7));
+        }
         float xi[kCl], yi[kCl], zi[kCl];
         int wi[kCl];
 #pragma unroll
@@ -394,9 +398,9 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                 }
             }
             if (GAUSS) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
-            g[3 * bead] = -ofx;
-            g[3 * bead + 1] = -ofy;
-            g[3 * bead + 2] = -ofz;
+            g[3 * (bead - P.own_lo)] = -ofx;
+            g[3 * (bead - P.own_lo) + 1] = -ofy;
+            g[3 * (bead - P.own_lo) + 2] = -ofz;
         }
         const float sev = wave_sum(tev), seg = wave_sum(teg);
         acc_ev += 0.5 * (double)sev;

@@ -59,6 +59,11 @@ _P = C.c_void_p
 SIGNATURES = {
     "mmx_abi_version": (C.c_int, []),
     "mmx_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "mmx_create_dd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "mmx_dd_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int32)]),
+    "mmx_comm_unique_id": (C.c_int, [_P]),
+    "mmx_comm_init": (C.c_int, [_P, _P]),
     "mmx_destroy": (C.c_int, [_P]),
     "mmx_last_error": (C.c_char_p, [_P]),
     "mmx_set_positions": (C.c_int, [_P, _P]),
@@ -111,14 +116,36 @@ def _f32(a) -> np.ndarray:
 class Engine:
     """One minimizer context on one MI355X."""
 
-    def __init__(self, n_beads: int, device: int = 0):
+    def __init__(self, n_beads: int, device: int = 0, rank: int = 0, world: int = 1):
+        """``world > 1``: domain-decomposed run, this handle owns slice ``rank`` of the beads (mmx.h)."""
         self._lib = load_library()
         self._h = _P()
         self.n = int(n_beads)
-        rc = self._lib.mmx_create(self.n, int(device), C.byref(self._h))
+        self.rank, self.world = int(rank), int(world)
+        if world > 1:
+            rc = self._lib.mmx_create_dd(self.n, self.rank, self.world, int(device), C.byref(self._h))
+        else:
+            rc = self._lib.mmx_create(self.n, int(device), C.byref(self._h))
         if rc != 0:
             msg = self._lib.mmx_last_error(None)
             raise MMXError(rc, msg.decode() if msg else "mmx_create failed")
+        lo, no = C.c_int32(), C.c_int32()
+        self._lib.mmx_dd_info(self._h, C.byref(lo), C.byref(no), None, None)
+        self.own_lo, self.n_own = lo.value, no.value
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.mmx_comm_unique_id(C.cast(buf, _P))
+        if rc != 0:
+            raise MMXError(rc, (lib.mmx_last_error(None) or b"?").decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes):
+        """Collective over all ranks: RCCL communicator on this handle's device."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(self._lib.mmx_comm_init(self._h, C.cast(buf, _P)))
 
     # -- plumbing ------------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -218,7 +245,7 @@ class Engine:
     def compute(self, forces: bool = True):
         """Returns (energy_terms[8] float64, forces [N,3] float32 or None) at the current positions."""
         et = np.zeros(N_TERMS, dtype=np.float64)
-        f = np.empty((self.n, 3), dtype=np.float32) if forces else None
+        f = np.empty((self.n_own, 3), dtype=np.float32) if forces else None
         self._chk(self._lib.mmx_compute(self._h, f.ctypes.data if forces else None, et.ctypes.data))
         return et, f
 
@@ -281,5 +308,5 @@ class Engine:
         return self
 
 
-def engine_for(system: ChromatinSystem, device: int = 0) -> Engine:
-    return Engine(system.n_beads, device).load_system(system)
+def engine_for(system: ChromatinSystem, device: int = 0, rank: int = 0, world: int = 1) -> Engine:
+    return Engine(system.n_beads, device, rank, world).load_system(system)
