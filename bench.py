@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg; 0 disables")
     ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
+                    help="N > 1: 'ensemble' = one replica per GPU (config 4, weak scaling, no collective); "
+                         "'dd' = ONE system decomposed over the GPUs (config 5, strong scaling, RCCL)")
     ap.add_argument("--nb-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the pair kernel from a separate rocprofv3 --pmc run "
                          "(profiles/): copied into roofline.traffic")
@@ -81,18 +84,34 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # MMX_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the launch path on a 1-GPU box)
+    backend = os.environ.get("MMX_DIST_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    local_rank = local_rank % ndev
+    tdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
 
     from multimm_amd import synthetic_system
     from multimm_amd.engine import K_NONBONDED, K_CELL_BUILD, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE, engine_for
 
-    system = synthetic_system(args.workload, seed=rank, n_beads=args.n_beads or None, jitter=args.jitter,
-                              NB_CUTOFF=args.cutoff)
-    eng = engine_for(system, device=local_rank)
+    dd = world > 1 and args.mode == "dd"
+    system = synthetic_system(args.workload, seed=0 if dd else rank, n_beads=args.n_beads or None,
+                              jitter=args.jitter, NB_CUTOFF=args.cutoff)
+    if dd:
+        from multimm_amd.engine import Engine
+        from multimm_amd.parallel import broadcast_bytes
+        eng = engine_for(system, device=local_rank, rank=rank, world=world)
+        uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128, device=tdev)
+        eng.comm_init(uid)
+    else:
+        eng = engine_for(system, device=local_rank)
     eng.set_option("profile", 0)
 
     def barrier():
@@ -113,12 +132,8 @@ def main():
 
     iters = st.iterations
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        it = torch.tensor([iters], dtype=torch.float64, device="cuda")
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        total_iters = float(it.item())
+        from multimm_amd.parallel import reduce_job_stats
+        dt, total_iters = reduce_job_stats(dt, iters, args.mode, device=tdev)
     else:
         total_iters = float(iters)
 
@@ -158,7 +173,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if dd else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -166,10 +181,13 @@ def main():
                 "workload": f"{system.name}: {n} beads, Hilbert-curve start, "
                             f"{'GW preset (EV+COB+container+lamina+bonds+angles+loops)' if 'gw' in args.workload else 'EV+bonds+angles+loops'}, "
                             f"{system.n_loops} loops, pair cutoff {args.cutoff} nm"
-                            + ("; one independent replica per GPU (seeds 0..N-1), no collective" if world > 1 else ""),
-                "n_beads": n, "cutoff_nm": args.cutoff, "replicas": world,
+                            + ("; ONE system, bead slices owned by the GPUs, pos4 all-gather + fp64 all-reduce on RCCL"
+                               if dd else "; one independent replica per GPU (seeds 0..N-1), no collective"
+                               if world > 1 else ""),
+                "n_beads": n, "cutoff_nm": args.cutoff, "replicas": 1 if dd else world, "mode": args.mode if world > 1 else "single",
             },
-            "iterations": iters, "evaluations": st.evaluations, "evals_per_s": st.evaluations * world / dt,
+            "iterations": iters, "evaluations": st.evaluations,
+            "evals_per_s": st.evaluations * (1 if dd else world) / dt,
             "status": st.status, "e_initial": st.e_initial, "e_final": st.e_final, "rms_force": st.rms_force,
             "kernel_us_mean": kern,
             "kernel_algorithmic_GBps": kernel_gbs,
