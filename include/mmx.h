@@ -181,9 +181,10 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
                   double *pairs_within_cutoff);
 
 /* Diagnostics of the cluster-pair kernel at the current positions: number of 8-bead clusters, number of
- * (i-cluster, j-cluster) tiles in the 27-cell stencils and number of tiles surviving the box-box cull
- * (each surviving tile = 64 pair lanes). */
-int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted);
+ * (i-cluster, j-cluster) tiles in the 27-cell stencils, number of tiles surviving the box-box cull and
+ * number of j beads surviving the per-bead cull (each is swept against the 8 beads of its i-cluster). */
+int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted,
+                       double *beads_swept);
 
 #ifdef __cplusplus
 }

@@ -234,9 +234,10 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
             /* default: cutoff by v_fma clamp + one energy accumulator pair per lane + per-bead cull;       \
                nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
             const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) |               \
-                            ((h->nb_variant & 128) ? 0 : 8);                                                \
+                            ((h->nb_variant & 128) ? 0 : 8) | ((h->nb_variant & 256) ? 16 : 0);             \
             switch (opt) {                                                                                  \
             case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
+            case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
             case 6: NBJ(PMODE, EV, GA, true, 6); break;                                                     \
             case 12: NBJ(PMODE, EV, GA, true, 12); break;                                                   \
             case 10: NBJ(PMODE, EV, GA, true, 10); break;                                                   \
@@ -1121,11 +1122,12 @@ __global__ __launch_bounds__(256) static void k_census(int n, const float4 *__re
 __global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float4 *__restrict__ cl_lo,
                                                             const float4 *__restrict__ cl_hi,
                                                             const int *__restrict__ cstart,
+                                                            const float4 *__restrict__ spos4,
                                                             const GridParams *__restrict__ grid, float rc2,
-                                                            double *__restrict__ out /* [2] */) {
+                                                            double *__restrict__ out /* [3] */) {
     const GridParams G = *grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double cand = 0.0, acc = 0.0;
+    double cand = 0.0, acc = 0.0, beads = 0.0;
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
         const int c = __float_as_int(lo_i.w);
@@ -1141,19 +1143,32 @@ __global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float
                     const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
                     const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
                     cand += 1.0;
-                    if (dx * dx + dy * dy + dz * dz < rc2) acc += 1.0;
+                    if (dx * dx + dy * dy + dz * dz < rc2) {
+                        acc += 1.0;
+                        // second-level cull: beads of the accepted j-cluster within the cutoff of the i box
+                        for (int k = 0; k < 8; ++k) {
+                            const float4 q = spos4[(size_t)jc * 8 + k];
+                            const float bx = fmaxf(fmaxf(lo_i.x - q.x, q.x - hi_i.x), 0.f);
+                            const float by = fmaxf(fmaxf(lo_i.y - q.y, q.y - hi_i.y), 0.f);
+                            const float bz = fmaxf(fmaxf(lo_i.z - q.z, q.z - hi_i.z), 0.f);
+                            if (bx * bx + by * by + bz * bz < rc2) beads += 1.0;
+                        }
+                    }
                 }
             }
     }
     cand = wave_sum(cand);
     acc = wave_sum(acc);
+    beads = wave_sum(beads);
     if (lane == 0) {
         atomicAdd(&out[0], cand);
         atomicAdd(&out[1], acc);
+        atomicAdd(&out[2], beads);
     }
 }
 
-int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted) {
+int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted,
+                       double *beads_swept) {
     if (!h) return MMX_ERR_BAD_ARG;
     int rc = prepare(h);
     if (rc) return rc;
@@ -1163,17 +1178,18 @@ int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidat
     if ((rc = push_state(h))) return rc;
     if ((rc = prime_items(h))) return rc;
     double *dout = nullptr;
-    HIPCHK(h, dalloc(&dout, 2));
+    HIPCHK(h, dalloc(&dout, 3));
     const int ncl = h->st_host->n_clusters;
     hipLaunchKernelGGL(k_tile_census, dim3(1024), dim3(256), 0, h->stream, ncl, h->cl_lo, h->cl_hi, h->cstart,
-                       h->gcur, h->P.rc2max, dout);
-    double res[2] = {0, 0};
+                       h->spos4, h->gcur, h->P.rc2max, dout);
+    double res[3] = {0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(dout);
     if (n_clusters) *n_clusters = ncl;
     if (tiles_candidate) *tiles_candidate = res[0];
     if (tiles_accepted) *tiles_accepted = res[1];
+    if (beads_swept) *beads_swept = res[2];
     return MMX_OK;
 }
 

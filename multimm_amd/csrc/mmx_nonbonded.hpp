@@ -182,7 +182,7 @@ constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
 template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT>
-__global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+__global__ __launch_bounds__(256, 6) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
                                                        const int *__restrict__ cstart,
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
     constexpr bool SATMASK = (OPT & 2) != 0; // cutoff by v_fma clamp instead of v_cmp + v_cndmask
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
     constexpr bool BEADCULL = (OPT & 8) != 0; // per-bead second-level cull + LDS ring compaction
+    constexpr bool NOSWEEP = (OPT & 16) != 0; // diagnosis only: skip the pair arithmetic (times culls + fold)
     __shared__ int s_list[4][kListCap + 72];
     __shared__ float4 s_ring[4][BEADCULL ? 128 : 1];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
@@ -319,6 +320,10 @@ __global__ __launch_bounds__(256) void k_nb_clusters_j(const FFParams P, const f
                     const int took = min(rcount, 64);
                     rhead = (rhead + took) & 127;
                     rcount -= took;
+                }
+                if (NOSWEEP) {
+                    fx[0] += q.x;
+                    continue;
                 }
                 const int lj = __float_as_int(q.w) & 7;
                 // rank-2 amplitude (compartment blocks only): A(s_i,s_j) = aA_i*alpha_j + aB_i*beta_j

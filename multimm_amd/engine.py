@@ -86,7 +86,8 @@ SIGNATURES = {
     "mmx_time_kernel": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mmx_nb_census": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "mmx_cluster_census": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mmx_cluster_census": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
 }
 
 
@@ -269,9 +270,10 @@ class Engine:
 
     def cluster_census(self) -> dict:
         nc = C.c_int64()
-        cand, acc = C.c_double(), C.c_double()
-        self._chk(self._lib.mmx_cluster_census(self._h, C.byref(nc), C.byref(cand), C.byref(acc)))
-        return dict(n_clusters=nc.value, tiles_candidate=cand.value, tiles_accepted=acc.value)
+        cand, acc, beads = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self._lib.mmx_cluster_census(self._h, C.byref(nc), C.byref(cand), C.byref(acc), C.byref(beads)))
+        return dict(n_clusters=nc.value, tiles_candidate=cand.value, tiles_accepted=acc.value,
+                    beads_swept=beads.value)
 
     # -- convenience: upload a whole ChromatinSystem the way add_forcefield orders it ---------------
     def load_system(self, s: ChromatinSystem):

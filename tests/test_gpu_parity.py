@@ -183,3 +183,46 @@ def test_rccl_path_single_rank():
     assert st1.iterations == st0.iterations == 30 and st1.evaluations == st0.evaluations
     assert st1.e_final == st0.e_final
     assert np.array_equal(x0, x1)
+
+
+def test_full_size_properties_200k():
+    """BASELINE-size checks that do not need the O(minutes) oracle: two independent pair kernels agree,
+    internal forces sum to zero (Newton's third law), energy is translation invariant, the minimizer
+    decreases the energy monotonically in accepted iterations."""
+    s = synthetic_system("gw_200k", jitter=0.02, seed=1)
+    internal = s.with_ff(SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
+    with engine_for(internal) as eng:
+        et0, F0 = eng.compute()
+        eng.set_option("nb_variant", 1)          # v1 cell kernel: different code, same physics
+        et1, F1 = eng.compute()
+        eng.set_option("nb_variant", 0)
+        fmax = np.abs(F0).max()
+        assert np.abs(F0 - F1).max() <= 2e-4 * fmax + 5e-2
+        assert np.all(np.abs(et0 - et1) <= 2e-5 * np.abs(et0).sum() + 1e-3)
+        # sum of internal forces vanishes; fp32 accumulation noise ~ sqrt(N) * eps * |F|
+        assert np.abs(F0.astype(np.float64).sum(0)).max() <= 1e-3 * fmax
+        shifted = internal.positions + np.array([3.0, -2.0, 1.0])
+        eng.set_positions(shifted)
+        et2, F2 = eng.compute()
+        assert np.all(np.abs(et2 - et0) <= 5e-5 * np.abs(et0).sum() + 1e-2)
+    with engine_for(s) as eng:
+        e_prev = None
+        for _ in range(4):
+            st = eng.minimize(tolerance=0.0, max_iters=25)
+            assert st.iterations == 25 and np.isfinite(st.e_final)
+            assert st.e_final < st.e_initial
+            if e_prev is not None:
+                assert st.e_initial == pytest.approx(e_prev, rel=1e-6)   # restart resumes from the same point
+            e_prev = st.e_final
+
+
+def test_one_million_beads_runs():
+    """BASELINE config 5 size on one GPU: allocation, cell build and kernels at N = 1e6."""
+    s = synthetic_system("gw_1m")
+    with engine_for(s) as eng:
+        et, F = eng.compute()
+        assert np.all(np.isfinite(et)) and np.all(np.isfinite(F))
+        # Hilbert lattice: every bond is exactly r0, so the bond energy is ~0 (fp32 lattice round-off)
+        assert abs(et[2]) < 1e-2 * s.n_beads * 1e-3
+        st = eng.minimize(tolerance=0.0, max_iters=10)
+        assert st.iterations == 10 and st.e_final < st.e_initial
