@@ -149,9 +149,17 @@ def main():
         roofline = None
         if nb_us:
             achieved = NB_BYTES_PER_BEAD * n / (nb_us * 1e-6) / 1e9
+            traffic = args.nb_traffic_bytes
+            if traffic is None and args.cutoff > 0 and n == 200000:
+                # per-launch HBM bytes of the same kernel on the same workload from the committed
+                # rocprofv3 --pmc passes (PMC collection cannot share a run with the timed region)
+                try:
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))["bytes_per_launch"]
+                except Exception:
+                    traffic = None
             roofline = {"bound": "hbm", "kernel": "k_nb_clusters_j" if args.cutoff > 0 else "k_nb_allpairs",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": args.nb_traffic_bytes, "launch_us": nb_us,
+                        "traffic": traffic, "launch_us": nb_us,
                         "samples": int(st.kernel_samples[K_NONBONDED])}
             if census:
                 pairs = census["pairs_within_cutoff"]  # directed pairs (each pair visited from both ends)

@@ -182,7 +182,7 @@ constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
 template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT>
-__global__ __launch_bounds__(256, 6) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+__global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
                                                        const int *__restrict__ cstart,
