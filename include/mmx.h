@@ -43,7 +43,8 @@ enum {
     MMX_T_CONTAINER = 5, /* add_spherical_container   model.py:453-466 */
     MMX_T_LAMINA = 6,    /* add_Blamina_interaction   model.py:468-507 */
     MMX_T_CENTRAL = 7,   /* add_central_force         model.py:552-623 */
-    MMX_N_TERMS = 8
+    MMX_T_CHB = 8,       /* add_chromosomal_blocks    model.py:386-451 */
+    MMX_N_TERMS = 9
 };
 
 /* Kernel slots of mmx_stats.kernel_* and mmx_time_kernel(). */
@@ -55,6 +56,7 @@ enum {
     MMX_K_CONFINE = 4,    /* K5: container + lamina + central */
     MMX_K_LBFGS = 5,      /* K6: all L-BFGS vector kernels of one accepted iteration */
     MMX_K_REDUCE = 6,     /* energy/dot reductions + line-search controller */
+    MMX_K_CHB = 7,        /* chromosomal blocks: all pairs inside each chromosome */
     MMX_N_KERNELS = 8
 };
 
@@ -143,6 +145,11 @@ int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float cen
 int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]);
 /* CustomExternalForce "G*chrom_s*(r-R1)^2", model.py:579-586; w is [N] chrom_strength. */
 int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w);
+/* CustomNonbondedForce "E*(k_C*r^4 - r^3 + r^2); E = dE*delta(chrom1-chrom2)", model.py:397-419
+ * (polynomial form).  chrom is [N] chrom_spin: two beads interact iff their values are equal; beads of
+ * one chromosome must be contiguous (they are: model.py:158-162 assigns by chr_ends ranges).  The
+ * potential grows with r, so there is no cutoff: every pair inside a chromosome is evaluated. */
+int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom);
 /* Removes a term again (term = MMX_T_*). */
 int mmx_disable_term(mmx_handle h, int32_t term);
 

@@ -136,6 +136,4 @@ def load_config(path_or_dict) -> SimulationConfig:
                 setattr(cfg, key, sval if sval is None else str(sval))
     cfg.ff = dataclasses.replace(cfg.ff, **ffkw)
     cfg.apply_modelling_level()
-    if cfg.ff.CHB_USE_CHROMOSOMAL_BLOCKS:
-        raise NotImplementedError("CHB_USE_CHROMOSOMAL_BLOCKS is not on the MI355X path yet (SURVEY.md section 8 f1)")
     return cfg

@@ -88,6 +88,7 @@ struct mmx_handle_s {
     int8_t *labels = nullptr;
     uint8_t *flags = nullptr;
     float *cf_w = nullptr;
+    int *chrom_of = nullptr, *chrom_lo = nullptr, *chrom_hi = nullptr; // chromosomal blocks: id per bead, range per id
     // cells
     int *cell_of = nullptr, *count = nullptr, *rank_in_cell = nullptr, *start = nullptr, *istart = nullptr,
         *perm = nullptr;
@@ -373,6 +374,14 @@ void enqueue_eval(mmx_handle_s *h, bool move) {
         prof_end(h, on, ep);
         A.nblk[P_LOOP] = gl;
     }
+    if (h->P.use_chb && h->chrom_of) {
+        const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
+        on = prof_begin(h, MMX_K_CHB, ep);
+        hipLaunchKernelGGL(k_chb, dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,
+                           h->chrom_hi, h->g, h->part, h->st);
+        prof_end(h, on, ep);
+        A.nblk[P_CHB] = std::min(gc, kPartStride);
+    }
     on = prof_begin(h, MMX_K_CONFINE, ep);
     hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
                        h->part, h->st);
@@ -620,7 +629,8 @@ int mmx_destroy(mmx_handle h) {
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
                     h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
-                    h->row_start, h->partner, h->loop_r0, h->fpart, h->epart, h->cstart, h->spos4, h->cl_lo, h->cl_hi};
+                    h->row_start, h->partner, h->loop_r0, h->fpart, h->epart, h->cstart, h->spos4, h->cl_lo, h->cl_hi,
+                    h->chrom_of, h->chrom_lo, h->chrom_hi};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -866,6 +876,41 @@ int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], cons
     return MMX_OK;
 }
 
+int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom) {
+    if (!h || !chrom) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    if ((h->n + 255) / 256 > kPartStride) return fail(h, MMX_ERR_BAD_ARG, "too many beads for the chromosomal-block kernel");
+    HIPCHK(h, hipSetDevice(h->device));
+    // chromosome ids must form contiguous runs; remap them to 0..K-1 in order of appearance
+    std::vector<int> id((size_t)h->n), lo, hi;
+    int k = -1;
+    std::vector<int> seen;
+    for (int i = 0; i < h->n; ++i) {
+        if (i == 0 || chrom[i] != chrom[i - 1]) {
+            for (int v : seen)
+                if (v == chrom[i]) return fail(h, MMX_ERR_BAD_ARG, "beads of one chromosome must be contiguous");
+            seen.push_back(chrom[i]);
+            ++k;
+            lo.push_back(i);
+            hi.push_back(i);
+        }
+        id[i] = k;
+        hi[k] = i + 1;
+    }
+    for (void *p : {(void *)h->chrom_of, (void *)h->chrom_lo, (void *)h->chrom_hi})
+        if (p) (void)hipFree(p);
+    h->chrom_of = h->chrom_lo = h->chrom_hi = nullptr;
+    HIPCHK(h, dalloc(&h->chrom_of, (size_t)h->n));
+    HIPCHK(h, dalloc(&h->chrom_lo, lo.size()));
+    HIPCHK(h, dalloc(&h->chrom_hi, hi.size()));
+    HIPCHK(h, hipMemcpy(h->chrom_of, id.data(), sizeof(int) * id.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->chrom_lo, lo.data(), sizeof(int) * lo.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->chrom_hi, hi.data(), sizeof(int) * hi.size(), hipMemcpyHostToDevice));
+    h->P.use_chb = 1;
+    h->P.chb_kc = k_C;
+    h->P.chb_de = dE;
+    return MMX_OK;
+}
+
 int mmx_disable_term(mmx_handle h, int32_t term) {
     if (!h) return MMX_ERR_BAD_ARG;
     switch (term) {
@@ -877,6 +922,7 @@ int mmx_disable_term(mmx_handle h, int32_t term) {
     case MMX_T_CONTAINER: h->P.use_container = 0; break;
     case MMX_T_LAMINA: h->P.use_lamina = 0; break;
     case MMX_T_CENTRAL: h->P.use_central = 0; break;
+    case MMX_T_CHB: h->P.use_chb = 0; break;
     default: return fail(h, MMX_ERR_BAD_ARG, "unknown term");
     }
     return MMX_OK;

@@ -213,4 +213,57 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
     }
 }
 
+// K7.  Chromosomal blocks (model.py:416-419): E = dE*(k_C r^4 - r^3 + r^2) for every pair of beads of the
+// same chromosome, no cutoff (the potential grows with r).  Beads of a chromosome are contiguous, so this is
+// a block-diagonal all-pairs sweep: a block owns 256 consecutive beads and walks the bead range spanned by the
+// chromosomes of its first and last bead in LDS tiles; pairs of different chromosomes inside that range are
+// masked.  F_i = -dE*(4 k_C r^2 - 3 r + 2)*d, one v_sqrt per pair.  Each thread adds to its own bead: no atomics.
+__global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__restrict__ pos4,
+                                             const int *__restrict__ chrom_of, const int *__restrict__ chrom_lo,
+                                             const int *__restrict__ chrom_hi, float *__restrict__ g,
+                                             double *__restrict__ part, const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float4 s_tile[256];
+    __shared__ int s_chr[256];
+    __shared__ double s_w[4];
+    const int li = blockIdx.x * 256 + threadIdx.x; // local index of an owned bead
+    const bool act = li < P.n_own;
+    const int i = P.own_lo + min(li, P.n_own - 1);
+    const float4 pi = pos4[i];
+    const int ci = chrom_of[i];
+    // bead range covered by the chromosomes of this block's beads (block-uniform)
+    const int ifirst = P.own_lo + blockIdx.x * 256, ilast = P.own_lo + min(blockIdx.x * 256 + 255, P.n_own - 1);
+    const int jlo = chrom_lo[chrom_of[ifirst]], jhi = chrom_hi[chrom_of[ilast]];
+    float fx = 0.f, fy = 0.f, fz = 0.f, e = 0.f;
+    const float k4 = 4.f * P.chb_kc;
+    for (int jb = jlo; jb < jhi; jb += 256) {
+        const int j = jb + threadIdx.x;
+        __syncthreads();
+        s_tile[threadIdx.x] = j < jhi ? pos4[j] : pi;
+        s_chr[threadIdx.x] = j < jhi ? chrom_of[j] : -1;
+        __syncthreads();
+        const int cnt = min(256, jhi - jb);
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {
+            const float4 q = s_tile[t];
+            const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
+            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            const float r = __builtin_amdgcn_sqrtf(r2);
+            const float m = (s_chr[t] == ci) ? P.chb_de : 0.f; // the self pair has r = 0: contributes nothing
+            e = fmaf(m * r2, fmaf(P.chb_kc, r2, 1.f - r), e);
+            const float fs = -m * (fmaf(k4, r2, 2.f) - 3.f * r);
+            fx = fmaf(fs, dx, fx);
+            fy = fmaf(fs, dy, fy);
+            fz = fmaf(fs, dz, fz);
+        }
+    }
+    if (act) {
+        g[3 * li] -= fx;
+        g[3 * li + 1] -= fy;
+        g[3 * li + 2] -= fz;
+    }
+    const double se = block_sum<256>(act ? 0.5 * (double)e : 0.0, s_w);
+    if (threadIdx.x == 0) part[P_CHB * kPartStride + blockIdx.x] = se;
+}
+
 } // namespace mmx

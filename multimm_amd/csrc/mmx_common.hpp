@@ -14,8 +14,8 @@ constexpr int kWave = 64;
 
 // Partial-sum slots (double, one value per block) written by the force kernels.
 enum PartSlot {
-    P_EV = 0, P_GAUSS, P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT, // == MMX_T_* order
-    P_GD, P_GG, P_XX,                                                 // g.d, g.g, x.x
+    P_EV = 0, P_GAUSS, P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT, P_CHB, // == MMX_T_* order
+    P_GD, P_GG, P_XX,                                                        // g.d, g.g, x.x
     P_NSLOTS
 };
 
@@ -49,6 +49,8 @@ struct FFParams {
     float ibl_B, ibl_R1, ibl_R2;
     float cf_G, cf_R1;
     float cx, cy, cz;
+    int use_chb;
+    float chb_kc, chb_de;
 };
 
 // Device-resident minimizer state; mirrored to pinned host memory when polled.
@@ -67,8 +69,8 @@ struct MinState {
     double finit, dginit, step, epsilon;
     double gnorm, xnorm;
     double cell_edge;
-    double eterms[8];       // per-term energies of the last evaluation
-    double eterms_acc[8];   // ... at the last accepted point
+    double eterms[9];       // per-term energies of the last evaluation
+    double eterms_acc[9];   // ... at the last accepted point
     double ys[MMX_M];
     double gram[MMX_NBASIS * MMX_NBASIS];
     double coef[MMX_NBASIS];

@@ -67,7 +67,7 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
 // LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE.  Every rank executes it on identical inputs.
 __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums) {
     double f = 0.0;
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 9; ++t) {
         st->eterms[t] = sums[t];
         f += sums[t];
     }
@@ -90,7 +90,7 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
             return;
         }
         st->fx = f;
-        for (int t = 0; t < 8; ++t) st->eterms_acc[t] = sums[t];
+        for (int t = 0; t < 9; ++t) st->eterms_acc[t] = sums[t];
         double xn = sqrt(xx);
         if (xn < 1.0) xn = 1.0;
         st->xnorm = xn;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     // accepted: one L-BFGS iteration finished
     st->iters += 1;
     st->fx = f;
-    for (int t = 0; t < 8; ++t) st->eterms_acc[t] = sums[t];
+    for (int t = 0; t < 9; ++t) st->eterms_acc[t] = sums[t];
     double xn = sqrt(xx);
     if (xn < 1.0) xn = 1.0;
     st->xnorm = xn;

@@ -15,10 +15,10 @@ import numpy as np
 
 from .system import ChromatinSystem
 
-N_TERMS = 8
+N_TERMS = 9
 N_KERNELS = 8
-TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")
-KERNEL_NAMES = ("cell_build", "nonbonded", "backbone", "loops", "confine", "lbfgs", "reduce", "_")
+TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central", "chb")
+KERNEL_NAMES = ("cell_build", "nonbonded", "backbone", "loops", "confine", "lbfgs", "reduce", "chb")
 K_CELL_BUILD, K_NONBONDED, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE = range(7)
 COMP_COB, COMP_SCB = 0, 1
 
@@ -47,8 +47,8 @@ class MMXStats(C.Structure):
         d["energy_terms"] = {TERM_NAMES[i]: self.energy_terms[i] for i in range(N_TERMS)}
         d["kernel_us_mean"] = {
             KERNEL_NAMES[i]: (self.kernel_ns[i] / self.kernel_samples[i] / 1e3 if self.kernel_samples[i] else None)
-            for i in range(N_KERNELS - 1)}
-        d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(N_KERNELS - 1)}
+            for i in range(N_KERNELS)}
+        d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(N_KERNELS)}
         return d
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "mmx_set_container": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
     "mmx_set_lamina": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
     "mmx_set_central": (C.c_int, [_P, C.c_float, C.c_float, _P, _P]),
+    "mmx_set_chromosomal_blocks": (C.c_int, [_P, C.c_float, C.c_float, _P]),
     "mmx_disable_term": (C.c_int, [_P, C.c_int32]),
     "mmx_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "mmx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
@@ -231,6 +232,12 @@ class Engine:
             raise ValueError("w must be [N]")
         self._chk(self._lib.mmx_set_central(self._h, G, R1, c.ctypes.data, ww.ctypes.data))
 
+    def set_chromosomal_blocks(self, k_C, dE, chrom):
+        c = np.ascontiguousarray(chrom, dtype=np.int32)
+        if c.shape != (self.n,):
+            raise ValueError("chrom must be [N]")
+        self._chk(self._lib.mmx_set_chromosomal_blocks(self._h, k_C, dE, c.ctypes.data))
+
     def disable_term(self, term: int):
         self._chk(self._lib.mmx_disable_term(self._h, term))
 
@@ -292,7 +299,7 @@ class Engine:
         if ff.SCB_USE_SUBCOMPARTMENT_BLOCKS:
             self.set_compartments(COMP_SCB, [ff.SCB_EA1, ff.SCB_EA2, ff.SCB_EB1, ff.SCB_EB2], r_comp, ff.NB_CUTOFF)
         if ff.CHB_USE_CHROMOSOMAL_BLOCKS:
-            raise NotImplementedError("CHB chromosomal blocks are not on the MI355X path yet (SURVEY.md 8 f1)")
+            self.set_chromosomal_blocks(ff.CHB_KC, ff.CHB_DE, s.chrom_of)
         if ff.SC_USE_SPHERICAL_CONTAINER:
             self.set_container(ff.SC_SCALE, R1, R2, centre)
         if ff.IBL_USE_B_LAMINA_INTERACTION:

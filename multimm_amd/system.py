@@ -54,7 +54,9 @@ class ForceFieldParams:
     IBL_SCALE: float = 400.0
     CF_USE_CENTRAL_FORCE: bool = False
     CF_STRENGTH: float = 20.0
-    CHB_USE_CHROMOSOMAL_BLOCKS: bool = False   # not on the path yet
+    CHB_USE_CHROMOSOMAL_BLOCKS: bool = False
+    CHB_KC: float = 0.3
+    CHB_DE: float = 1e-4
     # Engine-only key: pair cutoff in nm.  <= 0 reproduces the reference (OpenMM NoCutoff, all pairs);
     # > 0 is plain truncation (OpenMM CutoffNonPeriodic) and selects the cell-list kernel.
     NB_CUTOFF: float = 0.6
@@ -143,6 +145,12 @@ class ChromatinSystem:
     @property
     def flags(self) -> np.ndarray:
         return backbone_flags(self.n_beads, self.chr_ends)
+
+    @property
+    def chrom_of(self) -> np.ndarray:
+        """``chrom_spin`` (model.py:158-162): index of the chr_ends interval a bead lies in; only equality
+        of two beads' values matters to the chromosomal-block force."""
+        return (np.searchsorted(self.chr_ends, np.arange(self.n_beads), side="right") - 1).astype(np.int32)
 
     @property
     def n_loops(self) -> int:

@@ -24,6 +24,7 @@
  *   spherical container     model.py:453-466
  *   B-lamina "sin" shell    model.py:468-507
  *   central force           model.py:552-623 (harmonic form :579-586)
+ *   chromosomal blocks      model.py:386-451 (polynomial form :416-419)
  *   backbone bonds          model.py:625-636
  *   loop bonds              model.py:638-659
  *   angles                  model.py:708-720
@@ -48,7 +49,8 @@ enum {
     ORC_T_CONTAINER = 5,
     ORC_T_LAMINA = 6,
     ORC_T_CENTRAL = 7,
-    ORC_N_TERMS = 8
+    ORC_T_CHB = 8,
+    ORC_N_TERMS = 9
 };
 
 /* Mirrored field-for-field by oracle/oracle.py:OrcSystem (ctypes.Structure). */
@@ -76,6 +78,9 @@ typedef struct {
     double cf_G, cf_R1;
     const double *cf_w; /* [n] chrom_strength */
     double centre[3];   /* mass_center, model.py:759 */
+    int32_t use_chb;
+    double chb_kc, chb_de;
+    const int32_t *chrom_of; /* [n] chrom_spin: pairs interact iff equal (model.py:416-419) */
 } orc_system;
 
 typedef struct {
@@ -295,6 +300,34 @@ static int nonbonded_cells(const orc_system *s, const double *x, double *F, doub
     return 0;
 }
 
+/* Chromosomal blocks (model.py:416-419): E = dE*(k_C r^4 - r^3 + r^2) for every pair of beads with the
+ * same chrom_spin, no cutoff (the potential grows with r).  dE/dr = dE*(4 k_C r^3 - 3 r^2 + 2 r), so
+ * F_i = -dE*(4 k_C r^2 - 3 r + 2) * d with d = x_i - x_j (no division by r). */
+static void chromosomal_blocks(const orc_system *s, const double *x, double *F, double *eterms) {
+    const int n = s->n;
+    double e = 0.0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : e)
+    for (int i = 0; i < n; ++i) {
+        double fx = 0, fy = 0, fz = 0, ei = 0;
+        const int ci = s->chrom_of[i];
+        for (int j = 0; j < n; ++j) {
+            if (j == i || s->chrom_of[j] != ci) continue;
+            double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+            double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2);
+            ei += s->chb_de * r2 * (s->chb_kc * r2 - r + 1.0);
+            double fs = -s->chb_de * (4.0 * s->chb_kc * r2 - 3.0 * r + 2.0);
+            fx += fs * dx;
+            fy += fs * dy;
+            fz += fs * dz;
+        }
+        F[3 * i] += fx;
+        F[3 * i + 1] += fy;
+        F[3 * i + 2] += fz;
+        e += 0.5 * ei;
+    }
+    eterms[ORC_T_CHB] += e;
+}
+
 /* HarmonicBondForce: E = 1/2 k (r-r0)^2 (OpenMM convention).  F_i = -k (r-r0) d/r, d = x_i - x_j. */
 static inline double harmonic_pair(const double *x, double *F, int i, int j, double r0, double k) {
     double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
@@ -368,6 +401,7 @@ int orc_eval(const orc_system *s, const double *x, double *F_out, double *eterms
             return -1;
         }
     }
+    if (s->use_chb && s->chrom_of) chromosomal_blocks(s, x, F, eterms);
     if (s->bb_flags) {
         if (s->use_bond)
             for (int i = 0; i + 1 < n; ++i)

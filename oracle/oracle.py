@@ -14,8 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libmmx_oracle.so")
-N_TERMS = 8
-TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")
+N_TERMS = 9
+TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central", "chb")
 
 
 class OrcSystem(C.Structure):
@@ -33,6 +33,7 @@ class OrcSystem(C.Structure):
         ("use_lamina", C.c_int32), ("ibl_B", C.c_double), ("ibl_R1", C.c_double), ("ibl_R2", C.c_double),
         ("use_central", C.c_int32), ("cf_G", C.c_double), ("cf_R1", C.c_double), ("cf_w", C.c_void_p),
         ("centre", C.c_double * 3),
+        ("use_chb", C.c_int32), ("chb_kc", C.c_double), ("chb_de", C.c_double), ("chrom_of", C.c_void_p),
     ]
 
 
@@ -123,6 +124,11 @@ class Oracle:
         c = system.centre
         for k in range(3):
             o.centre[k] = r32(c[k])
+        o.use_chb = int(getattr(ff, "CHB_USE_CHROMOSOMAL_BLOCKS", False))
+        if o.use_chb:
+            self._keep["chrom"] = np.ascontiguousarray(system.chrom_of, dtype=np.int32)
+            o.chrom_of = self._keep["chrom"].ctypes.data
+            o.chb_kc, o.chb_de = r32(ff.CHB_KC), r32(ff.CHB_DE)
         self.o = o
         self.f32 = as_float32_inputs
 

@@ -17,7 +17,7 @@ def energy_terms(system, positions=None, cutoff=None) -> dict:
     R1, R2, r_comp = system.radii
     c = system.centre
     rc = ff.NB_CUTOFF if cutoff is None else cutoff
-    out = dict(ev=0.0, gauss=0.0, bond=0.0, angle=0.0, loop=0.0, container=0.0, lamina=0.0, central=0.0)
+    out = dict(ev=0.0, gauss=0.0, bond=0.0, angle=0.0, loop=0.0, container=0.0, lamina=0.0, central=0.0, chb=0.0)
     iu = np.triu_indices(n, k=1)
     if ff.EV_USE_EXCLUDED_VOLUME or ff.COB_USE_COMPARTMENT_BLOCKS or ff.SCB_USE_SUBCOMPARTMENT_BLOCKS:
         d = x[iu[0]] - x[iu[1]]
@@ -31,6 +31,11 @@ def energy_terms(system, positions=None, cutoff=None) -> dict:
             E = tab[system.labels[iu[0]].astype(int) + 2, system.labels[iu[1]].astype(int) + 2]
             e = -E * np.exp(-r * r / (2.0 * r_comp * r_comp))
             out["gauss"] = float(e[inside].sum())
+    if getattr(ff, "CHB_USE_CHROMOSOMAL_BLOCKS", False):  # "E*(k_C*r^4 - r^3 + r^2); E = dE*delta(chrom1-chrom2)", all pairs
+        d = x[iu[0]] - x[iu[1]]
+        r = np.sqrt((d * d).sum(1))
+        same = system.chrom_of[iu[0]] == system.chrom_of[iu[1]]
+        out["chb"] = float((ff.CHB_DE * (ff.CHB_KC * r ** 4 - r ** 3 + r ** 2))[same].sum())
     flags = system.flags
     if ff.POL_USE_HARMONIC_BOND:
         i = np.nonzero(flags & 1)[0]

@@ -30,8 +30,8 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_stats_struct_layout_matches_header():
     from multimm_amd.engine import MMXStats
-    # 4 int32 + 6 double + 8 double + 8 double + 8 int64 + 8 int64
-    assert ctypes.sizeof(MMXStats) == 16 + 8 * (6 + 8 + 8 + 8 + 8)
+    # 4 int32 + 6 double + 9 double (terms) + 8 double + 8 int64 + 8 int64 (kernel slots)
+    assert ctypes.sizeof(MMXStats) == 16 + 8 * (6 + 9 + 8 + 8 + 8)
 
 
 def test_no_cpu_fallback_without_gpu():

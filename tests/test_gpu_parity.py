@@ -24,7 +24,7 @@ def _check(system, cutoff, label):
     with engine_for(s) as eng:
         et, F = eng.compute()
     scale_e = np.abs(et_ref).sum()
-    for t in range(8):
+    for t in range(len(TERM_NAMES)):
         assert abs(et[t] - et_ref[t]) <= E_RTOL * scale_e + E_ATOL, (
             f"{label}: term {TERM_NAMES[t]} gpu={et[t]!r} ref={et_ref[t]!r}")
     ferr = np.abs(F.astype(np.float64) - F_ref).max()
@@ -73,6 +73,18 @@ def test_single_terms():
             s.chrom_strength = chrom_strength_per_bead(gw_chr_ends(3000), 3000)
         et, _ = _check(s, 0.6, on)
         assert np.count_nonzero(et) == 1, (on, et)
+
+
+def test_chromosomal_blocks_all_pairs_per_chromosome():
+    """CHB polynomial term (model.py:416-419, enabled by examples/config_gw.ini): exact all-pairs inside every
+    chromosome; strong dE so that the term is well above fp32 noise, plus the shipped force set of config_gw.ini."""
+    for n in (3000, 20000):
+        s = synthetic_system("gw_200k", n_beads=n, jitter=0.03, seed=7, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.05)
+        et, _ = _check(s, 0.6, f"CHB n={n}")
+        assert et[8] != 0.0
+    shipped = dict(SC_USE_SPHERICAL_CONTAINER=True, CHB_USE_CHROMOSOMAL_BLOCKS=True, COB_USE_COMPARTMENT_BLOCKS=False,
+                   SCB_USE_SUBCOMPARTMENT_BLOCKS=True, IBL_USE_B_LAMINA_INTERACTION=True, CF_USE_CENTRAL_FORCE=True)
+    _check(synthetic_system("gw_200k", n_beads=8000, jitter=0.03, **shipped), 0.6, "config_gw.ini force set")
 
 
 def test_generic_ev_power():
@@ -148,10 +160,11 @@ def test_domain_decomposition_owned_ranges():
     slice against the whole system's positions (no communicator needed for a single evaluation).  Forces
     concatenate to the single-domain result and the per-rank energy shares add up to the total."""
     from oracle.oracle import Oracle
-    s = synthetic_system("gw_200k", n_beads=20000, jitter=0.03, seed=5, **ALL_ON)
+    s = synthetic_system("gw_200k", n_beads=20000, jitter=0.03, seed=5, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.05,
+                         **ALL_ON)
     et_ref, F_ref = Oracle(s).eval()
     for world in (2, 3, 8):
-        et_sum = np.zeros(8)
+        et_sum = np.zeros(len(TERM_NAMES))
         parts = []
         for r in range(world):
             with engine_for(s, rank=r, world=world) as eng:

@@ -30,8 +30,7 @@ def test_gw_preset_matches_reference_argument_changer(tmp_path):
     assert c.ff.IBL_USE_B_LAMINA_INTERACTION and not c.ff.CF_USE_CENTRAL_FORCE and not c.SIM_RUN_MD
     c2 = load_config(dict(MODELLING_LEVEL="region", N_BEADS=77))
     assert c2.N_BEADS == 5000 and not c2.ff.COB_USE_COMPARTMENT_BLOCKS and not c2.ff.SC_USE_SPHERICAL_CONTAINER
-    with pytest.raises(NotImplementedError):
-        load_config(dict(CHB_USE_CHROMOSOMAL_BLOCKS=True))
+    assert load_config(dict(CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_KC=0.3)).ff.CHB_USE_CHROMOSOMAL_BLOCKS
     with pytest.raises(ValueError):
         load_config(dict(MODELLING_LEVEL="nonsense"))
 

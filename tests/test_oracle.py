@@ -91,10 +91,10 @@ def test_finite_difference_gradient_all_terms(oracle_lib):
     from oracle import oracle_np
     from oracle.oracle import Oracle
     s = synthetic_system("gw_200k", n_beads=300, jitter=0.02, NB_CUTOFF=0.0, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
-                         CF_USE_CENTRAL_FORCE=True)
+                         CF_USE_CENTRAL_FORCE=True, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.5)
     et, F = Oracle(s, as_float32_inputs=False).eval()
     en = oracle_np.energy_terms(s)
-    for i, k in enumerate(("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central")):
+    for i, k in enumerate(("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "central", "chb")):
         assert et[i] == pytest.approx(en[k], rel=1e-11, abs=1e-9), k
         assert et[i] != 0.0, k
     beads = [0, 1, 2, 5, 150, 298, 299] + list(np.unique(np.r_[s.loop_m, s.loop_n])[:3])
