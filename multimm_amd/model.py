@@ -37,6 +37,17 @@ class MultiMM:
         if str(self.args.PLATFORM).upper() not in ("MI355X", "GFX950"):
             raise ValueError(f"PLATFORM={self.args.PLATFORM!r}: this package only provides the MI355X platform")
         n = int(self.args.N_BEADS)
+        if ms is None and str(self.args.LOOPS_PATH or "").lower().endswith(".bedpe"):
+            # the reference's own inputs (model.py:105-132): compartments first, then loops, whose chr_ends
+            # overwrite the ones of import_bed
+            from .ingest import import_bed, import_mns_from_bedpe
+            chrom = self.args.CHROM or None
+            coords = (self.args.LOC_START, self.args.LOC_END) if chrom else None
+            if self.args.COMPARTMENT_PATH and str(self.args.COMPARTMENT_PATH).lower().endswith(".bed"):
+                Cs, chr_ends, _ = import_bed(self.args.COMPARTMENT_PATH, n, coords=coords, chrom=chrom,
+                                             seed=int(self.args.SHUFFLING_SEED))
+            ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(self.args.LOOPS_PATH, n, coords=coords, chrom=chrom,
+                                                             seed=int(self.args.SHUFFLING_SEED))
         if ms is None:
             preset = "gw_200k" if str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") else "chr1_50k"
             syn = synthetic_system(preset, seed=int(self.args.SHUFFLING_SEED), n_beads=n)
