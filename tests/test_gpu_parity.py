@@ -239,3 +239,27 @@ def test_one_million_beads_runs():
         assert abs(et[2]) < 1e-2 * s.n_beads * 1e-3
         st = eng.minimize(tolerance=0.0, max_iters=10)
         assert st.iterations == 10 and st.e_final < st.e_initial
+
+
+def test_multimm_run_end_to_end(tmp_path):
+    """The reference's own smoke-test shape (tests/test_simulations.py: run, then assert the output files) on
+    PLATFORM = MI355X, plus what the reference never checks: the written structure is the minimized one."""
+    import os
+    from multimm_amd import cif
+    from multimm_amd.config import load_config
+    from multimm_amd.model import MultiMM
+    ini = tmp_path / "config.ini"
+    ini.write_text("[Main]\nPLATFORM = MI355X\nN_BEADS = 3000\nOUT_PATH = %s\nSC_USE_SPHERICAL_CONTAINER = True\n"
+                   "COB_USE_COMPARTMENT_BLOCKS = True\nIBL_USE_B_LAMINA_INTERACTION = True\nMIN_MAX_ITERATIONS = 300\n"
+                   % (tmp_path / "out"))
+    m = MultiMM(load_config(str(ini)))
+    st = m.run()
+    out = tmp_path / "out"
+    assert os.path.exists(out / "metadata" / "MultiMM_init.cif")
+    assert os.path.exists(out / "model" / "MultiMM_minimized.cif")
+    assert os.path.exists(out / "model" / "chromosomes" / "MultiMM_minimized_chr1.cif")
+    assert st.iterations > 0 and st.e_final < st.e_initial
+    x = cif.read_positions(str(out / "model" / "MultiMM_minimized.cif"))
+    assert x.shape == (3000, 3) and np.abs(x - m.state_positions).max() <= 5.1e-5
+    bonds = np.linalg.norm(np.diff(x, axis=0), axis=1)[1:]
+    assert 0.05 < np.median(bonds) < 0.2
