@@ -221,8 +221,10 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
 
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
-        const int c = __float_as_int(lo_i.w);
-        if ((__float_as_int(hi_i.w) >> 8) == 0) continue; // no owned bead in this cluster (multi-GPU ghosts)
+        // wave-uniform values are moved to scalar registers explicitly (v_readfirstlane): hipcc cannot prove
+        // uniformity of loaded / ballot-derived values and would otherwise run the loop control on the VALU
+        const int c = __builtin_amdgcn_readfirstlane(__float_as_int(lo_i.w));
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w) >> 8) == 0) continue; // no owned bead in this cluster (multi-GPU ghosts)
         // i-cluster -> scalar registers
         float4 pv = spos4[(size_t)icl * kCl + slot];
         // padding slots sit at +1e18 in spos4 (they are also j entries of this very cluster) and ghost beads
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
                     }
                     const int zz = z0 + row_i / (y1 - y0 + 1), yy = y0 + row_i % (y1 - y0 + 1);
                     const int row = (zz * G.ny + yy) * G.nx;
-                    base = cstart[row + x0];
-                    c1 = cstart[row + x1 + 1];
+                    base = __builtin_amdgcn_readfirstlane(cstart[row + x0]);
+                    c1 = __builtin_amdgcn_readfirstlane(cstart[row + x1 + 1]);
                     ++row_i;
                     continue;
                 }
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
                 }
                 const unsigned long long mask = __ballot(ok);
                 if (ok) list[nlist + __popcll(mask & lt)] = jc;
-                nlist += __popcll(mask);
+                nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
                 base += 64;
             }
             if (nlist == 0 && (!BEADCULL || rcount == 0)) break;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
                     const bool okb = fmaf(bx, bx, fmaf(by, by, bz * bz)) < rc2;
                     const unsigned long long mb = __ballot(okb);
                     if (okb) ring[(rhead + rcount + __popcll(mb & lt)) & 127] = q;
-                    rcount += __popcll(mb);
+                    rcount += __builtin_amdgcn_readfirstlane(__popcll(mb));
                 }
                 const bool last = !more && (t + 1 == nsteps);
                 // BEADCULL: drain the ring 64 beads at a time (everything at the very last step)
