@@ -362,21 +362,39 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                 s_buf[q] = v;
             }
             __syncthreads();
+            // bitonic network; stages with j < 128 stay inside 128-element segments, each owned by one wave
+            // (wave-level LDS ordering only), so only the few stages with j >= 128 need a block barrier
             for (int k = 2; k <= n2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int q = threadIdx.x; q < (n2 >> 1); q += 256) {
-                        const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-                        const int i1 = i0 | j;
-                        const unsigned long long a = s_buf[i0], b = s_buf[i1];
-                        const bool up = (i0 & k) == 0;
-                        if ((a > b) == up) {
-                            s_buf[i0] = b;
-                            s_buf[i1] = a;
+                    if (j >= 128) {
+                        __syncthreads();
+                        for (int q = threadIdx.x; q < (n2 >> 1); q += 256) {
+                            const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                            const int i1 = i0 | j;
+                            const unsigned long long a = s_buf[i0], b = s_buf[i1];
+                            const bool up = (i0 & k) == 0;
+                            if ((a > b) == up) {
+                                s_buf[i0] = b;
+                                s_buf[i1] = a;
+                            }
                         }
+                        __syncthreads();
+                    } else {
+                        for (int seg = wave; seg < (n2 >> 7); seg += 4) {
+                            const int i0 = (seg << 7) + (((lane & ~(j - 1)) << 1) | (lane & (j - 1)));
+                            const int i1 = i0 | j;
+                            const unsigned long long a = s_buf[i0], b = s_buf[i1];
+                            const bool up = (i0 & k) == 0;
+                            if ((a > b) == up) {
+                                s_buf[i0] = b;
+                                s_buf[i1] = a;
+                            }
+                        }
+                        wave_lds_sync();
                     }
-                    __syncthreads();
                 }
             }
+            __syncthreads();
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
             __threadfence_block();
             __syncthreads();
