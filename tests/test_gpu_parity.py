@@ -263,3 +263,22 @@ def test_multimm_run_end_to_end(tmp_path):
     assert x.shape == (3000, 3) and np.abs(x - m.state_positions).max() <= 5.1e-5
     bonds = np.linalg.norm(np.diff(x, axis=0), axis=1)[1:]
     assert 0.05 < np.median(bonds) < 0.2
+
+
+def test_config2_converges_to_openmm_tolerance():
+    """BASELINE config 2 (chr1, 50k beads, EV + backbone + loops) minimized until OpenMM's default stop rule holds;
+    the oracle confirms energy and stop rule at the returned point."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("chr1_50k")
+    with engine_for(s) as eng:
+        st = eng.minimize(tolerance=10.0, max_iters=0)
+        x = eng.get_positions().astype(np.float64)
+    assert st.status == 0 and 200 < st.iterations < 20000
+    assert st.e_final < 0.2 * st.e_initial
+    et, F = Oracle(s).eval(x)
+    assert et.sum() == pytest.approx(st.e_final, rel=2e-5)
+    x0 = s.positions
+    eps = 10.0 / max(1.0, np.sqrt((x0 * x0).sum() / len(x0)))
+    assert np.linalg.norm(F) / max(1.0, np.linalg.norm(x)) <= eps * 1.02
+    bonds = np.linalg.norm(np.diff(x, axis=0), axis=1)[1:]
+    assert abs(np.median(bonds) - 0.1) < 0.01
