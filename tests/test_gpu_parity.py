@@ -282,3 +282,32 @@ def test_config2_converges_to_openmm_tolerance():
     assert np.linalg.norm(F) / max(1.0, np.linalg.norm(x)) <= eps * 1.02
     bonds = np.linalg.norm(np.diff(x, axis=0), axis=1)[1:]
     assert abs(np.median(bonds) - 0.1) < 0.01
+
+
+def test_edge_cases_tiny_coincident_and_crowded():
+    """Edge cases: 1-3 beads, no loops, coincident beads (r = 0: energy counted, zero force), every bead in ONE
+    cell (5000 beads: beyond the in-LDS sort, 625 clusters in one cell), beads far apart (one bead per cell)."""
+    from multimm_amd.system import ChromatinSystem, ForceFieldParams
+    from oracle.oracle import Oracle
+    ff = ForceFieldParams(LE_USE_HARMONIC_BOND=False, NB_CUTOFF=0.6)
+    for n in (1, 2, 3, 7, 9):
+        pos = np.arange(3 * n, dtype=np.float64).reshape(n, 3) * 0.037
+        s = ChromatinSystem(n, pos, np.array([0, n]), np.zeros(n, np.int8), ff=ff)
+        _check(s, 0.6, f"tiny n={n}")
+        _check(s, 0.0, f"tiny n={n} all-pairs")
+    # two beads at the same point + a third one: E_ev(0) = 100*(0.1/0.05)^6 = 6400 for the coincident pair
+    pos = np.array([[0.2, 0.2, 0.2], [0.2, 0.2, 0.2], [0.5, 0.2, 0.2]])
+    s = ChromatinSystem(3, pos, np.array([0, 3]), np.zeros(3, np.int8),
+                        ff=ForceFieldParams(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False,
+                                            LE_USE_HARMONIC_BOND=False, NB_CUTOFF=0.6))
+    for rc in (0.6, 0.0):
+        et, F = _check(s, rc, f"coincident rc={rc}")
+        assert et[0] > 6400.0 and np.all(np.isfinite(F))
+    rng = np.random.default_rng(0)
+    n = 5000
+    crowded = ChromatinSystem(n, rng.random((n, 3)) * 0.4, np.array([0, n]), rng.integers(-2, 3, n).astype(np.int8),
+                              ff=ForceFieldParams(LE_USE_HARMONIC_BOND=False, COB_USE_COMPARTMENT_BLOCKS=True, NB_CUTOFF=0.6))
+    _check(crowded, 0.6, "crowded: one cell")
+    sparse = ChromatinSystem(300, rng.random((300, 3)) * 40.0, np.array([0, 300]), np.zeros(300, np.int8),
+                             ff=ForceFieldParams(LE_USE_HARMONIC_BOND=False, NB_CUTOFF=0.6))
+    _check(sparse, 0.6, "sparse: one bead per cell")
