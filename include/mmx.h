@@ -177,6 +177,42 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out);
  * place (read them with mmx_get_positions).  max_iters == 0: until converged. */
 int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out);
 
+/* ---- molecular dynamics -----------------------------------------------------------
+ * Replaces the integrator objects of model.py:768-808 and `simulation.step(n)` of run_md(), model.py:907-995,
+ * on the same force kernels.  Update rules are OpenMM's leap-frog integrators without constraints:
+ *   MMX_INT_LANGEVIN  mm.LangevinIntegrator(T, friction, dt)   (the default, config.py:258-266)
+ *   MMX_INT_VERLET    mm.VerletIntegrator(dt)
+ *   MMX_INT_BROWNIAN  mm.BrownianIntegrator(T, friction, dt)
+ * (variable-step and aMD integrators are not provided: MMX_ERR_BAD_ARG).
+ * Units: ps, K, 1/ps, amu (ff.xml:5: 16427.889 for every bead); velocities nm/ps.  Noise comes from
+ * Philox4x32-10 keyed by `seed` and indexed by (bead, step): independent of the launch geometry and of the
+ * decomposition over GPUs (it is not OpenMM's generator: trajectories agree in distribution only). */
+#define MMX_INT_LANGEVIN 0
+#define MMX_INT_VERLET 1
+#define MMX_INT_BROWNIAN 2
+
+typedef struct {
+    int64_t step_count;  /* steps integrated since mmx_md_configure (State.getStepCount(), model.py:939) */
+    int32_t n_steps;     /* steps of this call */
+    int32_t integrator;
+    double potential;    /* kJ/mol at the final positions (State.getPotentialEnergy(), model.py:943) */
+    double kinetic;      /* kJ/mol; leap-frog velocities shifted by dt/2 as OpenMM reports them (model.py:944) */
+    double temperature;  /* 2 K / (3 N kB) in kelvin (the fallback formula of model.py:966-970) */
+    double seconds;      /* wall time of the call */
+    double energy_terms[MMX_N_TERMS];
+} mmx_md_stats;
+
+int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temperature_K, double friction_per_ps,
+                     double mass_amu, uint64_t seed);
+/* context.setVelocitiesToTemperature(T, seed), model.py:878: v = sqrt(kB T / m) N(0,1) per component. */
+int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uint64_t seed);
+/* [N,3] nm/ps, whole system (multi-GPU: the owned rows are used / filled, other rows are left untouched). */
+int mmx_set_velocities(mmx_handle h, const float *v_nm_per_ps);
+int mmx_get_velocities(mmx_handle h, float *v_nm_per_ps);
+/* simulation.step(n_steps) followed by getState(getEnergy=True): n force evaluations (+1 when positions or
+ * parameters changed since the last step), all enqueued on the device without host round trips. */
+int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * Launches kernel slot `kernel` (MMX_K_*) `reps` times back to back at the current positions on the
  * handle's stream between two HIP events and returns the mean duration per launch and the

@@ -31,6 +31,10 @@ def parse_quantity(text: Any) -> float:
     unit = str(text)[m.end():].strip().lower()
     if unit.startswith("angstrom"):
         val *= 0.1
+    elif unit.startswith("femtosecond"):
+        val *= 1e-3
+    elif unit.startswith("nanosecond"):
+        val *= 1e3
     elif unit.startswith("degree"):
         val *= 3.141592653589793 / 180.0
     return val
@@ -67,6 +71,13 @@ class SimulationConfig:
     SHUFFLING_SEED: int = 0
     N_ENSEMBLE: Optional[int] = None
     SIM_RUN_MD: bool = False
+    SIM_N_STEPS: int = 10000           # config.py:253
+    SIM_SAMPLING_STEP: int = 100       # config.py:257
+    SIM_INTEGRATOR_TYPE: str = "langevin"   # config.py:258; MI355X provides langevin / verlet / brownian
+    SIM_INTEGRATOR_STEP: float = 0.001      # ps  ("1 femtosecond", config.py:259)
+    SIM_FRICTION_COEFF: float = 0.5         # 1/ps (config.py:260-262)
+    SIM_TEMPERATURE: float = 310.0          # K   (config.py:266)
+    TRJ_FRAMES: int = 2000                  # config.py:267
     MIN_TOLERANCE: float = 10.0        # OpenMM minimizeEnergy() default, kJ/mol/nm
     MIN_MAX_ITERATIONS: int = 0        # 0 = until converged
     ff: ForceFieldParams = field(default_factory=ForceFieldParams)
@@ -106,7 +117,7 @@ _FF_FIELDS = {f.name: f.type for f in dataclasses.fields(ForceFieldParams)}
 
 def load_config(path_or_dict) -> SimulationConfig:
     """Reads ``[Main]`` of an ini file (or a flat dict) into a SimulationConfig; unknown keys that belong
-    to parts of MultiMM outside this path (plots, MD, nucleosomes, ...) are ignored."""
+    to parts of MultiMM outside this path (plots, nucleosomes, ...) are ignored."""
     if isinstance(path_or_dict, dict):
         raw = {str(k).upper(): v for k, v in path_or_dict.items()}
     else:
@@ -126,11 +137,12 @@ def load_config(path_or_dict) -> SimulationConfig:
             sval = None if (isinstance(val, str) and val.strip().lower() in ("", "none")) else val
             if isinstance(cur, bool):
                 setattr(cfg, key, parse_bool(val))
-            elif key in ("N_BEADS", "SHUFFLING_SEED", "MIN_MAX_ITERATIONS", "DEVICE"):
+            elif key in ("N_BEADS", "SHUFFLING_SEED", "MIN_MAX_ITERATIONS", "DEVICE", "SIM_N_STEPS",
+                         "SIM_SAMPLING_STEP", "TRJ_FRAMES"):
                 setattr(cfg, key, int(float(sval)) if sval is not None else getattr(cfg, key))
             elif key in ("LOC_START", "LOC_END", "N_ENSEMBLE"):
                 setattr(cfg, key, int(float(sval)) if sval is not None else None)
-            elif key == "MIN_TOLERANCE":
+            elif key in ("MIN_TOLERANCE", "SIM_INTEGRATOR_STEP", "SIM_FRICTION_COEFF", "SIM_TEMPERATURE"):
                 setattr(cfg, key, parse_quantity(val))
             else:
                 setattr(cfg, key, sval if sval is None else str(sval))

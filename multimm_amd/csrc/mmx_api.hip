@@ -5,6 +5,7 @@
 #include "mmx_cells.hpp"
 #include "mmx_common.hpp"
 #include "mmx_lbfgs.hpp"
+#include "mmx_md.hpp"
 #include "mmx_nonbonded.hpp"
 
 #include <dlfcn.h>
@@ -119,6 +120,14 @@ struct mmx_handle_s {
     float tab_cob[25]{}, tab_scb[25]{};
     bool has_cob = false, has_scb = false;
     float ev_cut = 0.f, g_cut = 0.f, g_rc = 0.15f;
+    // molecular dynamics (mmx_md_*): velocities, low-order position bits, integrator constants
+    float *v = nullptr, *xlo = nullptr;
+    double *ke_part = nullptr, *ke_out = nullptr;
+    bool md_configured = false, md_forces_valid = false;
+    int md_kind = 0;
+    double md_dt = 0.0, md_temp = 0.0, md_friction = 0.0, md_mass = 1.0;
+    uint64_t md_seed = 0, md_step = 0;
+    MdParams md{};
     // options
     int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0;
     // profiling
@@ -291,11 +300,24 @@ __global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const f
         pos4[i] = make_float4(3e18f, 3e18f, 3e18f, __int_as_float(-8 + 2)); // padding of the last slice
 }
 
-void enqueue_build(mmx_handle_s *h, bool move, bool init = false) {
+enum PackMode { PACK_PLAIN = 0, PACK_MOVE = 1, PACK_MD = 2 };
+
+void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
-    if (move)
+    if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
+        MdParams M = h->md;
+        M.step_lo = (uint32_t)h->md_step;
+        M.step_hi = (uint32_t)(h->md_step >> 32);
+#define MDP(K)                                                                                              \
+    hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xlo,   \
+                       h->v, h->g, h->labels, h->pos4, h->bbox_part, M)
+        if (h->md_kind == MD_LANGEVIN) MDP(MD_LANGEVIN);
+        else if (h->md_kind == MD_VERLET) MDP(MD_VERLET);
+        else MDP(MD_BROWNIAN);
+#undef MDP
+    } else if (mode == PACK_MOVE)
         hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
     else
@@ -325,11 +347,11 @@ void enqueue_build(mmx_handle_s *h, bool move, bool init = false) {
 }
 
 // One full energy+gradient evaluation followed by the line-search controller.
-void enqueue_eval(mmx_handle_s *h, bool move) {
+void enqueue_eval(mmx_handle_s *h, int mode) {
     EventPair ep{};
     CtlArgs A{};
     bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
-    enqueue_build(h, move);
+    enqueue_build(h, mode);
     prof_end(h, on, ep);
 
     on = prof_begin(h, MMX_K_NONBONDED, ep);
@@ -454,7 +476,7 @@ int ensure_allpairs_scratch(mmx_handle_s *h) {
 // First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
 int prime_items(mmx_handle_s *h) {
     if (!has_nb(h) || all_pairs(h)) return MMX_OK;
-    enqueue_build(h, false, true);
+    enqueue_build(h, PACK_PLAIN, true);
     return pull_state(h);
 }
 
@@ -626,6 +648,8 @@ int mmx_destroy(mmx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
+    for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out})
+        if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
                     h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
@@ -649,6 +673,7 @@ int mmx_destroy(mmx_handle h) {
 
 int mmx_set_positions(mmx_handle h, const float *xyz) {
     if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
     for (size_t i = 0; i < (size_t)3 * h->n; ++i)
         if (!std::isfinite(xyz[i])) return fail(h, MMX_ERR_BAD_ARG, "non-finite position");
@@ -691,6 +716,7 @@ int mmx_get_positions(mmx_handle h, float *xyz) {
 
 int mmx_set_labels(mmx_handle h, const int8_t *s) {
     if (!h || !s) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     for (int i = 0; i < h->n; ++i)
         if (s[i] < -2 || s[i] > 2) return fail(h, MMX_ERR_BAD_ARG, "label outside {-2..2}");
     HIPCHK(h, hipSetDevice(h->device));
@@ -702,6 +728,7 @@ int mmx_set_labels(mmx_handle h, const int8_t *s) {
 int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, float bond_k, float angle_theta0,
                            float angle_k, int32_t use_bond, int32_t use_angle) {
     if (!h || !flags) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     const int n = h->n;
     for (int i = 0; i < n; ++i) {
         if ((flags[i] & 1) && i + 1 >= n) return fail(h, MMX_ERR_BAD_ARG, "bond flag on the last bead");
@@ -743,6 +770,7 @@ int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, floa
 
 int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop) {
     if (!h || n_loops < 0 || (n_loops > 0 && (!m || !n || !r0))) return fail(h, MMX_ERR_BAD_ARG, "bad loop arrays");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
     for (int l = 0; l < n_loops; ++l) {
         if (m[l] < 0 || m[l] >= h->n || n[l] < 0 || n[l] >= h->n || m[l] == n[l])
@@ -801,6 +829,7 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
 
 int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) {
     if (!h) return MMX_ERR_BAD_ARG;
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power))
         return fail(h, MMX_ERR_BAD_ARG, "bad excluded-volume parameters");
     h->P.use_ev = 1;
@@ -814,6 +843,7 @@ int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small,
 
 int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm) {
     if (!h || !E || !(rc > 0.f)) return fail(h, MMX_ERR_BAD_ARG, "bad compartment parameters");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     auto idx = [](int si, int sj) { return (si + 2) * 5 + (sj + 2); };
     if (mode == MMX_COMP_COB) { // model.py:246-250: A = {1,2}, B = {-1,-2}
         std::memset(h->tab_cob, 0, sizeof(h->tab_cob));
@@ -840,6 +870,7 @@ int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, f
 
 int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]) {
     if (!h || !centre) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     h->P.use_container = 1;
     h->P.sc_C = C;
     h->P.sc_R1 = R1;
@@ -852,6 +883,7 @@ int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float cen
 
 int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]) {
     if (!h || !centre || !(R2 != R1)) return fail(h, MMX_ERR_BAD_ARG, "bad lamina parameters");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     h->P.use_lamina = 1;
     h->P.ibl_B = B;
     h->P.ibl_R1 = R1;
@@ -864,6 +896,7 @@ int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre
 
 int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w) {
     if (!h || !centre || !w) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->cf_w) HIPCHK(h, dalloc(&h->cf_w, (size_t)h->n));
     HIPCHK(h, hipMemcpy(h->cf_w, w, sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice));
@@ -878,6 +911,7 @@ int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], cons
 
 int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom) {
     if (!h || !chrom) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     if ((h->n + 255) / 256 > kPartStride) return fail(h, MMX_ERR_BAD_ARG, "too many beads for the chromosomal-block kernel");
     HIPCHK(h, hipSetDevice(h->device));
     // chromosome ids must form contiguous runs; remap them to 0..K-1 in order of appearance
@@ -913,6 +947,7 @@ int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t 
 
 int mmx_disable_term(mmx_handle h, int32_t term) {
     if (!h) return MMX_ERR_BAD_ARG;
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     switch (term) {
     case MMX_T_EV: h->P.use_ev = 0; break;
     case MMX_T_GAUSS: h->has_cob = h->has_scb = false; h->P.use_gauss = 0; break;
@@ -930,6 +965,7 @@ int mmx_disable_term(mmx_handle h, int32_t term) {
 
 int mmx_set_option(mmx_handle h, const char *key, double value) {
     if (!h || !key) return MMX_ERR_BAD_ARG;
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     const std::string k(key);
     if (k == "deterministic") h->deterministic = value != 0.0;
     else if (k == "profile") h->profile = (int)value;
@@ -952,13 +988,14 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) {
 
 int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
     if (!h) return MMX_ERR_BAD_ARG;
+    h->md_forces_valid = false;
     int rc = prepare(h);
     if (rc) return rc;
     std::memset(h->st_host, 0, sizeof(MinState));
     h->st_host->phase = PH_IDLE;
     if ((rc = push_state(h))) return rc;
     if ((rc = prime_items(h))) return rc;
-    enqueue_eval(h, false);
+    enqueue_eval(h, PACK_PLAIN);
     if ((rc = pull_state(h))) return rc;
     HIPCHK(h, hipGetLastError());
     prof_collect(h, nullptr);
@@ -976,6 +1013,7 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
 
 int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) {
     if (!h || max_iters < 0 || !(tolerance >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad minimize arguments");
+    h->md_forces_valid = false;
     int rc = prepare(h);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1008,7 +1046,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
-    enqueue_eval(h, false);
+    enqueue_eval(h, PACK_PLAIN);
     enqueue_accept(h);
     if ((rc = pull_state(h))) return rc;
     local.e_initial = h->st_host->fx;
@@ -1016,7 +1054,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
         int batch = h->poll_interval;
         if (max_iters > 0) batch = std::max(1, std::min(batch, max_iters - h->st_host->iters));
         for (int b = 0; b < batch; ++b) {
-            enqueue_eval(h, true);
+            enqueue_eval(h, PACK_MOVE);
             enqueue_accept(h);
         }
         if ((rc = pull_state(h))) return rc;
@@ -1048,8 +1086,150 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     return MMX_OK;
 }
 
+// ---- molecular dynamics ---------------------------------------------------------------
+static const double kBoltz = 0.008314462618; // kJ/(mol K), the constant of model.py:967
+
+static void md_refresh(mmx_handle_s *h) {
+    MdParams &M = h->md;
+    const double dt = h->md_dt, kT = kBoltz * h->md_temp, m = h->md_mass, gam = h->md_friction;
+    M.dt = (float)dt;
+    M.inv_dt = (float)(1.0 / dt);
+    M.key0 = (uint32_t)h->md_seed;
+    M.key1 = (uint32_t)(h->md_seed >> 32);
+    if (h->md_kind == MD_LANGEVIN) {
+        const double a = std::exp(-gam * dt);
+        M.vscale = (float)a;
+        M.fscale = (float)((gam > 0.0 ? (1.0 - a) / gam : dt) / m);
+        M.noise = (float)std::sqrt(kT * (1.0 - a * a) / m);
+    } else if (h->md_kind == MD_VERLET) {
+        M.vscale = 1.f;
+        M.fscale = (float)(dt / m);
+        M.noise = 0.f;
+    } else {
+        M.vscale = 0.f;
+        M.fscale = (float)(dt / (gam * m));
+        M.noise = (float)std::sqrt(2.0 * kT * dt / (gam * m));
+    }
+}
+
+int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temperature_K, double friction_per_ps,
+                     double mass_amu, uint64_t seed) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    if (integrator < MMX_INT_LANGEVIN || integrator > MMX_INT_BROWNIAN)
+        return fail(h, MMX_ERR_BAD_ARG, "integrator must be MMX_INT_LANGEVIN, MMX_INT_VERLET or MMX_INT_BROWNIAN");
+    if (!(dt_ps > 0.0) || !(mass_amu > 0.0) || !(temperature_K >= 0.0) || !(friction_per_ps >= 0.0) ||
+        (integrator == MMX_INT_BROWNIAN && !(friction_per_ps > 0.0)))
+        return fail(h, MMX_ERR_BAD_ARG, "bad integrator parameters");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nv = (size_t)h->n4 * 4;
+    if (!h->v) HIPCHK(h, dalloc(&h->v, nv));
+    if (!h->xlo) HIPCHK(h, dalloc(&h->xlo, nv));
+    if (!h->ke_part) HIPCHK(h, dalloc(&h->ke_part, (size_t)1024));
+    if (!h->ke_out) HIPCHK(h, dalloc(&h->ke_out, (size_t)2));
+    h->md_kind = integrator;
+    h->md_dt = dt_ps;
+    h->md_temp = temperature_K;
+    h->md_friction = friction_per_ps;
+    h->md_mass = mass_amu;
+    h->md_seed = seed;
+    h->md_step = 0;
+    h->md_configured = true;
+    h->md_forces_valid = false;
+    md_refresh(h);
+    return MMX_OK;
+}
+
+int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uint64_t seed) {
+    if (!h || !(temperature_K >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad temperature");
+    if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
+    HIPCHK(h, hipSetDevice(h->device));
+    const float sigma = (float)std::sqrt(kBoltz * temperature_K / h->md_mass);
+    hipLaunchKernelGGL(k_md_init_velocities, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own,
+                       h->own_lo, sigma, (uint32_t)seed, (uint32_t)(seed >> 32), h->v);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return MMX_OK;
+}
+
+int mmx_set_velocities(mmx_handle h, const float *vel) {
+    if (!h || !vel) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->v, vel + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyHostToDevice));
+    return MMX_OK;
+}
+
+int mmx_get_velocities(mmx_handle h, float *vel) {
+    if (!h || !vel) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(vel + (size_t)3 * h->own_lo, h->v, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
+    return MMX_OK;
+}
+
+int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) {
+    if (!h || n_steps < 0) return fail(h, MMX_ERR_BAD_ARG, "bad step count");
+    if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
+    int rc = prepare(h);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::memset(h->st_host, 0, sizeof(MinState));
+    h->st_host->phase = PH_IDLE;
+    if ((rc = push_state(h))) return rc;
+    if (!h->md_forces_valid) {
+        // positions / parameters changed: low-order position bits restart at zero, forces are recomputed
+        HIPCHK(h, hipMemsetAsync(h->xlo, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream));
+        if ((rc = prime_items(h))) return rc;
+        enqueue_eval(h, PACK_PLAIN);
+        h->md_forces_valid = true;
+    }
+    for (int s = 0; s < n_steps; ++s) {
+        enqueue_eval(h, PACK_MD);
+        h->md_step++;
+        if ((s + 1) % (8 * std::max(1, h->poll_interval)) == 0) { // bound the queue depth; learn the cluster count
+            if ((rc = pull_state(h))) return rc;
+            const double f = h->st_host->ftrial;
+            if (!(f - f == 0.0)) {
+                h->md_forces_valid = false;
+                return fail(h, MMX_ERR_NAN, "non-finite energy during MD (step too large?)");
+            }
+        }
+    }
+    // kinetic energy with the half-step shift OpenMM applies to leap-frog velocities (none for brownian)
+    const int gk = std::min((h->n_own + 255) / 256, 1024);
+    const double shift = h->md_kind == MD_BROWNIAN ? 0.0 : 0.5 * h->md_dt;
+    hipLaunchKernelGGL(k_md_kinetic, dim3(gk), dim3(256), 0, h->stream, h->n_own, h->v, h->g, (float)(shift / h->md_mass),
+                       0.5 * h->md_mass, h->ke_part);
+    hipLaunchKernelGGL(k_md_kinetic_fold, dim3(1), dim3(256), 0, h->stream, gk, h->ke_part, h->ke_out);
+    if (h->comm) (void)g_rccl.AllReduce(h->ke_out, h->ke_out, 1, ncclDouble, ncclSum, h->comm, h->stream);
+    if ((rc = pull_state(h))) return rc;
+    double ke = 0.0;
+    HIPCHK(h, hipMemcpy(&ke, h->ke_out, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipGetLastError());
+    prof_collect(h, nullptr);
+    const double f = h->st_host->ftrial;
+    if (!(f - f == 0.0) || !(ke - ke == 0.0)) {
+        h->md_forces_valid = false;
+        return fail(h, MMX_ERR_NAN, "non-finite energy during MD (step too large?)");
+    }
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->step_count = (int64_t)h->md_step;
+        out->n_steps = n_steps;
+        out->integrator = h->md_kind;
+        out->potential = f;
+        out->kinetic = ke;
+        out->temperature = 2.0 * ke / (3.0 * (double)h->n * kBoltz);
+        for (int t = 0; t < MMX_N_TERMS; ++t) out->energy_terms[t] = h->st_host->eterms[t];
+        out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return MMX_OK;
+}
+
 int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) {
     if (!h || reps < 1 || !mean_us) return fail(h, MMX_ERR_BAD_ARG, "bad arguments");
+    h->md_forces_valid = false;
     if (kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE)
         return fail(h, MMX_ERR_BAD_ARG, "mmx_time_kernel covers slots 0..4; L-BFGS slots are timed live (option profile)");
     int rc = prepare(h);
@@ -1058,7 +1238,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
     h->st_host->phase = PH_IDLE;
     if ((rc = push_state(h))) return rc;
     if ((rc = prime_items(h))) return rc;
-    enqueue_eval(h, false); // warm: builds cells, fills every buffer the slot reads
+    enqueue_eval(h, PACK_PLAIN); // warm: builds cells, fills every buffer the slot reads
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
@@ -1071,7 +1251,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
     for (int r = 0; r < reps; ++r) {
         switch (kernel) {
         case MMX_K_CELL_BUILD:
-            enqueue_build(h, false);
+            enqueue_build(h, PACK_PLAIN);
             bytes = 56.0 * h->n;
             break;
         case MMX_K_NONBONDED:

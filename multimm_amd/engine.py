@@ -52,6 +52,16 @@ class MMXStats(C.Structure):
         return d
 
 
+class MMXMdStats(C.Structure):
+    """mmx_md_stats of include/mmx.h."""
+    _fields_ = [("step_count", C.c_int64), ("n_steps", C.c_int32), ("integrator", C.c_int32),
+                ("potential", C.c_double), ("kinetic", C.c_double), ("temperature", C.c_double),
+                ("seconds", C.c_double), ("energy_terms", C.c_double * N_TERMS)]
+
+
+INTEGRATORS = {"langevin": 0, "verlet": 1, "brownian": 2}  # MMX_INT_*; model.py:768-808
+BEAD_MASS_AMU = 16427.889                                   # forcefields/ff.xml:5
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); also the list the symbol-export test checks against include/mmx.h
@@ -84,6 +94,11 @@ SIGNATURES = {
     "mmx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "mmx_compute": (C.c_int, [_P, _P, _P]),
     "mmx_minimize": (C.c_int, [_P, C.c_double, C.c_int32, C.POINTER(MMXStats)]),
+    "mmx_md_configure": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64]),
+    "mmx_md_set_velocities_to_temperature": (C.c_int, [_P, C.c_double, C.c_uint64]),
+    "mmx_set_velocities": (C.c_int, [_P, _P]),
+    "mmx_get_velocities": (C.c_int, [_P, _P]),
+    "mmx_md_step": (C.c_int, [_P, C.c_int32, C.POINTER(MMXMdStats)]),
     "mmx_time_kernel": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mmx_nb_census": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -260,6 +275,32 @@ class Engine:
     def minimize(self, tolerance: float = 10.0, max_iters: int = 0) -> MMXStats:
         st = MMXStats()
         self._chk(self._lib.mmx_minimize(self._h, float(tolerance), int(max_iters), C.byref(st)))
+        return st
+
+    # -- molecular dynamics (model.py:768-808, 878, 907-995) -------------------------------------------
+    def md_configure(self, integrator: str = "langevin", dt_ps: float = 0.001, temperature_K: float = 310.0,
+                     friction_per_ps: float = 0.5, mass_amu: float = BEAD_MASS_AMU, seed: int = 0):
+        if integrator not in INTEGRATORS:
+            raise MMXError(-1, f"integrator {integrator!r} is not provided by the MI355X engine "
+                               f"(available: {', '.join(INTEGRATORS)})")
+        self._chk(self._lib.mmx_md_configure(self._h, INTEGRATORS[integrator], float(dt_ps), float(temperature_K),
+                                             float(friction_per_ps), float(mass_amu), int(seed)))
+
+    def set_velocities_to_temperature(self, temperature_K: float, seed: int = 0):
+        self._chk(self._lib.mmx_md_set_velocities_to_temperature(self._h, float(temperature_K), int(seed)))
+
+    def set_velocities(self, v_nm_per_ps):
+        a = _f32(v_nm_per_ps).reshape(self.n, 3)
+        self._chk(self._lib.mmx_set_velocities(self._h, a.ctypes.data))
+
+    def get_velocities(self) -> np.ndarray:
+        out = np.zeros((self.n, 3), dtype=np.float32)
+        self._chk(self._lib.mmx_get_velocities(self._h, out.ctypes.data))
+        return out
+
+    def md_step(self, n_steps: int) -> MMXMdStats:
+        st = MMXMdStats()
+        self._chk(self._lib.mmx_md_step(self._h, int(n_steps), C.byref(st)))
         return st
 
     def time_kernel(self, kernel: int, reps: int = 20):

@@ -5,9 +5,10 @@ same order, same outputs:
 
     run() = set_radiuses -> initialize_simulation -> add_forcefield -> min_energy -> save_chromosomes
 
-(model.py:1216-1248).  What is NOT rebuilt: MD, plots, nucleosome interpolation, file parsers
-(SURVEY.md section 2).  Inputs that the reference parses from .bedpe/.bed files are taken as arrays
-(``ms, ns, ds, chr_ends, Cs``) or generated synthetically with the same tensor contracts.
+(model.py:1216-1248), followed by run_md() when SIM_RUN_MD is set (model.py:907-995).  What is NOT rebuilt:
+plots, nucleosome interpolation.  Inputs come from the reference's own .bedpe/.bed
+files (``multimm_amd/ingest.py``), as arrays (``ms, ns, ds, chr_ends, Cs``), or are generated synthetically
+with the same tensor contracts.
 """
 from __future__ import annotations
 
@@ -59,11 +60,12 @@ class MultiMM:
         self.Cs = np.zeros(n, np.int8) if Cs is None else np.asarray(Cs, dtype=np.int8)
         self.chrom_strength = chrom_strength
         self.save_path = os.path.join(self.args.OUT_PATH, "")
-        for sub in ("metadata", "model", os.path.join("model", "chromosomes")):
+        for sub in ("metadata", "model", os.path.join("model", "chromosomes"), "md_frames"):  # model.py:44-48
             os.makedirs(os.path.join(self.args.OUT_PATH, sub), exist_ok=True)
         self.engine: Optional[Engine] = None
         self.system: Optional[ChromatinSystem] = None
         self.stats = None
+        self.md_history = {"step": [], "potential": [], "kinetic": [], "total": [], "temperature": []}  # model.py:31
 
     # --- model.py:1016-1067 -------------------------------------------------------------------------
     def set_radiuses(self):
@@ -71,7 +73,7 @@ class MultiMM:
         logger.info("[Radiuses] b0=%.4f nm | N=%d | R1=%.4f nm | R2=%.4f nm | r_comp=%.4f nm",
                     self.args.ff.POL_HARMONIC_BOND_R0, self.args.N_BEADS, self.radius1, self.radius2, self.r_comp)
 
-    # --- model.py:722-810 (structure + particles; integrators are MD-only and out of scope) ------------
+    # --- model.py:722-810 (structure + particles; the integrator is configured in run_md) ---------------
     def initialize_simulation(self):
         n = int(self.args.N_BEADS)
         init_cif = os.path.join(self.args.OUT_PATH, "metadata", "MultiMM_init.cif")
@@ -129,6 +131,55 @@ class MultiMM:
                 cif.write_chromosome(os.path.join(self.args.OUT_PATH, "model", "chromosomes",
                                                   f"MultiMM_minimized_chr{i + 1}.cif"), seg)
 
+    # --- model.py:907-995 -----------------------------------------------------------------------------
+    def run_md(self):
+        """Relaxation MD after the minimization: StateDataReporter rows every SIM_SAMPLING_STEP steps into
+        md_history + md_frames/frame_<i>.cif, a DCD frame every SIM_N_STEPS // TRJ_FRAMES steps, and
+        model/MultiMM_afterMD.cif at the end."""
+        from .dcd import DCDWriter
+        a = self.args
+        n_steps, sampling = int(a.SIM_N_STEPS), max(1, int(a.SIM_SAMPLING_STEP))
+        dcd_every = max(1, n_steps // max(1, int(a.TRJ_FRAMES)))
+        kind = str(a.SIM_INTEGRATOR_TYPE).lower()
+        eng = self.engine
+        eng.md_configure(kind, dt_ps=float(a.SIM_INTEGRATOR_STEP), temperature_K=float(a.SIM_TEMPERATURE),
+                         friction_per_ps=float(a.SIM_FRICTION_COEFF), seed=int(a.SHUFFLING_SEED))
+        # context.setVelocitiesToTemperature(SIM_TEMPERATURE, SHUFFLING_SEED), model.py:878 (the minimizer
+        # leaves velocities alone, so setting them here is equivalent)
+        eng.set_velocities_to_temperature(float(a.SIM_TEMPERATURE), int(a.SHUFFLING_SEED))
+        logger.info("Running relaxation...")
+        t0 = time.time()
+        print("#\"Step\"\t\"Potential Energy (kJ/mole)\"\t\"Kinetic Energy (kJ/mole)\"\t\"Total Energy (kJ/mole)\"\t"
+              "\"Temperature (K)\"")
+        done = 0
+        with DCDWriter(os.path.join(a.OUT_PATH, "metadata", "MultiMM_annealing.dcd"), self.system.n_beads,
+                       float(a.SIM_INTEGRATOR_STEP), first_step=dcd_every, interval=dcd_every) as dcd:
+            for i in range(n_steps // sampling):
+                target = (i + 1) * sampling
+                while done < target:  # stop at every DCD frame boundary inside the sampling window
+                    nxt = min(target, (done // dcd_every + 1) * dcd_every)
+                    st = eng.md_step(nxt - done)
+                    done = nxt
+                    if done % dcd_every == 0:
+                        dcd.write_frame(eng.get_positions())
+                kinetic_T = st.temperature
+                print(f"{done}\t{st.potential}\t{st.kinetic}\t{st.potential + st.kinetic}\t{kinetic_T}")
+                self.md_history["step"].append(int(st.step_count))
+                self.md_history["potential"].append(st.potential)
+                self.md_history["kinetic"].append(st.kinetic)
+                self.md_history["total"].append(st.potential + st.kinetic)
+                # model.py:959-972: integrator.getTemperature() (the bath set point) when the integrator has
+                # one, else 2K / (3 N kB)
+                self.md_history["temperature"].append(float(a.SIM_TEMPERATURE) if kind != "verlet" else kinetic_T)
+                self.state_positions = eng.get_positions().astype(np.float64)
+                cif.write_structure(os.path.join(a.OUT_PATH, "md_frames", f"frame_{i + 1}.cif"),
+                                    self.state_positions, self.chr_ends)
+        self.state_positions = eng.get_positions().astype(np.float64)
+        cif.write_structure(os.path.join(a.OUT_PATH, "model", "MultiMM_afterMD.cif"), self.state_positions,
+                            self.chr_ends)
+        dt = time.time() - t0
+        logger.info("MD finished: %d steps in %.2f s (%.0f steps/s)", done, dt, done / max(dt, 1e-9))
+
     # --- model.py:1216-1248 ---------------------------------------------------------------------------
     def run(self):
         self.set_radiuses()
@@ -138,5 +189,5 @@ class MultiMM:
         if self.args.LOC_START is None:
             self.save_chromosomes()
         if self.args.SIM_RUN_MD:
-            logger.warning("SIM_RUN_MD is set but MD is outside the MI355X path (SURVEY.md section 2, row 8): skipped")
+            self.run_md()
         return self.stats

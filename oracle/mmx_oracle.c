@@ -589,3 +589,127 @@ done:
     free(buf);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Molecular dynamics: the integrators model.py:768-808 constructs, advanced by
+ * simulation.step(n), model.py:931.  Restates OpenMM 8.5.1's leap-frog update rules for a system
+ * without constraints [upstream: ReferenceStochasticDynamics / ReferenceVerletDynamics /
+ * ReferenceBrownianDynamics]:
+ *   langevin : v' = a v + (1-a)/gamma F/m + sqrt(kT (1-a^2)/m) N(0,1), a = exp(-gamma dt); x' = x + v' dt
+ *   verlet   : v' = v + dt F/m;                                                            x' = x + v' dt
+ *   brownian : x' = x + dt/(gamma m) F + sqrt(2 kT dt/(gamma m)) N(0,1);                   v' = (x'-x)/dt
+ * Noise: Philox4x32-10 (Salmon et al., SC'11) with key = seed and counter = {bead, step_lo, step_hi,
+ * stream}; three normals per block by Box-Muller on 24-bit uniforms.  OpenMM's own generator is not
+ * reproduced: MD parity with OpenMM would be statistical only; the HIP path is compared with THIS
+ * restatement, which uses the same generator.
+ * ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_normal3(uint32_t bead, uint64_t step, uint32_t stream, uint64_t seed, double z[3]) {
+    const uint32_t ctr[4] = {bead, (uint32_t)step, (uint32_t)(step >> 32), stream};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t r[4];
+    orc_philox4x32_10(ctr, key, r);
+    const double s = 1.0 / 16777216.0;
+    const double u1 = ((double)(r[0] >> 8) + 0.5) * s, u2 = ((double)(r[1] >> 8) + 0.5) * s;
+    const double u3 = ((double)(r[2] >> 8) + 0.5) * s, u4 = ((double)(r[3] >> 8) + 0.5) * s;
+    const double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
+    z[0] = ra * cos(2.0 * M_PI * u2);
+    z[1] = ra * sin(2.0 * M_PI * u2);
+    z[2] = rb * cos(2.0 * M_PI * u4);
+}
+
+#define ORC_KB 0.008314462618 /* kJ/(mol K), model.py:967 */
+
+/* context.setVelocitiesToTemperature(T, seed), model.py:878 (stream 1, step 0). */
+void orc_md_velocities(int32_t n, double temperature, double mass, uint64_t seed, double *v) {
+    const double sigma = sqrt(ORC_KB * temperature / mass);
+    for (int i = 0; i < n; ++i) {
+        double z[3];
+        orc_normal3((uint32_t)i, 0, 1, seed, z);
+        for (int q = 0; q < 3; ++q) v[3 * i + q] = sigma * z[q];
+    }
+}
+
+typedef struct {
+    int64_t step_count;
+    double potential, kinetic, temperature;
+    double eterms[ORC_N_TERMS];
+} orc_md_stats;
+
+/* kind: 0 langevin, 1 verlet, 2 brownian.  Advances (x, v) by n_steps starting at step index step0 and
+ * reports the energies at the final point the way OpenMM does (kinetic energy of velocities shifted by
+ * half a step for the leap-frog integrators, unshifted for brownian).  Returns 0 / -1. */
+int orc_md_step(const orc_system *s, int kind, double dt, double temperature, double friction, double mass,
+                uint64_t seed, int64_t step0, int32_t n_steps, double *x, double *v, orc_md_stats *st) {
+    const int n = s->n;
+    double *F = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    if (!F) return -1;
+    double et[ORC_N_TERMS];
+    const double kT = ORC_KB * temperature;
+    const double a = exp(-friction * dt);
+    double fscale, noise;
+    if (kind == 0) {
+        fscale = (friction > 0.0 ? (1.0 - a) / friction : dt) / mass;
+        noise = sqrt(kT * (1.0 - a * a) / mass);
+    } else if (kind == 1) {
+        fscale = dt / mass;
+        noise = 0.0;
+    } else {
+        fscale = dt / (friction * mass);
+        noise = sqrt(2.0 * kT * dt / (friction * mass));
+    }
+    if (orc_eval(s, x, F, et) != 0) { free(F); return -1; }
+    for (int32_t k = 0; k < n_steps; ++k) {
+        const uint64_t step = (uint64_t)(step0 + k);
+        for (int i = 0; i < n; ++i) {
+            double z[3] = {0.0, 0.0, 0.0};
+            if (kind != 1) orc_normal3((uint32_t)i, step, 0, seed, z);
+            for (int q = 0; q < 3; ++q) {
+                const int64_t c = 3 * (int64_t)i + q;
+                if (kind == 0) {
+                    v[c] = a * v[c] + fscale * F[c] + noise * z[q];
+                    x[c] += v[c] * dt;
+                } else if (kind == 1) {
+                    v[c] += fscale * F[c];
+                    x[c] += v[c] * dt;
+                } else {
+                    const double dx = fscale * F[c] + noise * z[q];
+                    x[c] += dx;
+                    v[c] = dx / dt;
+                }
+            }
+        }
+        if (orc_eval(s, x, F, et) != 0) { free(F); return -1; }
+    }
+    if (st) {
+        const double shift = kind == 2 ? 0.0 : 0.5 * dt;
+        double ke = 0.0, pot = 0.0;
+        for (int64_t c = 0; c < 3 * (int64_t)n; ++c) {
+            const double w = v[c] + shift * F[c] / mass;
+            ke += w * w;
+        }
+        ke *= 0.5 * mass;
+        for (int t = 0; t < ORC_N_TERMS; ++t) {
+            st->eterms[t] = et[t];
+            pot += et[t];
+        }
+        st->step_count = step0 + n_steps;
+        st->potential = pot;
+        st->kinetic = ke;
+        st->temperature = 2.0 * ke / (3.0 * (double)n * ORC_KB);
+    }
+    free(F);
+    return 0;
+}

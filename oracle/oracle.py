@@ -43,6 +43,14 @@ class OrcMinStats(C.Structure):
                 ("xnorm_final", C.c_double), ("seconds", C.c_double)]
 
 
+class OrcMdStats(C.Structure):
+    _fields_ = [("step_count", C.c_int64), ("potential", C.c_double), ("kinetic", C.c_double),
+                ("temperature", C.c_double), ("eterms", C.c_double * N_TERMS)]
+
+
+MD_KINDS = {"langevin": 0, "verlet": 1, "brownian": 2}
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "mmx_oracle.c")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
@@ -64,6 +72,12 @@ def lib() -> C.CDLL:
         _lib.orc_minimize.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_double, C.c_int, C.POINTER(OrcMinStats)]
         _lib.orc_hilbert_points.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_backbone_flags.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        _lib.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_normal3.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
+        _lib.orc_md_velocities.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_void_p]
+        _lib.orc_md_step.restype = C.c_int
+        _lib.orc_md_step.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(OrcMdStats)]
         assert _lib.orc_sizeof_system() == C.sizeof(OrcSystem), "OrcSystem layout mismatch"
     return _lib
 
@@ -163,6 +177,40 @@ class Oracle:
         if rc != 0:
             raise MemoryError("oracle allocation failed")
         return x, st
+
+
+    def md_step(self, x, v, n_steps, kind="langevin", dt=0.001, temperature=310.0, friction=0.5,
+                mass=16427.889, seed=0, step0=0):
+        """Advances copies of (x, v) by n_steps of the named integrator; returns (x, v, OrcMdStats)."""
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.s.n_beads, 3)).copy()
+        v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(self.s.n_beads, 3)).copy()
+        st = OrcMdStats()
+        rc = lib().orc_md_step(C.byref(self.o), MD_KINDS[kind], float(dt), float(temperature), float(friction),
+                               float(mass), int(seed), int(step0), int(n_steps), x.ctypes.data, v.ctypes.data,
+                               C.byref(st))
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+        return x, v, st
+
+
+def philox4x32_10(counter, key) -> np.ndarray:
+    c = np.ascontiguousarray(counter, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def normal3(bead: int, step: int, stream: int, seed: int) -> np.ndarray:
+    out = np.zeros(3)
+    lib().orc_normal3(bead, step, stream, seed, out.ctypes.data)
+    return out
+
+
+def md_velocities(n: int, temperature: float, mass: float, seed: int) -> np.ndarray:
+    v = np.zeros((n, 3))
+    lib().orc_md_velocities(n, float(temperature), float(mass), int(seed), v.ctypes.data)
+    return v
 
 
 def hilbert_points_c(n_points: int, p: int = 8, n: int = 3) -> np.ndarray:

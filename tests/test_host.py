@@ -93,3 +93,41 @@ def test_multimm_plumbing_until_the_engine(tmp_path):
             m.add_forcefield()
     with pytest.raises(ValueError):
         MultiMM(load_config(dict(PLATFORM="CUDA", N_BEADS=10, OUT_PATH=str(tmp_path / "o2"))))
+
+
+def test_md_config_keys_and_presets():
+    """SIM_* keys of config.py:252-267 (Quantity strings reduce to ps / K), REGION preset turns MD on (run.py:171)."""
+    from multimm_amd.config import load_config
+    c = load_config({"MODELLING_LEVEL": "region", "SIM_INTEGRATOR_STEP": "2 femtosecond", "SIM_TEMPERATURE": "300 kelvin",
+                     "SIM_N_STEPS": "500", "SIM_FRICTION_COEFF": "0.1", "TRJ_FRAMES": "50",
+                     "SIM_INTEGRATOR_TYPE": "brownian"})
+    assert c.SIM_RUN_MD and abs(c.SIM_INTEGRATOR_STEP - 0.002) < 1e-15 and c.SIM_TEMPERATURE == 300.0
+    assert (c.SIM_N_STEPS, c.TRJ_FRAMES, c.SIM_FRICTION_COEFF, c.SIM_INTEGRATOR_TYPE) == (500, 50, 0.1, "brownian")
+    d = load_config({"MODELLING_LEVEL": "gw"})
+    assert not d.SIM_RUN_MD
+    assert (d.SIM_N_STEPS, d.SIM_SAMPLING_STEP, d.SIM_INTEGRATOR_TYPE, d.SIM_INTEGRATOR_STEP, d.SIM_FRICTION_COEFF,
+            d.SIM_TEMPERATURE, d.TRJ_FRAMES) == (10000, 100, "langevin", 0.001, 0.5, 310.0, 2000)
+
+
+def test_dcd_layout_and_round_trip(tmp_path):
+    """CHARMM DCD as OpenMM's DCDReporter writes it for a non-periodic system: 84-byte CORD record with the
+    frame count at offset 8 and the last step at offset 20 (patched per frame), two 80-char titles, atom count,
+    then x / y / z float32 records in Angstrom."""
+    import struct
+    from multimm_amd.dcd import DCDWriter, read_dcd
+    p = str(tmp_path / "t.dcd")
+    x = np.random.default_rng(0).random((3, 7, 3)) * 5.0
+    with DCDWriter(p, 7, 0.001, first_step=5, interval=5) as w:
+        for f in x:
+            w.write_frame(f)
+    raw = open(p, "rb").read()
+    assert len(raw) == 92 + 172 + 12 + 3 * 3 * (8 + 4 * 7) == 276 + 324
+    assert struct.unpack_from("<i4s3i", raw, 0) == (84, b"CORD", 3, 5, 5)
+    assert struct.unpack_from("<i", raw, 20)[0] == 20
+    assert struct.unpack_from("<3i", raw, 84) == (24, 84, 164) and struct.unpack_from("<i", raw, 96)[0] == 2
+    assert struct.unpack_from("<3i", raw, 264) == (4, 7, 4)
+    first_x = np.frombuffer(raw, "<f4", 7, 280)
+    assert np.allclose(first_x, x[0][:, 0] * 10.0, rtol=1e-6)
+    r = read_dcd(p)
+    assert (r["n_frames"], r["n_atoms"], r["first_step"], r["interval"], r["last_step"]) == (3, 7, 5, 5, 20)
+    assert abs(r["dt_ps"] - 0.001) < 1e-9 and np.abs(r["frames_nm"] - x).max() < 1e-6

@@ -160,3 +160,59 @@ def test_lbfgs_restatement_converges(oracle_lib):
     # fixed iteration budget is honoured exactly
     _, st2 = orc.minimize(tolerance=0.0, max_iters=7)
     assert st2.iterations == 7 and st2.status == 1 and st2.evaluations >= 8
+
+
+# ---- MD restatement -------------------------------------------------------------------
+def test_philox_known_answers():
+    """Philox4x32-10 against the three known-answer vectors published with Random123 (kat_vectors):
+    zero counter/key, all-ones, and the digits-of-pi vector."""
+    from oracle.oracle import philox4x32_10
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        assert [int(v) for v in philox4x32_10(ctr, key)] == want
+
+
+def test_md_normals_and_initial_velocities():
+    from oracle.oracle import md_velocities, normal3
+    z = np.array([normal3(i, 3, 0, 99) for i in range(20000)])
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and abs(z.var() - 1.0) < 4 * np.sqrt(2.0 / z.size)
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.03 and abs(np.corrcoef(z[:-1, 2], z[1:, 2])[0, 1]) < 0.03
+    assert not np.array_equal(normal3(5, 3, 0, 99), normal3(5, 4, 0, 99))
+    v = md_velocities(30000, 310.0, 16427.889, 1)
+    kT_over_m = 0.008314462618 * 310.0 / 16427.889
+    assert abs(v.var() / kT_over_m - 1.0) < 4 * np.sqrt(2.0 / v.size)
+
+
+def test_md_integrators_basic_properties():
+    """Verlet: energy conserved and time-reversible; Langevin with zero friction and temperature == Verlet;
+    Brownian at T = 0 is steepest descent (energy decreases)."""
+    from oracle.oracle import Oracle, md_velocities
+    s = synthetic_system("region_5k", n_beads=300, jitter=0.01, seed=1)
+    orc = Oracle(s)
+    x0, _ = orc.minimize(tolerance=0.0, max_iters=200)
+    v0 = md_velocities(s.n_beads, 310.0, 16427.889, 2)
+    kw = dict(dt=0.005, mass=16427.889)
+    x1, v1, st1 = orc.md_step(x0, v0, 200, kind="verlet", **kw)
+    _, _, st0 = orc.md_step(x0, v0, 0, kind="verlet", **kw)
+    e0, e1 = st0.potential + st0.kinetic, st1.potential + st1.kinetic
+    assert abs(e1 - e0) < 2e-3 * st0.kinetic, (e0, e1, st0.kinetic)
+    assert st1.step_count == 200
+    # leap-frog reversibility: the stored velocity is v_{n-1/2}; restarting from (x_n, -v_{n+1/2}) retraces
+    # the positions exactly (to rounding), so 200 steps later the start is recovered
+    orc64 = Oracle(s, as_float32_inputs=False)
+    xa, va, _ = orc64.md_step(x0, v0, 200, kind="verlet", **kw)
+    _, Fa = orc64.eval(xa)
+    xb, _, _ = orc64.md_step(xa, -(va + kw["dt"] * Fa / kw["mass"]), 200, kind="verlet", **kw)
+    assert np.abs(xb - x0).max() < 1e-9
+    xl, vl, _ = orc.md_step(x0, v0, 50, kind="langevin", temperature=0.0, friction=0.0, **kw)
+    xv, vv, _ = orc.md_step(x0, v0, 50, kind="verlet", **kw)
+    assert np.allclose(xl, xv, atol=1e-12) and np.allclose(vl, vv, atol=1e-12)
+    _, _, sb0 = orc.md_step(s.positions, 0 * v0, 0, kind="brownian", temperature=0.0, friction=50.0, **kw)
+    _, _, sb1 = orc.md_step(s.positions, 0 * v0, 20, kind="brownian", temperature=0.0, friction=50.0, dt=1e-4,
+                            mass=16427.889)
+    assert sb1.potential < sb0.potential
