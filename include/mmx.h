@@ -150,6 +150,26 @@ int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], cons
  * one chromosome must be contiguous (they are: model.py:158-162 assigns by chr_ends ranges).  The
  * potential grows with r, so there is no cutoff: every pair inside a chromosome is evaluated. */
 int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom);
+/* ---- alternative functional forms (the *_FORCE_TYPE ini keys, config.py:269-312) -----
+ * form 0 is the default the mmx_set_* call of the term documents; the others follow model.py:
+ *   MMX_SEL_EV       1 gaussian_core   eps*exp(-r^2/(2 sigma^2))                                  :205-209
+ *   MMX_SEL_COB/SCB  1 yukawa          -E*exp(-r/r_comp)/r          2 theta  -E*step(r_comp - r)    :262-288, 340-377
+ *   MMX_SEL_CHB      1 gaussian        -dE*exp(-k_C r^2)            2 saturating  -dE/(1+k_C r^2)   :424-443
+ *   MMX_SEL_LAMINA   1 gaussian_shell  2 harmonic_shell  3 logistic_shell                          :508-539
+ *   MMX_SEL_CENTRAL  1 gaussian        2 logistic                                                  :588-612
+ *   MMX_SEL_LOOPS    1 fene_soft       2 gaussian_tether                                           :662-701
+ * The COB yukawa expression of the reference reads the label of particle 1 twice (model.py:266-267), i.e. it is
+ * not symmetric in the pair; the lower bead index is taken as particle 1 (OpenMM Reference platform order). */
+#define MMX_SEL_EV 0
+#define MMX_SEL_COB 1
+#define MMX_SEL_SCB 2
+#define MMX_SEL_CHB 3
+#define MMX_SEL_LAMINA 4
+#define MMX_SEL_CENTRAL 5
+#define MMX_SEL_LOOPS 6
+#define MMX_N_SELECTORS 7
+int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form);
+
 /* Removes a term again (term = MMX_T_*). */
 int mmx_disable_term(mmx_handle h, int32_t term);
 

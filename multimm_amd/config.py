@@ -14,7 +14,7 @@ import re
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
-from .system import ForceFieldParams
+from .system import ForceFieldParams, form_index
 
 _BOOL_TRUE = {"true", "1", "yes", "on"}
 _BOOL_FALSE = {"false", "0", "no", "off", "", "none"}
@@ -131,7 +131,11 @@ def load_config(path_or_dict) -> SimulationConfig:
     for key, val in raw.items():
         if key in _FF_FIELDS:
             cur = getattr(cfg.ff, key)
-            ffkw[key] = parse_bool(val) if isinstance(cur, bool) else parse_quantity(val)
+            if isinstance(cur, str):  # *_FORCE_TYPE: validated like model.py:214-215 ("Unknown EV_FORCE_TYPE: ...")
+                form_index(key, str(val).strip())
+                ffkw[key] = str(val).strip()
+            else:
+                ffkw[key] = parse_bool(val) if isinstance(cur, bool) else parse_quantity(val)
         elif hasattr(cfg, key) and key != "ff":
             cur = getattr(cfg, key)
             sval = None if (isinstance(val, str) and val.strip().lower() in ("", "none")) else val

@@ -128,6 +128,9 @@ struct mmx_handle_s {
     double md_dt = 0.0, md_temp = 0.0, md_friction = 0.0, md_mass = 1.0;
     uint64_t md_seed = 0, md_step = 0;
     MdParams md{};
+    int forms[MMX_N_SELECTORS]{}; // functional form per term selector (0 = default)
+    FormParams Q{};               // derived constants of the non-default forms (host copy)
+    FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
     // options
     int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0;
     // profiling
@@ -194,6 +197,28 @@ void refresh_params(mmx_handle_s *h) {
     for (int i = 0; i < 25; ++i) P.table[i] = (h->has_cob ? h->tab_cob[i] : 0.f) + (h->has_scb ? h->tab_scb[i] : 0.f);
     P.g_inv_rc2 = 1.0f / (h->g_rc * h->g_rc);
     P.g_c2 = (float)(-1.4426950408889634 / (2.0 * (double)h->g_rc * (double)h->g_rc));
+    // alternative functional forms
+    FormParams &Q = h->Q;
+    Q.ev_form = h->forms[MMX_SEL_EV];
+    Q.ev_gc2 = (float)(-1.4426950408889634 / (2.0 * (double)P.ev_sigma * (double)P.ev_sigma));
+    Q.ev_inv_s2 = 1.0f / (P.ev_sigma * P.ev_sigma);
+    Q.has_cob = h->has_cob ? 1 : 0;
+    Q.has_scb = h->has_scb ? 1 : 0;
+    Q.cob_form = h->forms[MMX_SEL_COB];
+    Q.scb_form = h->forms[MMX_SEL_SCB];
+    for (int i = 0; i < 25; ++i) {
+        Q.tab_cob[i] = h->has_cob ? h->tab_cob[i] : 0.f;
+        Q.tab_scb[i] = h->has_scb ? h->tab_scb[i] : 0.f;
+    }
+    for (int l = 0; l < 5; ++l) Q.cob_a[l] = Q.tab_cob[l * 5 + l];
+    Q.g_rcomp = h->g_rc;
+    Q.g_yuk = (float)(-1.4426950408889634 / (double)h->g_rc);
+    Q.lam_form = h->forms[MMX_SEL_LAMINA];
+    Q.cf_form = h->forms[MMX_SEL_CENTRAL];
+    Q.loop_form = h->forms[MMX_SEL_LOOPS];
+    Q.chb_form = h->forms[MMX_SEL_CHB];
+    Q.generic_pairs = ((P.use_ev && Q.ev_form != 0) || (h->has_cob && Q.cob_form != 0) ||
+                       (h->has_scb && Q.scb_form != 0)) ? 1 : 0;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
@@ -237,7 +262,11 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
                        h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part)
 #define NBC(EV, GA)                                                                                         \
     do {                                                                                                    \
-        if (h->nb_variant == 1)                                                                             \
+        if (h->Q.generic_pairs) { /* non-default functional forms: one generic instance per term combination */ \
+            hipLaunchKernelGGL((k_nb_clusters_j<0, EV, GA, false, 14, true>), dim3(grid), dim3(256), 0,       \
+                               h->stream, P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g,  \
+                               h->part, h->formp);                                                          \
+        } else if (h->nb_variant == 1)                                                                      \
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
         else if (!(EV && GA) || P.ev_rc2 == P.g_rc2) {                                                      \
@@ -268,8 +297,14 @@ void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
     const FFParams &P = h->P;
     dim3 b(256), gdim((h->n + 255) / 256, h->ap_slices);
 #define NBA(EV, GA)                                                                                         \
-    hipLaunchKernelGGL((k_nb_allpairs<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4, tiles_per_slice,   \
-                       h->fpart, h->epart, h->st)
+    do {                                                                                                    \
+        if (h->Q.generic_pairs)                                                                             \
+            hipLaunchKernelGGL((k_nb_allpairs<0, EV, GA, true>), gdim, b, 0, h->stream, P, h->pos4,          \
+                               tiles_per_slice, h->fpart, h->epart, h->st, h->formp);                       \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_nb_allpairs<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4,            \
+                               tiles_per_slice, h->fpart, h->epart, h->st);                                 \
+    } while (0)
     if (P.use_ev && P.use_gauss) NBA(true, true);
     else if (P.use_ev) NBA(true, false);
     else NBA(false, true);
@@ -392,7 +427,7 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
         const int gl = std::min((h->n_rows + 255) / 256, 1024);
         on = prof_begin(h, MMX_K_LOOPS, ep);
         hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
-                           h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st);
+                           h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
         prof_end(h, on, ep);
         A.nblk[P_LOOP] = gl;
     }
@@ -400,13 +435,13 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
         const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
         on = prof_begin(h, MMX_K_CHB, ep);
         hipLaunchKernelGGL(k_chb, dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,
-                           h->chrom_hi, h->g, h->part, h->st);
+                           h->chrom_hi, h->g, h->part, h->st, h->Q.chb_form);
         prof_end(h, on, ep);
         A.nblk[P_CHB] = std::min(gc, kPartStride);
     }
     on = prof_begin(h, MMX_K_CONFINE, ep);
     hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
-                       h->part, h->st);
+                       h->part, h->st, h->Q.lam_form, h->Q.cf_form);
     prof_end(h, on, ep);
     A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
 
@@ -486,8 +521,15 @@ int prepare(mmx_handle_s *h) {
     refresh_params(h);
     if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
         return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
+    if (h->Q.generic_pairs && h->nb_variant == 1 && has_nb(h) && !all_pairs(h))
+        return fail(h, MMX_ERR_STATE, "nb_variant 1 only implements the default functional forms");
     int rc = ensure_allpairs_scratch(h);
     if (rc) return rc;
+    if (h->Q.generic_pairs) {
+        if (!h->formp) HIPCHK(h, dalloc(&h->formp, (size_t)1));
+        HIPCHK(h, hipMemcpyAsync(h->formp, &h->Q, sizeof(FormParams), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // h->Q is pageable host memory that may change afterwards
+    }
     if (h->xg && h->pos4_dirty) { // ghosts of the first evaluation come from the host-set global positions
         hipLaunchKernelGGL(k_fill_pos4_all, dim3((h->n_all + 255) / 256), dim3(256), 0, h->stream, h->n, h->n_all,
                            h->xg, h->labels, h->pos4);
@@ -648,7 +690,7 @@ int mmx_destroy(mmx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
-    for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out})
+    for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
@@ -942,6 +984,16 @@ int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t 
     h->P.use_chb = 1;
     h->P.chb_kc = k_C;
     h->P.chb_de = dE;
+    return MMX_OK;
+}
+
+int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form) {
+    if (!h) return MMX_ERR_BAD_ARG;
+    h->md_forces_valid = false;
+    static const int n_forms[MMX_N_SELECTORS] = {2, 3, 3, 3, 4, 3, 3}; // EV, COB, SCB, CHB, LAMINA, CENTRAL, LOOPS
+    if (selector < 0 || selector >= MMX_N_SELECTORS) return fail(h, MMX_ERR_BAD_ARG, "unknown term selector");
+    if (form < 0 || form >= n_forms[selector]) return fail(h, MMX_ERR_BAD_ARG, "unknown functional form for this term");
+    h->forms[selector] = form;
     return MMX_OK;
 }
 
@@ -1286,12 +1338,12 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             if (h->n_rows <= 0) break;
             hipLaunchKernelGGL(k_loops, dim3(std::min((h->n_rows + 255) / 256, 1024)), dim3(256), 0, h->stream, h->P,
                                h->n_rows, h->pos4, h->row_bead, h->row_start, h->partner, h->loop_r0, h->g, h->part,
-                               h->st);
+                               h->st, h->Q.loop_form);
             bytes = 64.0 * h->n_loops;
             break;
         case MMX_K_CONFINE:
             hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g,
-                               h->d, h->part, h->st);
+                               h->d, h->part, h->st, h->Q.lam_form, h->Q.cf_form);
             bytes = 25.0 * h->n;
             break;
         }

@@ -31,6 +31,33 @@ __device__ __forceinline__ float bond_grad(F3 pi, F3 pj, float r0, float k, floa
     return 0.5f * k * dr * dr;
 }
 
+// Loop restraint with the alternative forms of add_loops (model.py:662-701); form 0 = the harmonic default.
+//   1 fene_soft        E = k u^2/(1 + u^2/r0^2)          dE/du = 2 k u/(1 + u^2/r0^2)^2      (u = r - r0)
+//   2 gaussian_tether  E = k (1 - exp(-u^2/sigma^2))     dE/du = 2 k u/sigma^2 exp(-u^2/sigma^2), sigma = r0/2
+__device__ __forceinline__ float loop_grad(int form, F3 pi, F3 pj, float r0, float k, float &gx, float &gy, float &gz) {
+    if (form == 0) return bond_grad(pi, pj, r0, k, gx, gy, gz);
+    const F3 d = sub(pi, pj);
+    const float r2 = dot(d, d);
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    const float u = r2 * rinv - r0, u2 = u * u;
+    float E, dEdu;
+    if (form == 1) {
+        const float den = __builtin_amdgcn_rcpf(fmaf(u2, __builtin_amdgcn_rcpf(r0 * r0), 1.f));
+        E = k * u2 * den;
+        dEdu = 2.f * k * u * den * den;
+    } else {
+        const float is2 = 4.f * __builtin_amdgcn_rcpf(r0 * r0);
+        const float ex = __builtin_amdgcn_exp2f(-1.44269504f * u2 * is2);
+        E = k * (1.f - ex);
+        dEdu = 2.f * k * u * is2 * ex;
+    }
+    const float s = dEdu * rinv;
+    gx = fmaf(s, d.x, gx);
+    gy = fmaf(s, d.y, gy);
+    gz = fmaf(s, d.z, gz);
+    return E;
+}
+
 // HarmonicAngleForce E = 1/2 k (theta-theta0)^2, theta at the middle bead.  OpenMM force form:
 // a = x_i-x_j, b = x_k-x_j, c = a x b (|c| clamped >= 1e-6),
 //   F_i = -dEdth*(a x c)/(|a|^2|c|), F_k = -dEdth*(c x b)/(|b|^2|c|), F_j = -(F_i+F_k).   model.py:708-720.
@@ -117,7 +144,7 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
                                                const int *__restrict__ row_bead, const int *__restrict__ row_start,
                                                const int *__restrict__ partner, const float *__restrict__ r0,
                                                float *__restrict__ g, double *__restrict__ part,
-                                               const MinState *__restrict__ st) {
+                                               const MinState *__restrict__ st, const int loop_form) {
     if (st->phase == PH_DONE) return;
     __shared__ double s_w[4];
     double e = 0.0;
@@ -126,7 +153,7 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
         const F3 pb = f3(pos4[b]);
         float gx = 0.f, gy = 0.f, gz = 0.f;
         for (int q = row_start[r]; q < row_start[r + 1]; ++q)
-            e += 0.5 * (double)bond_grad(pb, f3(pos4[partner[q]]), r0[q], P.loop_k, gx, gy, gz);
+            e += 0.5 * (double)loop_grad(loop_form, pb, f3(pos4[partner[q]]), r0[q], P.loop_k, gx, gy, gz);
         g[3 * (b - P.own_lo)] += gx;
         g[3 * (b - P.own_lo) + 1] += gy;
         g[3 * (b - P.own_lo) + 2] += gz;
@@ -143,7 +170,8 @@ template <bool DOTS>
 __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 *__restrict__ pos4,
                                                  const float *__restrict__ cf_w, float *__restrict__ g,
                                                  const float *__restrict__ d, double *__restrict__ part,
-                                                 const MinState *__restrict__ st) {
+                                                 const MinState *__restrict__ st, const int lam_form,
+                                                 const int cf_form) {
     if (st->phase == PH_DONE) return;
     __shared__ double s_w[4];
     double ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
@@ -165,18 +193,50 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
             if (P.use_lamina) {
                 const int s = (__float_as_int(p.w) & 7) - 2;
                 if (s < 0) {
-                    const float w = 3.14159265358979f / (P.ibl_R2 - P.ibl_R1);
-                    float sn, cs;
-                    sincosf(w * (r - P.ibl_R1), &sn, &cs);
-                    const float s2 = sn * sn, s4 = s2 * s2;
-                    el += (double)(P.ibl_B * (s4 * s4 - 1.f));
-                    dEdr += P.ibl_B * 8.f * s4 * s2 * sn * cs * w;
+                    const float span = P.ibl_R2 - P.ibl_R1;
+                    if (lam_form == 0) { // sin^8 shell, model.py:503-505
+                        const float w = 3.14159265358979f / span;
+                        float sn, cs;
+                        sincosf(w * (r - P.ibl_R1), &sn, &cs);
+                        const float s2 = sn * sn, s4 = s2 * s2;
+                        el += (double)(P.ibl_B * (s4 * s4 - 1.f));
+                        dEdr += P.ibl_B * 8.f * s4 * s2 * sn * cs * w;
+                    } else if (lam_form == 1) { // gaussian_shell, sigma = 0.1 (R2-R1), model.py:511-518
+                        const float is2 = 100.f / (span * span);
+                        const float a = r - P.ibl_R1, b = r - P.ibl_R2;
+                        const float e1 = __expf(-0.5f * a * a * is2), e2 = __expf(-0.5f * b * b * is2);
+                        el += (double)(-P.ibl_B * (e1 + e2));
+                        dEdr += P.ibl_B * is2 * (a * e1 + b * e2);
+                    } else if (lam_form == 2) { // harmonic_shell, r0 = (R1+R2)/2, model.py:521-528
+                        const float u = r - 0.5f * (P.ibl_R1 + P.ibl_R2);
+                        el += (double)(P.ibl_B * u * u);
+                        dEdr += 2.f * P.ibl_B * u;
+                    } else { // logistic_shell, lambda = 0.05 (R2-R1), model.py:531-539
+                        const float il = 20.f / span;
+                        const float a = 1.f / (1.f + __expf((r - P.ibl_R2) * il));
+                        const float b = 1.f / (1.f + __expf(-(r - P.ibl_R1) * il));
+                        el += (double)(-P.ibl_B * (a + b));
+                        dEdr += -P.ibl_B * il * (b * (1.f - b) - a * (1.f - a));
+                    }
                 }
             }
             if (P.use_central) {
-                const float q = r - P.cf_R1, gw = P.cf_G * cf_w[P.own_lo + i];
-                ef += (double)(gw * q * q);
-                dEdr += 2.f * gw * q;
+                const float gw = P.cf_G * cf_w[P.own_lo + i];
+                if (cf_form == 0) { // harmonic, model.py:579-586
+                    const float q = r - P.cf_R1;
+                    ef += (double)(gw * q * q);
+                    dEdr += 2.f * gw * q;
+                } else if (cf_form == 1) { // gaussian, sigma = R1/2, model.py:591-599
+                    const float is2 = 4.f / (P.cf_R1 * P.cf_R1);
+                    const float e1 = __expf(-0.5f * r2 * is2);
+                    ef += (double)(-gw * e1);
+                    dEdr += gw * r * is2 * e1;
+                } else { // logistic, lambda = 0.2 R1, model.py:604-612
+                    const float il = 5.f / P.cf_R1;
+                    const float a = 1.f / (1.f + __expf((r - P.cf_R1) * il));
+                    ef += (double)(-gw * a);
+                    dEdr += gw * il * a * (1.f - a);
+                }
             }
             const float s = dEdr * rinv; // r == 0 => (dx,dy,dz) == 0 => zero gradient
             gx = fmaf(s, dx, gx);
@@ -221,7 +281,8 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
 __global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__restrict__ pos4,
                                              const int *__restrict__ chrom_of, const int *__restrict__ chrom_lo,
                                              const int *__restrict__ chrom_hi, float *__restrict__ g,
-                                             double *__restrict__ part, const MinState *__restrict__ st) {
+                                             double *__restrict__ part, const MinState *__restrict__ st,
+                                             const int chb_form) {
     if (st->phase == PH_DONE) return;
     __shared__ float4 s_tile[256];
     __shared__ int s_chr[256];
@@ -249,9 +310,23 @@ __global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__r
             const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
             const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
             const float r = __builtin_amdgcn_sqrtf(r2);
-            const float m = (s_chr[t] == ci) ? P.chb_de : 0.f; // the self pair has r = 0: contributes nothing
-            e = fmaf(m * r2, fmaf(P.chb_kc, r2, 1.f - r), e);
-            const float fs = -m * (fmaf(k4, r2, 2.f) - 3.f * r);
+            float m = (s_chr[t] == ci) ? P.chb_de : 0.f; // the self pair has r = 0: contributes nothing
+            float fs;
+            if (chb_form == 0) { // polynomial, model.py:416-419
+                e = fmaf(m * r2, fmaf(P.chb_kc, r2, 1.f - r), e);
+                fs = -m * (fmaf(k4, r2, 2.f) - 3.f * r);
+            } else {
+                m = (jb + t == i) ? 0.f : m; // these forms are non-zero at r = 0: drop the self pair explicitly
+                if (chb_form == 1) { // gaussian: -dE exp(-k_C r^2), model.py:428-431
+                    const float ex = m * __expf(-P.chb_kc * r2);
+                    e -= ex;
+                    fs = -2.f * P.chb_kc * ex;
+                } else { // saturating: -dE/(1 + k_C r^2), model.py:440-443
+                    const float den = 1.f / fmaf(P.chb_kc, r2, 1.f);
+                    e -= m * den;
+                    fs = -2.f * P.chb_kc * m * den * den;
+                }
+            }
             fx = fmaf(fs, dx, fx);
             fy = fmaf(fs, dy, fy);
             fz = fmaf(fs, dz, fz);

@@ -53,6 +53,23 @@ struct FFParams {
     float chb_kc, chb_de;
 };
 
+// Alternative functional forms (model.py:173,229,305,395,479,557,648).  0 = the default form.
+// Kept out of FFParams so that the default pair kernel's argument block (and its code) is unaffected.
+struct FormParams {
+    int generic_pairs;      // 1: some pair term uses a non-default form -> the FORMS instances of the pair kernels
+    int ev_form;            // 1 gaussian_core
+    float ev_gc2, ev_inv_s2; // gaussian core: -log2(e)/(2 sigma^2), 1/sigma^2
+    int has_cob, has_scb, cob_form, scb_form; // 1 yukawa, 2 theta
+    float tab_cob[25], tab_scb[25];           // separate amplitude tables (the default path uses their sum)
+    float cob_a[5];         // COB yukawa: amplitude by the label of ONE bead (the expression reads s1 twice)
+    float g_rcomp;          // r_comp: theta contact radius and yukawa screening length
+    float g_yuk;            // -log2(e)/r_comp
+    int lam_form;           // 1 gaussian_shell, 2 harmonic_shell, 3 logistic_shell
+    int cf_form;            // 1 gaussian, 2 logistic
+    int loop_form;          // 1 fene_soft, 2 gaussian_tether
+    int chb_form;           // 1 gaussian, 2 saturating
+};
+
 // Device-resident minimizer state; mirrored to pinned host memory when polled.
 struct MinState {
     int phase;

@@ -26,14 +26,91 @@ struct PairAcc {
     float fx, fy, fz, eev, eg;
 };
 
+// ---- alternative functional forms of the pair terms ---------------------------------------
+//   EV  gaussian_core  E = eps*exp(-r^2/(2 sigma^2))                       model.py:205-209
+//   COB/SCB yukawa     E = -A*exp(-r/lambda)/r, lambda = r_comp            model.py:262-274, 340-356
+//   COB/SCB theta      E = -A*step(r_comp - r)  (no force)                 model.py:277-288, 359-377
+// The COB yukawa expression reads s1 twice (model.py:266-267): its amplitude depends on ONE bead of the pair,
+// which OpenMM leaves undefined for a CustomNonbondedForce; we follow the Reference platform's evaluation order
+// (particle 1 = the lower bead index).  Coincident beads (r = 0) get no yukawa term (the reference's is -inf).
+// One attraction term of form `form` with amplitude A; returns the energy, adds -dE/dr / r to fs.
+__device__ __forceinline__ float comp_form_term(const FFParams &P, const FormParams &Q, int form, float A, float r2, float r, float rinv,
+                                                float &fs) {
+    if (form == 0) {
+        const float gg = A * __builtin_amdgcn_exp2f(r2 * P.g_c2);
+        fs = fmaf(-gg, P.g_inv_rc2, fs);
+        return -gg;
+    } else if (form == 1) {
+        const float y = r2 > 0.f ? A * __builtin_amdgcn_exp2f(r * Q.g_yuk) * rinv : 0.f;
+        fs = fmaf(-y * rinv, __builtin_amdgcn_rcpf(Q.g_rcomp) + rinv, fs);
+        return -y;
+    }
+    return r <= Q.g_rcomp ? -A : 0.f;
+}
+
+// Generic pair: every form by run-time (wave-uniform) switches.  wi/wj = packed (bead<<3 | label+2) words,
+// tabc/tabs = COB/SCB amplitude tables with row stride `ts`.  in_ev/in_g = cutoff masks (0/1).
+template <bool EV, bool GAUSS>
+__device__ __forceinline__ void pair_generic(const FFParams &P, const FormParams &Q, float r2, int wi, int wj, const float *tabc,
+                                             const float *tabs, int ts, float in_ev, float in_g, float &e_ev,
+                                             float &e_g, float &fs) {
+    const float r2s = r2 + 1e-20f;
+    const float rinv = __builtin_amdgcn_rsqf(r2s);
+    const float r = r2s * rinv;
+    const float notself = wi != wj ? 1.f : 0.f;
+    e_ev = 0.f;
+    e_g = 0.f;
+    fs = 0.f;
+    if (EV) {
+        float E, f1;
+        if (Q.ev_form == 0) {
+            const float u = __builtin_amdgcn_rcpf(r + P.ev_rs);
+            E = P.ev_eps * __builtin_amdgcn_exp2f(P.ev_power * __builtin_amdgcn_logf(P.ev_sigma * u));
+            f1 = P.ev_power * E * u * rinv;
+        } else {
+            E = P.ev_eps * __builtin_amdgcn_exp2f(r2 * Q.ev_gc2);
+            f1 = E * Q.ev_inv_s2;
+        }
+        const float m = in_ev * notself;
+        e_ev = E * m;
+        fs = f1 * m;
+    }
+    if (GAUSS) {
+        const int li = wi & 7, lj = wj & 7;
+        float f2 = 0.f, e2 = 0.f;
+        if (Q.has_cob) {
+            const float A = Q.cob_form == 1 ? Q.cob_a[wi < wj ? li : lj] : tabc[li * ts + lj];
+            e2 += comp_form_term(P, Q, Q.cob_form, A, r2, r, rinv, f2);
+        }
+        if (Q.has_scb) e2 += comp_form_term(P, Q, Q.scb_form, tabs[li * ts + lj], r2, r, rinv, f2);
+        const float m = in_g * notself;
+        e_g = e2 * m;
+        fs = fmaf(f2, m, fs);
+    }
+}
+
 // One (i,j) interaction accumulated on the i side.  `wi`/`wj` are the packed (bead<<3 | label+2) words;
 // equal words mean the same bead (self term skipped).  tab5 points at row s_i of the amplitude table.
-template <int PMODE, bool EV, bool GAUSS>
+template <int PMODE, bool EV, bool GAUSS, bool FORMS = false>
 __device__ __forceinline__ void pair_accum(const FFParams &P, const float4 pi, const int wi, const float4 q,
-                                           const float *tab5, PairAcc &a) {
+                                           const float *tab5, PairAcc &a, const FormParams *Q = nullptr,
+                                           const float *tabc = nullptr, const float *tabs = nullptr) {
     const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
     const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
     const int wj = __float_as_int(q.w);
+    if (FORMS) {
+        if (r2 < P.rc2max && wj != wi) {
+            float e1, e2, fs;
+            pair_generic<EV, GAUSS>(P, *Q, r2, wi, wj, tabc, tabs, 5, r2 < P.ev_rc2 ? 1.f : 0.f,
+                                    r2 < P.g_rc2 ? 1.f : 0.f, e1, e2, fs);
+            a.eev += e1;
+            a.eg += e2;
+            a.fx = fmaf(fs, dx, a.fx);
+            a.fy = fmaf(fs, dy, a.fy);
+            a.fz = fmaf(fs, dz, a.fz);
+        }
+        return;
+    }
     if (r2 < P.rc2max && wj != wi) {
         const float r2s = fmaxf(r2, 1e-20f);
         const float rinv = __builtin_amdgcn_rsqf(r2s);
@@ -181,15 +258,18 @@ __device__ __forceinline__ float fma_sat(float a, float b_sgpr, float c) {
 constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
-template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT>
-__global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT, bool FORMS = false>
+__global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
                                                        const int *__restrict__ cstart,
                                                        const GridParams *__restrict__ grid,
                                                        const MinState *__restrict__ st, float *__restrict__ g,
-                                                       double *__restrict__ part) {
+                                                       double *__restrict__ part,
+                                                       const FormParams *__restrict__ Qd = nullptr) {
     if (st->phase == PH_DONE) return;
+    FormParams Q;
+    if (FORMS) Q = *Qd; // uniform loads into scalar registers; the default instances never touch it
     constexpr bool RANK2 = (OPT & 1) != 0;  // amplitude = aA_i*alpha_j + aB_i*beta_j instead of an LDS lookup
     constexpr bool SATMASK = (OPT & 2) != 0; // cutoff by v_fma clamp instead of v_cmp + v_cndmask
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
@@ -198,11 +278,19 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
     __shared__ int s_list[4][kListCap + 72];
     __shared__ float4 s_ring[4][BEADCULL ? 128 : 1];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
+    __shared__ float s_tabc[FORMS ? 40 : 1], s_tabs[FORMS ? 40 : 1]; // COB / SCB tables of the generic forms
     __shared__ double s_e[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 3, slot = lane & 7;
-    if (threadIdx.x < 40)
-        s_tab[threadIdx.x] = (threadIdx.x & 7) < 5 ? P.table[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.f;
+    if (threadIdx.x < 40) {
+        const bool in5 = (threadIdx.x & 7) < 5;
+        const int t5 = (threadIdx.x >> 3) * 5 + (threadIdx.x & 7);
+        s_tab[threadIdx.x] = in5 ? P.table[t5] : 0.f;
+        if (FORMS) {
+            s_tabc[threadIdx.x] = in5 ? Qd->tab_cob[t5] : 0.f;
+            s_tabs[threadIdx.x] = in5 ? Qd->tab_scb[t5] : 0.f;
+        }
+    }
     const GridParams G = *grid;
     const int ncl = st->n_clusters;
     __syncthreads();
@@ -330,6 +418,23 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
                 const int lj = __float_as_int(q.w) & 7;
                 // rank-2 amplitude (compartment blocks only): A(s_i,s_j) = aA_i*alpha_j + aB_i*beta_j
                 const float alpha_j = (lj == 3 || lj == 4) ? 1.f : 0.f, beta_j = (lj == 0 || lj == 1) ? 1.f : 0.f;
+                if (FORMS) { // non-default functional forms: run-time switches, self pair masked (not subtracted)
+                    const int wj = __float_as_int(q.w);
+#pragma unroll
+                    for (int s = 0; s < kCl; ++s) {
+                        const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
+                        const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                        float e1, e2, fs;
+                        pair_generic<EV, GAUSS>(P, Q, r2, wi[s], wj, s_tabc, s_tabs, 8, fma_sat(r2, nbig, cut_ev),
+                                                fma_sat(r2, nbig, cut_g), e1, e2, fs);
+                        ee[0] += e1;
+                        eg[0] += e2;
+                        fx[s] = fmaf(fs, dx, fx[s]);
+                        fy[s] = fmaf(fs, dy, fy[s]);
+                        fz[s] = fmaf(fs, dz, fz[s]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int s = 0; s < kCl; ++s) {
                     const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
@@ -395,7 +500,7 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
         const bool own = bead >= 0;
         if (own) {
             // the self pair (r = 0, zero force) was swept with everything else: remove its energy
-            if (EV) {
+            if (EV && !FORMS) {
                 const float u = __builtin_amdgcn_rcpf(fmaf(1e-20f, __builtin_amdgcn_rsqf(1e-20f), P.ev_rs));
                 if (PMODE == 6) {
                     const float u2 = u * u;
@@ -404,7 +509,7 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
                     tev -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
                 }
             }
-            if (GAUSS) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
+            if (GAUSS && !FORMS) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
             g[3 * (bead - P.own_lo)] = -ofx;
             g[3 * (bead - P.own_lo) + 1] = -ofy;
             g[3 * (bead - P.own_lo) + 2] = -ofz;
@@ -429,14 +534,23 @@ __global__ __launch_bounds__(256, 5) void k_nb_clusters_j(const FFParams P, cons
 // slice; j tiles of 256 beads are staged in LDS and broadcast-read.  Partial forces per slice go to
 // fpart[slice][bead] and are folded in a fixed order by k_nb_allpairs_fold.
 // ------------------------------------------------------------------------------------------------
-template <int PMODE, bool EV, bool GAUSS>
+template <int PMODE, bool EV, bool GAUSS, bool FORMS = false>
 __global__ __launch_bounds__(256) void k_nb_allpairs(const FFParams P, const float4 *__restrict__ pos4, int tiles_per_slice,
                                                      float4 *__restrict__ fpart, float2 *__restrict__ epart,
-                                                     const MinState *__restrict__ st) {
+                                                     const MinState *__restrict__ st,
+                                                     const FormParams *__restrict__ Qd = nullptr) {
     if (st->phase == PH_DONE) return;
     __shared__ float4 s_tile[256];
-    __shared__ float s_tab[32];
-    if (threadIdx.x < 25) s_tab[threadIdx.x] = P.table[threadIdx.x];
+    __shared__ float s_tab[32], s_tabc[FORMS ? 32 : 1], s_tabs[FORMS ? 32 : 1];
+    FormParams Q;
+    if (FORMS) Q = *Qd;
+    if (threadIdx.x < 25) {
+        s_tab[threadIdx.x] = P.table[threadIdx.x];
+        if (FORMS) {
+            s_tabc[threadIdx.x] = Qd->tab_cob[threadIdx.x];
+            s_tabs[threadIdx.x] = Qd->tab_scb[threadIdx.x];
+        }
+    }
     const int n = P.n;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n;
@@ -459,7 +573,7 @@ __global__ __launch_bounds__(256) void k_nb_allpairs(const FFParams P, const flo
 #pragma unroll 4
         for (int t = 0; t < cnt; ++t) {
             const float4 q = s_tile[t];
-            pair_accum<PMODE, EV, GAUSS>(P, pi, wi, q, tab5, a);
+            pair_accum<PMODE, EV, GAUSS, FORMS>(P, pi, wi, q, tab5, a, &Q, s_tabc, s_tabs);
         }
     }
     if (act) {

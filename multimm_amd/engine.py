@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .system import ChromatinSystem
+from .system import FORM_SELECTORS, ChromatinSystem, form_index
 
 N_TERMS = 9
 N_KERNELS = 8
@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmx_set_lamina": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
     "mmx_set_central": (C.c_int, [_P, C.c_float, C.c_float, _P, _P]),
     "mmx_set_chromosomal_blocks": (C.c_int, [_P, C.c_float, C.c_float, _P]),
+    "mmx_set_functional_form": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "mmx_disable_term": (C.c_int, [_P, C.c_int32]),
     "mmx_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "mmx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
@@ -253,6 +254,9 @@ class Engine:
             raise ValueError("chrom must be [N]")
         self._chk(self._lib.mmx_set_chromosomal_blocks(self._h, k_C, dE, c.ctypes.data))
 
+    def set_functional_form(self, selector: int, form: int):
+        self._chk(self._lib.mmx_set_functional_form(self._h, int(selector), int(form)))
+
     def disable_term(self, term: int):
         self._chk(self._lib.mmx_disable_term(self._h, term))
 
@@ -355,6 +359,8 @@ class Engine:
                               ff.POL_USE_HARMONIC_BOND, ff.POL_USE_HARMONIC_ANGLE)
         if ff.LE_USE_HARMONIC_BOND and s.n_loops:
             self.set_loops(s.loop_m, s.loop_n, s.loop_rest_lengths(), ff.LE_HARMONIC_BOND_K)
+        for key, sel in FORM_SELECTORS.items():  # the *_FORCE_TYPE keys (config.py:269-312)
+            self.set_functional_form(sel, form_index(key, getattr(ff, key)))
         return self
 
 

@@ -57,9 +57,39 @@ class ForceFieldParams:
     CHB_USE_CHROMOSOMAL_BLOCKS: bool = False
     CHB_KC: float = 0.3
     CHB_DE: float = 1e-4
+    # Functional forms (config.py:269-312); the first entry of FORM_NAMES[key] is the default
+    EV_FORCE_TYPE: str = "powerlaw"
+    COB_FORCE_TYPE: str = "gaussian"
+    SCB_FORCE_TYPE: str = "gaussian"
+    CHB_FORCE_TYPE: str = "polynomial"
+    BLAMINA_FORCE_TYPE: str = "sin"
+    CENTRAL_FORCE_TYPE: str = "harmonic"
+    LE_LOOP_FORCE_TYPE: str = "harmonic"
     # Engine-only key: pair cutoff in nm.  <= 0 reproduces the reference (OpenMM NoCutoff, all pairs);
     # > 0 is plain truncation (OpenMM CutoffNonPeriodic) and selects the cell-list kernel.
     NB_CUTOFF: float = 0.6
+
+
+# ini key -> (names in the order of mmx_set_functional_form's form index, MMX_SEL_* selector)
+FORM_NAMES = {
+    "EV_FORCE_TYPE": ("powerlaw", "gaussian_core"),
+    "COB_FORCE_TYPE": ("gaussian", "yukawa", "theta"),
+    "SCB_FORCE_TYPE": ("gaussian", "yukawa", "theta"),
+    "CHB_FORCE_TYPE": ("polynomial", "gaussian", "saturating"),
+    "BLAMINA_FORCE_TYPE": ("sin", "gaussian_shell", "harmonic_shell", "logistic_shell"),
+    "CENTRAL_FORCE_TYPE": ("harmonic", "gaussian", "logistic"),
+    "LE_LOOP_FORCE_TYPE": ("harmonic", "fene_soft", "gaussian_tether"),
+}
+FORM_SELECTORS = {"EV_FORCE_TYPE": 0, "COB_FORCE_TYPE": 1, "SCB_FORCE_TYPE": 2, "CHB_FORCE_TYPE": 3,
+                  "BLAMINA_FORCE_TYPE": 4, "CENTRAL_FORCE_TYPE": 5, "LE_LOOP_FORCE_TYPE": 6}
+
+
+def form_index(key: str, name: str) -> int:
+    """Index of a *_FORCE_TYPE value; unknown names raise like the reference does (model.py:214-215 etc.)."""
+    names = FORM_NAMES[key]
+    if str(name) not in names:
+        raise ValueError(f"Unknown {key}: {name}")
+    return names.index(str(name))
 
 
 def set_radiuses(n_beads: int, b0: float) -> tuple[float, float, float]:

@@ -81,6 +81,15 @@ typedef struct {
     int32_t use_chb;
     double chb_kc, chb_de;
     const int32_t *chrom_of; /* [n] chrom_spin: pairs interact iff equal (model.py:416-419) */
+    /* alternative functional forms (the *_FORCE_TYPE keys, config.py:269-312); 0 = the default form */
+    int32_t ev_form;              /* 1 gaussian_core                          model.py:205-209 */
+    int32_t has_cob, has_scb;     /* which tables below are live (their sum is gauss_table) */
+    int32_t cob_form, scb_form;   /* 1 yukawa, 2 theta                        model.py:262-288, 340-377 */
+    double tab_cob[25], tab_scb[25];
+    int32_t chb_form;             /* 1 gaussian, 2 saturating                 model.py:424-443 */
+    int32_t lam_form;             /* 1 gaussian_shell, 2 harmonic_shell, 3 logistic_shell   model.py:508-539 */
+    int32_t cf_form;              /* 1 gaussian, 2 logistic                   model.py:588-612 */
+    int32_t loop_form;            /* 1 fene_soft, 2 gaussian_tether           model.py:662-701 */
 } orc_system;
 
 typedef struct {
@@ -162,22 +171,57 @@ void orc_backbone_flags(int32_t n, const int32_t *chr_ends, int32_t n_ends, uint
  * cutoff (OpenMM CutoffNonPeriodic: pairs with r >= cutoff are skipped, no shift).
  * At r == 0 the direction is undefined: energy is counted, force is zero.
  * ------------------------------------------------------------------------------------------ */
-static inline double pair_terms(const orc_system *s, double r2, int li, int lj, double *e_ev, double *e_g) {
+/* One attraction term in the form `form` (0 gaussian, 1 yukawa, 2 theta) with amplitude A:
+ *   gaussian  -A exp(-r^2/(2 rc^2))          dE/dr = +A r/rc^2 exp(.)
+ *   yukawa    -A exp(-r/lambda)/r, lambda = r_comp (model.py:270,352)   dE/dr = A exp(-r/l) (1/(l r) + 1/r^2)
+ *   theta     -A step(rc - r), step(0) = 1 [upstream: OpenMM step(x) = 0 if x < 0, 1 otherwise]; no force
+ * Coincident beads (r == 0) get no yukawa term (the reference's expression is -inf there). */
+static inline double comp_term(int form, double A, double rc, double r2, double r, double *fs) {
+    if (A == 0.0) return 0.0;
+    if (form == 0) {
+        double inv = 1.0 / (rc * rc);
+        double g = A * exp(-0.5 * r2 * inv);
+        *fs -= g * inv;
+        return -g;
+    }
+    if (form == 1) {
+        if (!(r > 0.0)) return 0.0;
+        double y = A * exp(-r / rc) / r;
+        *fs -= y * (1.0 / rc + 1.0 / r) / r;
+        return -y;
+    }
+    return r <= rc ? -A : 0.0;
+}
+
+/* `i_lower`: bead i has the lower index of the pair.  Only the COB yukawa amplitude needs it: the reference's
+ * expression reads s1 twice (model.py:266-267), so the amplitude depends on ONE bead; OpenMM's Reference platform
+ * evaluates pairs with particle 1 = the lower index, which is what is restated here. */
+static inline double pair_terms(const orc_system *s, double r2, int li, int lj, int i_lower, double *e_ev, double *e_g) {
     double fs = 0.0;
     double r = sqrt(r2);
     if (s->use_ev && (s->ev_cutoff <= 0.0 || r < s->ev_cutoff)) {
-        double u = 1.0 / (r + s->ev_rsmall);
-        double E = s->ev_eps * pow(s->ev_sigma * u, s->ev_power);
-        *e_ev += E;
-        if (r > 0.0) fs += s->ev_power * E * u / r;
+        if (s->ev_form == 0) {
+            double u = 1.0 / (r + s->ev_rsmall);
+            double E = s->ev_eps * pow(s->ev_sigma * u, s->ev_power);
+            *e_ev += E;
+            if (r > 0.0) fs += s->ev_power * E * u / r;
+        } else { /* gaussian_core: eps*exp(-r^2/(2 sigma^2)), model.py:205-209 */
+            double inv = 1.0 / (s->ev_sigma * s->ev_sigma);
+            double E = s->ev_eps * exp(-0.5 * r2 * inv);
+            *e_ev += E;
+            fs += E * inv;
+        }
     }
     if (s->use_gauss && (s->gauss_cutoff <= 0.0 || r < s->gauss_cutoff)) {
-        double Eab = s->gauss_table[li * 5 + lj];
-        if (Eab != 0.0) {
-            double inv = 1.0 / (s->gauss_rc * s->gauss_rc);
-            double g = Eab * exp(-0.5 * r2 * inv);
-            *e_g -= g;
-            fs -= g * inv;
+        if (s->cob_form == 0 && s->scb_form == 0) {
+            *e_g += comp_term(0, s->gauss_table[li * 5 + lj], s->gauss_rc, r2, r, &fs);
+        } else {
+            if (s->has_cob) {
+                int l1 = i_lower ? li : lj;
+                double A = s->cob_form == 1 ? s->tab_cob[l1 * 5 + l1] : s->tab_cob[li * 5 + lj];
+                *e_g += comp_term(s->cob_form, A, s->gauss_rc, r2, r, &fs);
+            }
+            if (s->has_scb) *e_g += comp_term(s->scb_form, s->tab_scb[li * 5 + lj], s->gauss_rc, r2, r, &fs);
         }
     }
     return fs;
@@ -197,7 +241,7 @@ static void nonbonded_allpairs(const orc_system *s, const double *x, double *F, 
             double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
             double r2 = dx * dx + dy * dy + dz * dz;
             const int lj = s->labels ? s->labels[j] + 2 : 2;
-            double fs = pair_terms(s, r2, li, lj, &ev, &eg);
+            double fs = pair_terms(s, r2, li, lj, i < j, &ev, &eg);
             fx += fs * dx;
             fy += fs * dy;
             fz += fs * dz;
@@ -279,7 +323,7 @@ static int nonbonded_cells(const orc_system *s, const double *x, double *F, doub
                     double r2 = dx * dx + dy * dy + dz * dz;
                     if (r2 >= rc * rc) continue;
                     const int lj = s->labels ? s->labels[j] + 2 : 2;
-                    double fs = pair_terms(s, r2, li, lj, &ev, &eg);
+                    double fs = pair_terms(s, r2, li, lj, i < j, &ev, &eg);
                     fx += fs * dx;
                     fy += fs * dy;
                     fz += fs * dz;
@@ -314,8 +358,19 @@ static void chromosomal_blocks(const orc_system *s, const double *x, double *F, 
             if (j == i || s->chrom_of[j] != ci) continue;
             double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
             double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2);
-            ei += s->chb_de * r2 * (s->chb_kc * r2 - r + 1.0);
-            double fs = -s->chb_de * (4.0 * s->chb_kc * r2 - 3.0 * r + 2.0);
+            double fs;
+            if (s->chb_form == 0) {
+                ei += s->chb_de * r2 * (s->chb_kc * r2 - r + 1.0);
+                fs = -s->chb_de * (4.0 * s->chb_kc * r2 - 3.0 * r + 2.0);
+            } else if (s->chb_form == 1) { /* -dE exp(-k_C r^2), model.py:428-431 */
+                double ex = s->chb_de * exp(-s->chb_kc * r2);
+                ei -= ex;
+                fs = -2.0 * s->chb_kc * ex;
+            } else { /* -dE/(1 + k_C r^2), model.py:440-443 */
+                double den = 1.0 / (1.0 + s->chb_kc * r2);
+                ei -= s->chb_de * den;
+                fs = -2.0 * s->chb_kc * s->chb_de * den * den;
+            }
             fx += fs * dx;
             fy += fs * dy;
             fz += fs * dz;
@@ -343,6 +398,35 @@ static inline double harmonic_pair(const double *x, double *F, int i, int j, dou
         F[3 * j + 2] -= fs * dz;
     }
     return 0.5 * k * dr * dr;
+}
+
+/* Loop restraint in the alternative forms of add_loops (CustomBondForce, no 1/2):
+ *   1 fene_soft        k u^2/(1 + alpha u^2), alpha = 1/r0^2        model.py:664-682
+ *   2 gaussian_tether  k (1 - exp(-u^2/sigma^2)), sigma = r0/2      model.py:685-701      (u = r - r0) */
+static inline double loop_pair(int form, const double *x, double *F, int i, int j, double r0, double k) {
+    if (form == 0) return harmonic_pair(x, F, i, j, r0, k);
+    double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double u = r - r0, E, dEdu;
+    if (form == 1) {
+        double alpha = 1.0 / (r0 * r0), den = 1.0 / (1.0 + alpha * u * u);
+        E = k * u * u * den;
+        dEdu = 2.0 * k * u * den * den;
+    } else {
+        double sigma = 0.5 * r0, ex = exp(-u * u / (sigma * sigma));
+        E = k * (1.0 - ex);
+        dEdu = 2.0 * k * u / (sigma * sigma) * ex;
+    }
+    if (r > 0.0) {
+        double fs = -dEdu / r;
+        F[3 * i] += fs * dx;
+        F[3 * i + 1] += fs * dy;
+        F[3 * i + 2] += fs * dz;
+        F[3 * j] -= fs * dx;
+        F[3 * j + 1] -= fs * dy;
+        F[3 * j + 2] -= fs * dz;
+    }
+    return E;
 }
 
 /* HarmonicAngleForce: E = 1/2 k (theta-theta0)^2, theta at the middle bead j of (i,j,k).
@@ -412,7 +496,7 @@ int orc_eval(const orc_system *s, const double *x, double *F_out, double *eterms
                     eterms[ORC_T_ANGLE] += harmonic_angle(x, F, i, i + 1, i + 2, s->angle_theta0, s->angle_k);
     }
     for (int l = 0; l < s->n_loops; ++l)
-        eterms[ORC_T_LOOP] += harmonic_pair(x, F, s->loop_m[l], s->loop_n[l], s->loop_r0[l], s->loop_k);
+        eterms[ORC_T_LOOP] += loop_pair(s->loop_form, x, F, s->loop_m[l], s->loop_n[l], s->loop_r0[l], s->loop_k);
 
     if (s->use_container || s->use_lamina || s->use_central) {
         for (int i = 0; i < n; ++i) {
@@ -424,18 +508,46 @@ int orc_eval(const orc_system *s, const double *x, double *F_out, double *eterms
                 eterms[ORC_T_CONTAINER] += s->sc_C * (o * o + in * in);
                 dEdr += 2.0 * s->sc_C * (o - in);
             }
-            if (s->use_lamina && s->labels && s->labels[i] < 0) { /* model.py:503-505 */
-                double w = M_PI / (s->ibl_R2 - s->ibl_R1);
-                double u = w * (r - s->ibl_R1);
-                double sn = sin(u), cs = cos(u);
-                double s2 = sn * sn, s4 = s2 * s2;
-                eterms[ORC_T_LAMINA] += s->ibl_B * (s4 * s4 - 1.0);
-                dEdr += s->ibl_B * 8.0 * s4 * s2 * sn * cs * w;
+            if (s->use_lamina && s->labels && s->labels[i] < 0) {
+                const double span = s->ibl_R2 - s->ibl_R1;
+                if (s->lam_form == 0) { /* sin^8 shell, model.py:503-505 */
+                    double w = M_PI / span;
+                    double u = w * (r - s->ibl_R1);
+                    double sn = sin(u), cs = cos(u);
+                    double s2 = sn * sn, s4 = s2 * s2;
+                    eterms[ORC_T_LAMINA] += s->ibl_B * (s4 * s4 - 1.0);
+                    dEdr += s->ibl_B * 8.0 * s4 * s2 * sn * cs * w;
+                } else if (s->lam_form == 1) { /* gaussian_shell, sigma = 0.1 (R2-R1), model.py:511-518 */
+                    double sg = 0.1 * span, a = r - s->ibl_R1, b = r - s->ibl_R2;
+                    double e1 = exp(-a * a / (2 * sg * sg)), e2 = exp(-b * b / (2 * sg * sg));
+                    eterms[ORC_T_LAMINA] += -s->ibl_B * (e1 + e2);
+                    dEdr += s->ibl_B * (a * e1 + b * e2) / (sg * sg);
+                } else if (s->lam_form == 2) { /* harmonic_shell, r0 = (R1+R2)/2, model.py:521-528 */
+                    double u = r - 0.5 * (s->ibl_R1 + s->ibl_R2);
+                    eterms[ORC_T_LAMINA] += s->ibl_B * u * u;
+                    dEdr += 2.0 * s->ibl_B * u;
+                } else { /* logistic_shell, lambda = 0.05 (R2-R1), model.py:531-539 */
+                    double lam = 0.05 * span;
+                    double a = 1.0 / (1.0 + exp((r - s->ibl_R2) / lam)), b = 1.0 / (1.0 + exp(-(r - s->ibl_R1) / lam));
+                    eterms[ORC_T_LAMINA] += -s->ibl_B * (a + b);
+                    dEdr += -s->ibl_B * (b * (1.0 - b) - a * (1.0 - a)) / lam;
+                }
             }
-            if (s->use_central && s->cf_w) { /* model.py:584-586 */
-                double q = r - s->cf_R1;
-                eterms[ORC_T_CENTRAL] += s->cf_G * s->cf_w[i] * q * q;
-                dEdr += 2.0 * s->cf_G * s->cf_w[i] * q;
+            if (s->use_central && s->cf_w) {
+                const double gw = s->cf_G * s->cf_w[i];
+                if (s->cf_form == 0) { /* harmonic, model.py:584-586 */
+                    double q = r - s->cf_R1;
+                    eterms[ORC_T_CENTRAL] += gw * q * q;
+                    dEdr += 2.0 * gw * q;
+                } else if (s->cf_form == 1) { /* gaussian, sigma = R1/2, model.py:591-599 */
+                    double sg = 0.5 * s->cf_R1, e1 = exp(-r * r / (2 * sg * sg));
+                    eterms[ORC_T_CENTRAL] += -gw * e1;
+                    dEdr += gw * r / (sg * sg) * e1;
+                } else { /* logistic, lambda = 0.2 R1, model.py:604-612 */
+                    double lam = 0.2 * s->cf_R1, a = 1.0 / (1.0 + exp((r - s->cf_R1) / lam));
+                    eterms[ORC_T_CENTRAL] += -gw * a;
+                    dEdr += gw * a * (1.0 - a) / lam;
+                }
             }
             if (r > 0.0)
                 for (int q = 0; q < 3; ++q) F[3 * i + q] -= dEdr * d[q] / r;

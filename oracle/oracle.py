@@ -34,6 +34,9 @@ class OrcSystem(C.Structure):
         ("use_central", C.c_int32), ("cf_G", C.c_double), ("cf_R1", C.c_double), ("cf_w", C.c_void_p),
         ("centre", C.c_double * 3),
         ("use_chb", C.c_int32), ("chb_kc", C.c_double), ("chb_de", C.c_double), ("chrom_of", C.c_void_p),
+        ("ev_form", C.c_int32), ("has_cob", C.c_int32), ("has_scb", C.c_int32), ("cob_form", C.c_int32),
+        ("scb_form", C.c_int32), ("tab_cob", C.c_double * 25), ("tab_scb", C.c_double * 25),
+        ("chb_form", C.c_int32), ("lam_form", C.c_int32), ("cf_form", C.c_int32), ("loop_form", C.c_int32),
     ]
 
 
@@ -49,6 +52,18 @@ class OrcMdStats(C.Structure):
 
 
 MD_KINDS = {"langevin": 0, "verlet": 1, "brownian": 2}
+
+# Functional forms by ini key, default first (config.py:269-312; branches of model.py:173-215, 229-292, 305-382,
+# 395-449, 479-544, 557-615, 648-703).  The index is what orc_system.*_form holds.
+FORM_NAMES = {
+    "EV_FORCE_TYPE": ("powerlaw", "gaussian_core"),
+    "COB_FORCE_TYPE": ("gaussian", "yukawa", "theta"),
+    "SCB_FORCE_TYPE": ("gaussian", "yukawa", "theta"),
+    "CHB_FORCE_TYPE": ("polynomial", "gaussian", "saturating"),
+    "BLAMINA_FORCE_TYPE": ("sin", "gaussian_shell", "harmonic_shell", "logistic_shell"),
+    "CENTRAL_FORCE_TYPE": ("harmonic", "gaussian", "logistic"),
+    "LE_LOOP_FORCE_TYPE": ("harmonic", "fene_soft", "gaussian_tether"),
+}
 
 
 def build(force: bool = False) -> str:
@@ -143,6 +158,22 @@ class Oracle:
             self._keep["chrom"] = np.ascontiguousarray(system.chrom_of, dtype=np.int32)
             o.chrom_of = self._keep["chrom"].ctypes.data
             o.chb_kc, o.chb_de = r32(ff.CHB_KC), r32(ff.CHB_DE)
+        # alternative functional forms (the *_FORCE_TYPE keys)
+        o.ev_form = FORM_NAMES["EV_FORCE_TYPE"].index(getattr(ff, "EV_FORCE_TYPE", "powerlaw"))
+        o.cob_form = FORM_NAMES["COB_FORCE_TYPE"].index(getattr(ff, "COB_FORCE_TYPE", "gaussian"))
+        o.scb_form = FORM_NAMES["SCB_FORCE_TYPE"].index(getattr(ff, "SCB_FORCE_TYPE", "gaussian"))
+        o.chb_form = FORM_NAMES["CHB_FORCE_TYPE"].index(getattr(ff, "CHB_FORCE_TYPE", "polynomial"))
+        o.lam_form = FORM_NAMES["BLAMINA_FORCE_TYPE"].index(getattr(ff, "BLAMINA_FORCE_TYPE", "sin"))
+        o.cf_form = FORM_NAMES["CENTRAL_FORCE_TYPE"].index(getattr(ff, "CENTRAL_FORCE_TYPE", "harmonic"))
+        o.loop_form = FORM_NAMES["LE_LOOP_FORCE_TYPE"].index(getattr(ff, "LE_LOOP_FORCE_TYPE", "harmonic"))
+        o.has_cob, o.has_scb = int(ff.COB_USE_COMPARTMENT_BLOCKS), int(ff.SCB_USE_SUBCOMPARTMENT_BLOCKS)
+        for a in (1, 2):  # COB: Ea on {1,2}x{1,2}, Eb on {-1,-2}x{-1,-2} (model.py:246-253)
+            for b in (1, 2):
+                o.tab_cob[(a + 2) * 5 + b + 2] = r32(ff.COB_EA) if o.has_cob else 0.0
+                o.tab_cob[(2 - a) * 5 + 2 - b] = r32(ff.COB_EB) if o.has_cob else 0.0
+        if o.has_scb:      # SCB: diagonal only (model.py:322-333)
+            o.tab_scb[4 * 5 + 4], o.tab_scb[3 * 5 + 3] = r32(ff.SCB_EA1), r32(ff.SCB_EA2)
+            o.tab_scb[1 * 5 + 1], o.tab_scb[0 * 5 + 0] = r32(ff.SCB_EB1), r32(ff.SCB_EB2)
         self.o = o
         self.f32 = as_float32_inputs
 

@@ -311,3 +311,41 @@ def test_edge_cases_tiny_coincident_and_crowded():
     sparse = ChromatinSystem(300, rng.random((300, 3)) * 40.0, np.array([0, 300]), np.zeros(300, np.int8),
                              ff=ForceFieldParams(LE_USE_HARMONIC_BOND=False, NB_CUTOFF=0.6))
     _check(sparse, 0.6, "sparse: one bead per cell")
+
+
+FORM_SETS = [
+    dict(EV_FORCE_TYPE="gaussian_core", COB_FORCE_TYPE="yukawa", SCB_FORCE_TYPE="yukawa", CHB_FORCE_TYPE="gaussian",
+         BLAMINA_FORCE_TYPE="gaussian_shell", CENTRAL_FORCE_TYPE="gaussian", LE_LOOP_FORCE_TYPE="fene_soft"),
+    dict(COB_FORCE_TYPE="theta", SCB_FORCE_TYPE="yukawa", CHB_FORCE_TYPE="saturating",
+         BLAMINA_FORCE_TYPE="harmonic_shell", CENTRAL_FORCE_TYPE="logistic", LE_LOOP_FORCE_TYPE="gaussian_tether"),
+    dict(COB_FORCE_TYPE="gaussian", SCB_FORCE_TYPE="theta", BLAMINA_FORCE_TYPE="logistic_shell"),
+    dict(EV_FORCE_TYPE="gaussian_core"),
+    dict(COB_FORCE_TYPE="yukawa", SCB_USE_SUBCOMPARTMENT_BLOCKS=False),
+]
+
+
+@pytest.mark.parametrize("forms", FORM_SETS)
+@pytest.mark.parametrize("n,cutoff", [(2048, 0.0), (2048, 0.6), (20000, 0.6)])
+def test_alternative_functional_forms(forms, n, cutoff):
+    """Every *_FORCE_TYPE alternative of config.py:269-312, all-pairs and cell-list kernels."""
+    kw = dict(ALL_ON, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.5)
+    kw.update(forms)
+    et, _ = _check(synthetic_system("gw_200k", n_beads=n, jitter=0.03, seed=4, **kw), cutoff,
+                   f"forms {forms} n={n} rc={cutoff}")
+    assert et[0] != 0.0 and et[1] != 0.0
+
+
+def test_alternative_forms_minimize():
+    """Bounded forms minimize like the defaults.  (gaussian_core + yukawa is unbounded below -- -E/r against a
+    finite core -- so that combination of the reference's options is only checked for parity above.)"""
+    forms = dict(EV_FORCE_TYPE="gaussian_core", COB_FORCE_TYPE="theta", SCB_FORCE_TYPE="gaussian",
+                 CHB_FORCE_TYPE="saturating", BLAMINA_FORCE_TYPE="gaussian_shell", CENTRAL_FORCE_TYPE="logistic",
+                 LE_LOOP_FORCE_TYPE="gaussian_tether", CHB_USE_CHROMOSOMAL_BLOCKS=True)
+    s = synthetic_system("gw_200k", n_beads=6000, **dict(ALL_ON, **forms))
+    with engine_for(s) as eng:
+        st = eng.minimize(tolerance=0.0, max_iters=150)
+        assert st.iterations == 150 and np.isfinite(st.e_final) and st.e_final < st.e_initial
+        x = eng.get_positions()
+    from oracle.oracle import Oracle
+    e_ref = Oracle(s).energy(x)
+    assert abs(e_ref - st.e_final) <= 2e-5 * abs(e_ref) + 1e-2

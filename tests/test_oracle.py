@@ -216,3 +216,125 @@ def test_md_integrators_basic_properties():
     _, _, sb1 = orc.md_step(s.positions, 0 * v0, 20, kind="brownian", temperature=0.0, friction=50.0, dt=1e-4,
                             mass=16427.889)
     assert sb1.potential < sb0.potential
+
+
+# ---- alternative functional forms (config.py:269-312) ------------------------------------
+def test_kat_alternative_pair_forms(oracle_lib):
+    """Hand-derivable values of the non-default pair forms (model.py:205-209, 262-288, 340-377)."""
+    two = lambda r: [[0, 0, 0], [r, 0, 0]]
+    ev = dict(EV_USE_EXCLUDED_VOLUME=True, EV_FORCE_TYPE="gaussian_core")
+    et, F = _eval(_sys(two(0.1), **ev))
+    assert et[0] == pytest.approx(100.0 * np.exp(-0.5), rel=1e-12)            # eps*exp(-r^2/(2 sigma^2)), r = sigma
+    assert F[0, 0] == pytest.approx(-et[0] * 0.1 / 0.01, rel=1e-12)           # repulsive: -dE/dr = E r/sigma^2
+    cob = dict(COB_USE_COMPARTMENT_BLOCKS=True)
+    et, F = _eval(_sys(two(0.15), labels=[-1, -2], COB_FORCE_TYPE="yukawa", **cob))
+    assert et[1] == pytest.approx(-2.0 * np.exp(-1.0) / 0.15, rel=1e-12)      # -Eb exp(-r/l)/r at r = l = r_comp
+    assert F[0, 0] == pytest.approx(2.0 * np.exp(-1.0) / 0.15 * (1 / 0.15 + 1 / 0.15), rel=1e-12)  # attractive
+    # the COB yukawa expression reads s1 twice (model.py:266-267): the LOWER index decides the amplitude
+    assert _eval(_sys(two(0.15), labels=[1, -1], COB_FORCE_TYPE="yukawa", **cob))[0][1] == \
+        pytest.approx(-1.0 * np.exp(-1.0) / 0.15, rel=1e-12)
+    assert _eval(_sys(two(0.15), labels=[-1, 1], COB_FORCE_TYPE="yukawa", **cob))[0][1] == \
+        pytest.approx(-2.0 * np.exp(-1.0) / 0.15, rel=1e-12)
+    assert _eval(_sys(two(0.15), labels=[0, 1], COB_FORCE_TYPE="yukawa", **cob))[0][1] == 0.0
+    assert _eval(_sys(two(0.15), labels=[1, -1], COB_FORCE_TYPE="gaussian", **cob))[0][1] == 0.0   # symmetric form
+    et, F = _eval(_sys(two(0.1), labels=[1, 2], COB_FORCE_TYPE="theta", **cob))
+    assert et[1] == -1.0 and np.all(F == 0.0)                                 # -Ea step(r_comp - r), no force
+    assert _eval(_sys(two(0.15), labels=[1, 2], COB_FORCE_TYPE="theta", **cob))[0][1] == -1.0   # step(0) = 1
+    assert _eval(_sys(two(0.151), labels=[1, 2], COB_FORCE_TYPE="theta", **cob))[0][1] == 0.0
+    scb = dict(SCB_USE_SUBCOMPARTMENT_BLOCKS=True)
+    assert _eval(_sys(two(0.3), labels=[1, 1], SCB_FORCE_TYPE="yukawa", **scb))[0][1] == \
+        pytest.approx(-1.33 * np.exp(-2.0) / 0.3, rel=1e-12)
+    assert _eval(_sys(two(0.3), labels=[1, 2], SCB_FORCE_TYPE="yukawa", **scb))[0][1] == 0.0
+    # COB and SCB with different forms at once: two Force objects in the reference, their energies add
+    both = _eval(_sys(two(0.1), labels=[2, 2], COB_FORCE_TYPE="theta", SCB_FORCE_TYPE="gaussian", **cob, **scb))[0][1]
+    assert both == pytest.approx(-1.0 - 1.0 * np.exp(-0.01 / (2 * 0.0225)), rel=1e-12)
+
+
+def test_kat_alternative_single_bead_and_bond_forms(oracle_lib):
+    """Loops (model.py:664-701), chromosomal blocks (:424-443), lamina shells (:508-539), central (:588-612)."""
+    two = lambda r: [[0, 0, 0], [r, 0, 0]]
+    lo = dict(LE_USE_HARMONIC_BOND=True)
+    k = 30000.0
+    e = _eval(_sys(two(0.3), loops=([0], [1], [0.15]), LE_LOOP_FORCE_TYPE="fene_soft", **lo))[0][4]
+    assert e == pytest.approx(k * 0.15 ** 2 / 2.0, rel=1e-12)                 # u = r0: k u^2/(1 + 1)
+    e = _eval(_sys(two(0.3), loops=([0], [1], [0.2]), LE_LOOP_FORCE_TYPE="gaussian_tether", **lo))[0][4]
+    assert e == pytest.approx(k * (1 - np.exp(-1.0)), rel=1e-12)              # u = sigma = r0/2
+    e = _eval(_sys(two(0.3), loops=([0], [1], [0.2]), **lo))[0][4]
+    assert e == pytest.approx(0.5 * k * 0.01, rel=1e-12)                      # default keeps the 1/2
+    chb = dict(CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_KC=0.3, CHB_DE=0.5)
+    s = _sys(two(2.0), chr_ends=[0, 2], CHB_FORCE_TYPE="gaussian", **chb)
+    assert _eval(s)[0][8] == pytest.approx(-0.5 * np.exp(-0.3 * 4.0), rel=1e-12)
+    s = _sys(two(2.0), chr_ends=[0, 2], CHB_FORCE_TYPE="saturating", **chb)
+    assert _eval(s)[0][8] == pytest.approx(-0.5 / (1 + 0.3 * 4.0), rel=1e-12)
+    n = 1001
+    R1, R2, _ = set_radiuses(n, 0.1)
+    half = np.random.default_rng(0).normal(size=(500, 3))
+    half *= (0.5 * (R1 + R2)) / np.linalg.norm(half, axis=1, keepdims=True)
+
+    def at_r(r, label, **ff):
+        p = np.zeros((n, 3))
+        p[1:] = np.concatenate([half, -half])
+        p[0, 0] = r * n / (n - 1)
+        return _sys(p, labels=[label] + [0] * (n - 1), chr_ends=[0, n], **ff)
+
+    ibl = dict(IBL_USE_B_LAMINA_INTERACTION=True)
+    sg = 0.1 * (R2 - R1)
+    e = _eval(at_r(R1, -1, BLAMINA_FORCE_TYPE="gaussian_shell", **ibl))[0][6]
+    assert e == pytest.approx(-400.0 * (1.0 + np.exp(-(R2 - R1) ** 2 / (2 * sg * sg))), rel=1e-9)
+    e = _eval(at_r(R2, -2, BLAMINA_FORCE_TYPE="harmonic_shell", **ibl))[0][6]
+    assert e == pytest.approx(400.0 * (0.5 * (R2 - R1)) ** 2, rel=1e-9)
+    e = _eval(at_r(0.5 * (R1 + R2), -1, BLAMINA_FORCE_TYPE="logistic_shell", **ibl))[0][6]
+    assert e == pytest.approx(-400.0 * 2.0 / (1.0 + np.exp(-10.0)), rel=1e-9)  # both walls 10 lambda away
+    assert _eval(at_r(R1, 1, BLAMINA_FORCE_TYPE="harmonic_shell", **ibl))[0][6] == 0.0
+    cf = dict(CF_USE_CENTRAL_FORCE=True)
+    w = chrom_strength_per_bead(np.array([0, n]), n)
+    s = at_r(0.5 * R1, 0, CENTRAL_FORCE_TYPE="gaussian", **cf)
+    s.chrom_strength = w
+    rr = np.linalg.norm(s.positions - s.centre, axis=1)
+    assert _eval(s)[0][7] == pytest.approx(np.sum(-20.0 * w * np.exp(-rr ** 2 / (2 * (0.5 * R1) ** 2))), rel=1e-9)
+    s = at_r(R1, 0, CENTRAL_FORCE_TYPE="logistic", **cf)
+    s.chrom_strength = w
+    rr = np.linalg.norm(s.positions - s.centre, axis=1)
+    assert _eval(s)[0][7] == pytest.approx(np.sum(-20.0 * w / (1 + np.exp((rr - R1) / (0.2 * R1)))), rel=1e-9)
+
+
+@pytest.mark.parametrize("forms", [
+    dict(EV_FORCE_TYPE="gaussian_core", COB_FORCE_TYPE="yukawa", SCB_FORCE_TYPE="yukawa", CHB_FORCE_TYPE="gaussian",
+         BLAMINA_FORCE_TYPE="gaussian_shell", CENTRAL_FORCE_TYPE="gaussian", LE_LOOP_FORCE_TYPE="fene_soft"),
+    dict(COB_FORCE_TYPE="theta", SCB_FORCE_TYPE="yukawa", CHB_FORCE_TYPE="saturating",
+         BLAMINA_FORCE_TYPE="harmonic_shell", CENTRAL_FORCE_TYPE="logistic", LE_LOOP_FORCE_TYPE="gaussian_tether"),
+    dict(COB_FORCE_TYPE="gaussian", SCB_FORCE_TYPE="theta", BLAMINA_FORCE_TYPE="logistic_shell"),
+])
+@pytest.mark.parametrize("cutoff", [0.0, 0.6])
+def test_finite_difference_gradient_alternative_forms(oracle_lib, forms, cutoff):
+    """Analytic forces of every non-default form against central differences of the oracle's own energy."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=240, jitter=0.03, seed=5, NB_CUTOFF=cutoff, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
+                         COB_USE_COMPARTMENT_BLOCKS=True, CF_USE_CENTRAL_FORCE=True, CHB_USE_CHROMOSOMAL_BLOCKS=True,
+                         CHB_DE=0.5, **forms)
+    orc = Oracle(s, as_float32_inputs=False)
+    et, F = orc.eval()
+    assert all(et[t] != 0.0 for t in (0, 1, 4, 6, 7, 8))
+    x = s.positions.copy()
+    beads = [0, 1, 7, 120, 239] + list(np.unique(np.r_[s.loop_m, s.loop_n])[:2])
+    h = 1e-6
+    for b in beads:
+        for k in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[b, k] += h
+            xm[b, k] -= h
+            fd = -(orc.energy(xp) - orc.energy(xm)) / (2 * h)
+            # theta steps / the cutoff make the energy piecewise: a bead pair within h of a discontinuity is
+            # astronomically unlikely with jittered coordinates
+            assert fd == pytest.approx(F[b, k], rel=2e-5, abs=2e-4 * max(1.0, np.abs(F[b]).max())), (b, k)
+
+
+def test_form_name_tables_agree_and_unknown_names_raise():
+    from multimm_amd.config import load_config
+    from multimm_amd.system import FORM_NAMES, form_index
+    from oracle.oracle import FORM_NAMES as ORC_NAMES
+    assert FORM_NAMES == ORC_NAMES
+    assert form_index("BLAMINA_FORCE_TYPE", "logistic_shell") == 3
+    with pytest.raises(ValueError, match="Unknown EV_FORCE_TYPE"):
+        load_config({"EV_FORCE_TYPE": "soft_lj"})
+    assert load_config({"COB_FORCE_TYPE": "yukawa"}).ff.COB_FORCE_TYPE == "yukawa"
