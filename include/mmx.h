@@ -115,6 +115,11 @@ int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, in
 int mmx_comm_unique_id(uint8_t *id128);
 /* every rank: ncclCommInitRank on the handle's device with the handle's rank/world (collective). */
 int mmx_comm_init(mmx_handle h, const uint8_t *id128);
+/* Test/rehearsal communicator: the `world` handles are ranks 0..world-1 of one system created in ONE process on
+ * ONE device; afterwards every call that issues collectives (compute, minimize, md_step) must be made for all
+ * ranks concurrently, one host thread per handle.  Collectives are host barriers + HIP events + device copies,
+ * reduced in rank order.  Exercises the multi-rank control flow on a single GPU; production runs use RCCL. */
+int mmx_comm_init_local(mmx_handle *handles, int32_t world);
 
 /* ---- system description (replaces the OpenMM Force-object construction in model.py) ----------- */
 /* context.setPositions, model.py:877.  xyz_nm is [N,3] row-major (always the whole system). */

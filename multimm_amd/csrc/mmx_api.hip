@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,12 +75,53 @@ static bool load_rccl(std::string &err) {
     return true;
 }
 
+// In-process loopback communicator (mmx_comm_init_local): the ranks of a decomposed system are handles of ONE
+// process on ONE device, each driven by its own host thread.  Collectives = host barrier + HIP events +
+// device-to-device copies, summed in rank order.  It exists so that the multi-rank control flow (slices, ghosts,
+// identical decisions on every rank) can be executed and tested on a single GPU; production runs use RCCL.
+struct mmx_handle_s;
+struct LocalComm {
+    int world = 0;
+    std::vector<mmx_handle_s *> h;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool broken = false;
+    std::vector<hipEvent_t> ready, done; // [rank*2 + parity]
+    std::vector<double *> mailbox;       // [rank*2 + parity] -> 64 doubles on the device
+    ~LocalComm() {
+        for (auto e : ready) (void)hipEventDestroy(e);
+        for (auto e : done) (void)hipEventDestroy(e);
+        for (auto m : mailbox) (void)hipFree(m);
+    }
+    // Host barrier over the driving threads; false when a rank gave up (timeout / error) so that nobody hangs.
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return generation != gen || broken; })) broken = true;
+        if (broken) cv.notify_all();
+        return !broken;
+    }
+};
+
 struct mmx_handle_s {
     int n = 0, n4 = 0, device = 0;
     // domain decomposition (single GPU: rank 0 of 1, owns every bead)
     int rank = 0, world = 1, slice = 0; // slice = beads per rank (n padded to world * slice = n_all)
     int n_all = 0, own_lo = 0, n_own = 0;
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LocalComm> lcomm; // in-process loopback communicator (tests on one GPU)
+    unsigned long long coll_seq = 0;  // collectives issued so far (parity selects the event / mailbox set)
+    bool coll_failed = false;
+    double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
     float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
     bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation
     hipStream_t stream = nullptr;
@@ -337,6 +381,70 @@ __global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const f
 
 enum PackMode { PACK_PLAIN = 0, PACK_MOVE = 1, PACK_MD = 2 };
 
+
+bool has_comm(const mmx_handle_s *h) { return h->comm != nullptr || h->lcomm != nullptr; }
+
+__global__ void k_local_sum(int world, int count, double *const *__restrict__ boxes, double *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i >= count) return;
+    double r = 0.0;
+    for (int q = 0; q < world; ++q) r += boxes[q][i]; // rank order: every rank gets the same bits
+    out[i] = r;
+}
+
+// Loopback collectives.  Protocol per call (p = parity of the call number): [stage own data] -> record ready[r][p]
+// -> host barrier -> wait ready[q][p] of every rank, read their data -> record done[r][p] -> host barrier -> wait
+// done[q][p] of every rank (nobody may overwrite what another rank is still reading).
+bool local_begin(mmx_handle_s *h, int &p) {
+    LocalComm &L = *h->lcomm;
+    p = (int)(h->coll_seq++ & 1);
+    (void)hipEventRecord(L.ready[h->rank * 2 + p], h->stream);
+    if (!L.barrier()) return false;
+    for (int q = 0; q < L.world; ++q)
+        if (q != h->rank) (void)hipStreamWaitEvent(h->stream, L.ready[q * 2 + p], 0);
+    return true;
+}
+bool local_end(mmx_handle_s *h, int p) {
+    LocalComm &L = *h->lcomm;
+    (void)hipEventRecord(L.done[h->rank * 2 + p], h->stream);
+    if (!L.barrier()) return false;
+    for (int q = 0; q < L.world; ++q)
+        if (q != h->rank) (void)hipStreamWaitEvent(h->stream, L.done[q * 2 + p], 0);
+    return true;
+}
+
+// In-place all-gather of the position slices (ghost beads of every term).
+void coll_allgather_pos4(mmx_handle_s *h) {
+    if (h->comm) {
+        (void)g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat, h->comm,
+                               h->stream);
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        for (int q = 0; q < L.world; ++q)
+            if (q != h->rank)
+                (void)hipMemcpyAsync(h->pos4 + (size_t)q * h->slice, L.h[q]->pos4 + (size_t)q * h->slice,
+                                     sizeof(float4) * (size_t)h->slice, hipMemcpyDeviceToDevice, h->stream);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+}
+
+// In-place fp64 sum of `count` (<= 64) doubles over the ranks.
+void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
+    if (h->comm) {
+        (void)g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, h->stream);
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        const int p0 = (int)(h->coll_seq & 1);
+        (void)hipMemcpyAsync(L.mailbox[h->rank * 2 + p0], buf, sizeof(double) * count, hipMemcpyDeviceToDevice, h->stream);
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        hipLaunchKernelGGL(k_local_sum, dim3(1), dim3(64), 0, h->stream, L.world, count, h->lbox[p], buf);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+}
+
 void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
@@ -358,9 +466,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
-    if (h->comm) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
-        (void)g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat, h->comm,
-                               h->stream);
+    if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
+        coll_allgather_pos4(h);
     if (has_nb(h) && !all_pairs(h)) {
         const float hm = hmin_of(h);
         GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
@@ -446,11 +553,11 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
     A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
 
     on = prof_begin(h, MMX_K_REDUCE, ep);
-    if (!h->comm) {
+    if (!has_comm(h)) {
         hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
     } else { // energies + g.d, g.g, x.x of all ranks: one fp64 all-reduce of 16 doubles per evaluation
         hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
-        (void)g_rccl.AllReduce(h->st->sums, h->st->sums, 16, ncclDouble, ncclSum, h->comm, h->stream);
+        coll_allreduce(h, h->st->sums, 16);
         hipLaunchKernelGGL(k_controller_decide, dim3(1), dim3(64), 0, h->stream, h->st);
     }
     prof_end(h, on, ep);
@@ -465,12 +572,11 @@ void enqueue_accept(mmx_handle_s *h) {
     hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
                        (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (float4 *)h->S,
                        (float4 *)h->Y, h->rows, h->st);
-    if (!h->comm) {
+    if (!has_comm(h)) {
         hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
     } else { // the 39 Gram-row entries of all ranks: one fp64 all-reduce per accepted iteration
         hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
-        (void)g_rccl.AllReduce(h->st->rowsum, h->st->rowsum, MMX_NROWS * MMX_NBASIS + 1, ncclDouble, ncclSum,
-                               h->comm, h->stream);
+        coll_allreduce(h, h->st->rowsum, MMX_NROWS * MMX_NBASIS + 1);
         hipLaunchKernelGGL(k_direction_coef_decide, dim3(1), dim3(64), 0, h->stream, h->st);
     }
     hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
@@ -488,6 +594,7 @@ int pull_state(mmx_handle_s *h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
     if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, "loopback collective timed out: every rank of the group must make the same call from its own thread");
     return MMX_OK;
 }
 
@@ -684,13 +791,53 @@ int mmx_comm_init(mmx_handle h, const uint8_t *id128) {
     return MMX_OK;
 }
 
+int mmx_comm_init_local(mmx_handle *handles, int32_t world) {
+    if (!handles || world < 1) return MMX_ERR_BAD_ARG;
+    for (int r = 0; r < world; ++r) {
+        mmx_handle_s *h = handles[r];
+        if (!h) return MMX_ERR_BAD_ARG;
+        if (h->world != world || h->rank != r || h->n != handles[0]->n || h->device != handles[0]->device)
+            return fail(h, MMX_ERR_BAD_ARG, "handles must be ranks 0..world-1 of one system on one device");
+        if (has_comm(h)) return fail(h, MMX_ERR_STATE, "communicator already initialised");
+    }
+    mmx_handle_s *h0 = handles[0];
+    HIPCHK(h0, hipSetDevice(h0->device));
+    auto L = std::make_shared<LocalComm>();
+    L->world = world;
+    L->h.assign(handles, handles + world);
+    for (int i = 0; i < 2 * world; ++i) {
+        hipEvent_t a, b;
+        HIPCHK(h0, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        L->ready.push_back(a);
+        HIPCHK(h0, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        L->done.push_back(b);
+        double *m = nullptr;
+        HIPCHK(h0, dalloc(&m, (size_t)64));
+        L->mailbox.push_back(m);
+    }
+    for (int r = 0; r < world; ++r) {
+        mmx_handle_s *h = handles[r];
+        for (int p = 0; p < 2; ++p) {
+            std::vector<double *> boxes(world);
+            for (int q = 0; q < world; ++q) boxes[q] = L->mailbox[q * 2 + p];
+            HIPCHK(h, dalloc(&h->lbox[p], (size_t)world));
+            HIPCHK(h, hipMemcpy(h->lbox[p], boxes.data(), sizeof(double *) * world, hipMemcpyHostToDevice));
+        }
+        h->lcomm = L;
+        h->coll_seq = 0;
+        h->coll_failed = false;
+    }
+    return MMX_OK;
+}
+
 int mmx_destroy(mmx_handle h) {
     if (!h) return MMX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
-    for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp})
+    for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
+                    (void *)h->lbox[1]})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
@@ -1254,7 +1401,7 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) {
     hipLaunchKernelGGL(k_md_kinetic, dim3(gk), dim3(256), 0, h->stream, h->n_own, h->v, h->g, (float)(shift / h->md_mass),
                        0.5 * h->md_mass, h->ke_part);
     hipLaunchKernelGGL(k_md_kinetic_fold, dim3(1), dim3(256), 0, h->stream, gk, h->ke_part, h->ke_out);
-    if (h->comm) (void)g_rccl.AllReduce(h->ke_out, h->ke_out, 1, ncclDouble, ncclSum, h->comm, h->stream);
+    if (has_comm(h)) coll_allreduce(h, h->ke_out, 1);
     if ((rc = pull_state(h))) return rc;
     double ke = 0.0;
     HIPCHK(h, hipMemcpy(&ke, h->ke_out, sizeof(double), hipMemcpyDeviceToHost));

@@ -74,6 +74,7 @@ SIGNATURES = {
                               C.POINTER(C.c_int32)]),
     "mmx_comm_unique_id": (C.c_int, [_P]),
     "mmx_comm_init": (C.c_int, [_P, _P]),
+    "mmx_comm_init_local": (C.c_int, [C.POINTER(_P), C.c_int32]),
     "mmx_destroy": (C.c_int, [_P]),
     "mmx_last_error": (C.c_char_p, [_P]),
     "mmx_set_positions": (C.c_int, [_P, _P]),
@@ -159,6 +160,16 @@ class Engine:
         if rc != 0:
             raise MMXError(rc, (lib.mmx_last_error(None) or b"?").decode())
         return bytes(buf)
+
+    @staticmethod
+    def comm_init_local(engines):
+        """Loopback communicator over ranks 0..world-1 living in this process on one device (mmx.h); afterwards
+        drive every engine from its own thread."""
+        lib = load_library()
+        arr = (_P * len(engines))(*[e._h for e in engines])
+        rc = lib.mmx_comm_init_local(arr, len(engines))
+        if rc != 0:
+            raise MMXError(rc, (lib.mmx_last_error(engines[0]._h) or b"?").decode())
 
     def comm_init(self, unique_id: bytes):
         """Collective over all ranks: RCCL communicator on this handle's device."""
