@@ -317,10 +317,15 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
             /* default: cutoff by v_fma clamp + one energy accumulator pair per lane + per-bead cull;       \
                nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
             const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) |               \
-                            ((h->nb_variant & 128) ? 0 : 8) | ((h->nb_variant & 256) ? 16 : 0);             \
+                            ((h->nb_variant & 128) ? 0 : 8) | ((h->nb_variant & 256) ? 16 : 0) |           \
+                            ((h->nb_variant & 512) ? 32 : 0) | ((h->nb_variant & 1024) ? 64 : 0);          \
             switch (opt) {                                                                                  \
             case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
             case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
+            case 46: NBJ(PMODE, EV, GA, true, 46); break;                                                   \
+            case 22: NBJ(PMODE, EV, GA, true, 22); break;                                                   \
+            case 78: NBJ(PMODE, EV, GA, true, 78); break;                                                   \
+            case 62: NBJ(PMODE, EV, GA, true, 62); break;                                                   \
             case 6: NBJ(PMODE, EV, GA, true, 6); break;                                                     \
             case 12: NBJ(PMODE, EV, GA, true, 12); break;                                                   \
             case 10: NBJ(PMODE, EV, GA, true, 10); break;                                                   \

@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
     constexpr bool BEADCULL = (OPT & 8) != 0; // per-bead second-level cull + LDS ring compaction
     constexpr bool NOSWEEP = (OPT & 16) != 0; // diagnosis only: skip the pair arithmetic (times culls + fold)
+    constexpr bool P1ONLY = (OPT & 64) != 0;  // diagnosis only: cluster cull + fold, no j stream at all
+    constexpr bool SAMEJ = (OPT & 32) != 0;   // diagnosis only: every j load hits the same 64 clusters (L1-resident)
     __shared__ int s_list[4][kListCap + 72];
     __shared__ float4 s_ring[4][BEADCULL ? 128 : 1];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
@@ -376,6 +378,12 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                 nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
                 base += 64;
             }
+            if (P1ONLY) {
+                fx[0] += (float)nlist;
+                nlist = 0;
+                wave_lds_sync();
+                continue;
+            }
             if (nlist == 0 && (!BEADCULL || rcount == 0)) break;
             // pad to a multiple of 8 clusters with "no cluster" (also gives the ring its flush step)
             if (lane < 8) list[nlist + lane] = -1;
@@ -383,11 +391,13 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
             const int nsteps = max((nlist + 7) >> 3, 1);
             // ---- sweep: 8 j-clusters (64 j beads) per step against the 8 scalar i beads
             int jn = list[sub];
+            if (SAMEJ && jn >= 0) jn &= 63;
             float4 qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
             for (int t = 0; t < nsteps; ++t) {
                 float4 q = qn;
                 if (t + 1 < nsteps) { // prefetch the next 8 clusters
                     jn = list[(t + 1) * 8 + sub];
+                    if (SAMEJ && jn >= 0) jn &= 63;
                     qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
                 }
                 if (BEADCULL) {
