@@ -318,8 +318,10 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
                nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
             const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) |               \
                             ((h->nb_variant & 128) ? 0 : 8) | ((h->nb_variant & 256) ? 16 : 0) |           \
-                            ((h->nb_variant & 512) ? 32 : 0) | ((h->nb_variant & 1024) ? 64 : 0);          \
-            switch (opt) {                                                                                  \
+                            ((h->nb_variant & 512) ? 32 : 0) | ((h->nb_variant & 1024) ? 64 : 0) |         \
+                            ((h->nb_variant & 2048) ? 128 : 0);                                            \
+            if (opt == 142) { NBJ(PMODE, EV, GA, true, 142); break; }                                       \
+            switch (opt & 127) { /* A/B and diagnosis instances keep the plain block -> cluster mapping */  \
             case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
             case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
             case 46: NBJ(PMODE, EV, GA, true, 46); break;                                                   \
@@ -369,7 +371,7 @@ int nb_grid(const mmx_handle_s *h) {
     // cluster kernel: 4 clusters (waves) per block, grid-stride beyond the estimate
     int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     int g = (cl + cl / 8) / 4 + 64;
-    return std::max(256, std::min(g, kPartStride));
+    return (std::max(256, std::min(g, kPartStride)) + 7) & ~7; // multiple of 8: whole rounds over the XCDs
 }
 
 // Fills pos4 of every bead from the host-set global positions (multi-GPU: beads of other ranks are

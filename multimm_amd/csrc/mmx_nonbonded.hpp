@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
     constexpr bool BEADCULL = (OPT & 8) != 0; // per-bead second-level cull + LDS ring compaction
     constexpr bool NOSWEEP = (OPT & 16) != 0; // diagnosis only: skip the pair arithmetic (times culls + fold)
+    constexpr bool XCDMAP = (OPT & 128) != 0; // blocks of one XCD (blockIdx % 8) take contiguous cluster ranges
     constexpr bool P1ONLY = (OPT & 64) != 0;  // diagnosis only: cluster cull + fold, no j stream at all
     constexpr bool SAMEJ = (OPT & 32) != 0;   // diagnosis only: every j load hits the same 64 clusters (L1-resident)
     __shared__ int s_list[4][kListCap + 72];
@@ -309,7 +310,19 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                 cut_g = 1e30f * fminf(P.g_rc2, 1e6f);
     double acc_ev = 0.0, acc_g = 0.0;
 
-    for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
+    // Optional XCD-aware work mapping (nb_variant bit 2048; OFF by default): workgroups go round-robin to the 8
+    // XCDs (blockIdx % 8), each with its own 4 MB L2.  Clusters are cell-sorted, so a contiguous range of clusters
+    // is a spatial slab: XCD x takes slabs x and x+8 of 16 and its L2 then holds two slabs plus halo instead of
+    // every position.  Measured at 200k beads: L2 fetches from the fabric / 2.5, kernel time + 1 % (lattice) to
+    // + 5 % (relaxed sphere): slabs near the z ends carry less work, so some XCDs drain early, and the kernel is
+    // not bandwidth-bound in the first place.
+    const int nvb = (ncl + 3) >> 2, per16 = (nvb + 15) >> 4;
+    const int jend = XCDMAP ? 2 * per16 : nvb, jstep = XCDMAP ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (int j = XCDMAP ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; j < jend; j += jstep) {
+        const int xcd = blockIdx.x & 7;
+        const int vb = !XCDMAP ? j : (j < per16 ? xcd * per16 + j : (8 + xcd) * per16 + (j - per16));
+        const int icl = vb * 4 + wave;
+        if (icl >= ncl) continue;
         const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
         // wave-uniform values are moved to scalar registers explicitly (v_readfirstlane): hipcc cannot prove
         // uniformity of loaded / ballot-derived values and would otherwise run the loop control on the VALU
