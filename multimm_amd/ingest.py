@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+import os
+
 from .system import CHROM_LENGTHS
 
 CHRS = {i: f"chr{i + 1}" for i in range(22)}
@@ -42,9 +44,20 @@ def _chrom_layout(chrom, rng, shuffle, n_chroms):
     return chrom_idxs, ends
 
 
+def _save_meta(path, **arrays):
+    """metadata/<name>.npy under the run directory, what plots.py:456-458 and viz_chroms read back."""
+    if path is None:
+        return
+    d = os.path.join(path, "metadata")
+    os.makedirs(d, exist_ok=True)
+    for name, a in arrays.items():
+        np.save(os.path.join(d, name + ".npy"), a)
+
+
 def import_mns_from_bedpe(bedpe_file, n_beads, coords=None, chrom=None, threshold=0, min_loop_dist=2, down_prob=1.0,
-                          shuffle=False, seed=0, n_chroms=22):
-    """-> (ms, ns, ds, chr_ends, chrom_idxs) as MultiMM.__init__ receives them (model.py:122-132)."""
+                          shuffle=False, seed=0, n_chroms=22, path=None):
+    """-> (ms, ns, ds, chr_ends, chrom_idxs) as MultiMM.__init__ receives them (model.py:122-132).
+    ``path``: run directory; writes metadata/{chrom_lengths,chrom_idxs,ms,ns,ds}.npy (utils.py:477,536-539)."""
     rng = np.random.RandomState(seed)          # same stream as np.random.seed(seed) in the reference
     rows = _read_tsv(bedpe_file, 7)
     c0 = np.array([r[0] for r in rows])
@@ -101,6 +114,7 @@ def import_mns_from_bedpe(bedpe_file, n_beads, coords=None, chrom=None, threshol
     if down_prob < 1.0:
         keep = np.where(rng.rand(len(ms)) < down_prob)[0]
         ms, ns, ds = ms[keep], ns[keep], ds[keep]
+    _save_meta(path, chrom_lengths=chrom_ends, chrom_idxs=chrom_idxs, ms=ms, ns=ns, ds=ds)
     return ms.astype(int), ns.astype(int), ds, chrom_ends.astype(int), chrom_idxs.astype(int)
 
 
@@ -117,8 +131,9 @@ def _label_value(label: str):
 
 
 def import_bed(bed_file, n_beads, coords=None, chrom=None, shuffle=False, seed=0, n_chroms=22, flip_prob=0.0,
-               noise_strength=0.0):
-    """-> (Cs, chr_ends, chrom_idxs) as MultiMM.__init__ receives them (model.py:105-117)."""
+               noise_strength=0.0, path=None):
+    """-> (Cs, chr_ends, chrom_idxs) as MultiMM.__init__ receives them (model.py:105-117).
+    ``path``: run directory; writes metadata/{chrom_lengths,compartments,chrom_idxs}.npy (utils.py:274,343-344)."""
     rng = np.random.RandomState(seed)
     rows = _read_tsv(bed_file, 4)
     c0 = np.array([r[0] for r in rows])
@@ -158,4 +173,5 @@ def import_bed(bed_file, n_beads, coords=None, chrom=None, shuffle=False, seed=0
         comps[mask] += step[mask]
         comps = np.clip(comps, -2, 2)
     cs = np.where(comps > 1.5, 2, np.where(comps > 0.2, 1, np.where(comps < -1.5, -2, np.where(comps < -0.2, -1, 0))))
+    _save_meta(path, chrom_lengths=chrom_ends, compartments=cs.astype(int), chrom_idxs=chrom_idxs)
     return cs.astype(int), chrom_ends.astype(int), chrom_idxs.astype(int)

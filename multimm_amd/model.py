@@ -46,9 +46,9 @@ class MultiMM:
             coords = (self.args.LOC_START, self.args.LOC_END) if chrom else None
             if self.args.COMPARTMENT_PATH and str(self.args.COMPARTMENT_PATH).lower().endswith(".bed"):
                 Cs, chr_ends, _ = import_bed(self.args.COMPARTMENT_PATH, n, coords=coords, chrom=chrom,
-                                             seed=int(self.args.SHUFFLING_SEED))
+                                             seed=int(self.args.SHUFFLING_SEED), path=self.args.OUT_PATH)
             ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(self.args.LOOPS_PATH, n, coords=coords, chrom=chrom,
-                                                             seed=int(self.args.SHUFFLING_SEED))
+                                                             seed=int(self.args.SHUFFLING_SEED), path=self.args.OUT_PATH)
         if ms is None:
             preset = "gw_200k" if str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") else "chr1_50k"
             syn = synthetic_system(preset, seed=int(self.args.SHUFFLING_SEED), n_beads=n)
@@ -190,4 +190,15 @@ class MultiMM:
             self.save_chromosomes()
         if self.args.SIM_RUN_MD:
             self.run_md()
+        self.save_parameters()
         return self.stats
+
+    # --- utils.py:733-742 (save_args_to_txt), called at model.py:1246 -------------------------------------------
+    def save_parameters(self):
+        """metadata/parameters.txt: one ``NAME = value`` line per configuration key (None -> empty value)."""
+        import dataclasses
+        items = {k: v for k, v in dataclasses.asdict(self.args).items() if k != "ff"}
+        items.update(dataclasses.asdict(self.args.ff))
+        with open(os.path.join(self.args.OUT_PATH, "metadata", "parameters.txt"), "w") as f:
+            for name, value in items.items():
+                f.write(f"{name} = \n" if value is None else f"{name} = {value}\n")

@@ -172,6 +172,8 @@ def test_multimm_run_with_md_writes_reference_outputs(tmp_path):
     d = read_dcd(str(out / "metadata" / "MultiMM_annealing.dcd"))
     assert (d["n_frames"], d["n_atoms"], d["interval"], d["first_step"], d["last_step"]) == (20, 2000, 10, 10, 210)
     assert np.abs(d["frames_nm"][-1] - m.state_positions).max() < 1e-5
+    params = open(out / "metadata" / "parameters.txt").read()   # save_args_to_txt, model.py:1246
+    assert "SIM_N_STEPS = 200\n" in params and "EV_POWER = 6.0\n" in params and "LOC_START = \n" in params
     minimized = cif.read_positions(str(out / "model" / "MultiMM_minimized.cif"))
     moved = np.abs(after - minimized).max()
     assert 1e-4 < moved < 0.5, moved

@@ -103,3 +103,17 @@ def test_ingest_feeds_the_model(tmp_path):
     m.set_radiuses()
     m.initialize_simulation()
     assert m.system.n_loops == len(ms) and set(np.unique(m.system.labels)) <= {-1, 0, 2}
+
+
+def test_metadata_npy_files_like_the_reference(tmp_path):
+    """The parsers leave metadata/*.npy behind (utils.py:274,343-344,477,536-539): plots.py:456-458 reads them."""
+    b = _write(tmp_path / "a.bedpe", [("chr1", 100, 120, "chr1", 300, 320, 8.0), ("chr1", 700, 720, "chr1", 900, 940, 1.0)])
+    e = _write(tmp_path / "e.bed", [("chr1", 100, 300, "A.1.1"), ("chr1", 500, 700, "B.1.1")])
+    out = tmp_path / "run"
+    cs, ends_b, idx_b = import_bed(e, 100, coords=(0, 1000), chrom="chr1", path=str(out))
+    ms, ns, ds, ends, idxs = import_mns_from_bedpe(b, 100, coords=(0, 1000), chrom="chr1", path=str(out))
+    meta = out / "metadata"
+    assert np.array_equal(np.load(meta / "compartments.npy"), cs)
+    assert np.array_equal(np.load(meta / "chrom_lengths.npy"), ends) and np.array_equal(np.load(meta / "chrom_idxs.npy"), idxs)
+    assert np.array_equal(np.load(meta / "ms.npy"), ms) and np.array_equal(np.load(meta / "ns.npy"), ns)
+    assert np.allclose(np.load(meta / "ds.npy"), ds)
