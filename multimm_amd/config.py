@@ -84,7 +84,9 @@ class SimulationConfig:
 
     def apply_modelling_level(self) -> None:
         """Presets of run.py:137-213 (only the keys on this path)."""
-        level = str(self.MODELLING_LEVEL).lower()
+        level = "" if self.MODELLING_LEVEL is None else str(self.MODELLING_LEVEL).strip().lower()
+        if level == "none":
+            level = ""
         has_comp = bool(self.COMPARTMENT_PATH)
         ff = self.ff
         if level == "gene":

@@ -23,7 +23,7 @@ from . import cif
 from .config import SimulationConfig, load_config
 from .engine import Engine, MMXError
 from .hilbert import hilbert_points
-from .system import ChromatinSystem, set_radiuses, synthetic_system
+from .system import ChromatinSystem, chrom_strength_per_bead, set_radiuses, synthetic_system
 
 logger = logging.getLogger("multimm_amd")
 
@@ -50,7 +50,9 @@ class MultiMM:
             ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(self.args.LOOPS_PATH, n, coords=coords, chrom=chrom,
                                                              seed=int(self.args.SHUFFLING_SEED), path=self.args.OUT_PATH)
         if ms is None:
-            preset = "gw_200k" if str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") else "chr1_50k"
+            # no CHROM = genome-wide layout (22 chromosome intervals), as the parsers produce for chrom=None
+            preset = "gw_200k" if (str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") or not self.args.CHROM) \
+                else "chr1_50k"
             syn = synthetic_system(preset, seed=int(self.args.SHUFFLING_SEED), n_beads=n)
             ms, ns, ds = syn.loop_m, syn.loop_n, syn.loop_r0
             chr_ends = syn.chr_ends if chr_ends is None else chr_ends
@@ -58,7 +60,12 @@ class MultiMM:
         self.ms, self.ns, self.ds = np.asarray(ms), np.asarray(ns), np.asarray(ds)
         self.chr_ends = np.asarray(chr_ends if chr_ends is not None else [0, n], dtype=np.int32)
         self.Cs = np.zeros(n, np.int8) if Cs is None else np.asarray(Cs, dtype=np.int8)
-        self.chrom_strength = chrom_strength
+        # model.py:158-162: per-bead central-force weights by chromosome INTERVAL position (utils.py:137); a single
+        # region (CHROM set) keeps zeros, as the reference does
+        if chrom_strength is None:
+            chrom_strength = (chrom_strength_per_bead(self.chr_ends, n) if not self.args.CHROM
+                              else np.zeros(n, dtype=np.float64))
+        self.chrom_strength = np.asarray(chrom_strength, dtype=np.float64)
         self.save_path = os.path.join(self.args.OUT_PATH, "")
         for sub in ("metadata", "model", os.path.join("model", "chromosomes"), "md_frames"):  # model.py:44-48
             os.makedirs(os.path.join(self.args.OUT_PATH, sub), exist_ok=True)
