@@ -548,8 +548,13 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
     if (h->P.use_chb && h->chrom_of) {
         const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
         on = prof_begin(h, MMX_K_CHB, ep);
-        hipLaunchKernelGGL(k_chb, dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,
-                           h->chrom_hi, h->g, h->part, h->st, h->Q.chb_form);
+#define CHB(F)                                                                                              \
+    hipLaunchKernelGGL((k_chb<F>), dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,    \
+                       h->chrom_hi, h->g, h->part, h->st)
+        if (h->Q.chb_form == 0) CHB(0);
+        else if (h->Q.chb_form == 1) CHB(1);
+        else CHB(2);
+#undef CHB
         prof_end(h, on, ep);
         A.nblk[P_CHB] = std::min(gc, kPartStride);
     }

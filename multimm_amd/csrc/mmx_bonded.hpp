@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
 // a block-diagonal all-pairs sweep: a block owns 256 consecutive beads and walks the bead range spanned by the
 // chromosomes of its first and last bead in LDS tiles; pairs of different chromosomes inside that range are
 // masked.  F_i = -dE*(4 k_C r^2 - 3 r + 2)*d, one v_sqrt per pair.  Each thread adds to its own bead: no atomics.
+template <int FORM> // 0 polynomial, 1 gaussian, 2 saturating (compile-time: the pair loop carries no branch)
 __global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__restrict__ pos4,
                                              const int *__restrict__ chrom_of, const int *__restrict__ chrom_lo,
                                              const int *__restrict__ chrom_hi, float *__restrict__ g,
-                                             double *__restrict__ part, const MinState *__restrict__ st,
-                                             const int chb_form) {
+                                             double *__restrict__ part, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ float4 s_tile[256];
     __shared__ int s_chr[256];
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__r
             const float r = __builtin_amdgcn_sqrtf(r2);
             float m = (s_chr[t] == ci) ? P.chb_de : 0.f; // the self pair has r = 0: contributes nothing
             float fs;
-            if (chb_form == 0) { // polynomial, model.py:416-419
+            if (FORM == 0) { // polynomial, model.py:416-419
                 e = fmaf(m * r2, fmaf(P.chb_kc, r2, 1.f - r), e);
                 fs = -m * (fmaf(k4, r2, 2.f) - 3.f * r);
             } else {
                 m = (jb + t == i) ? 0.f : m; // these forms are non-zero at r = 0: drop the self pair explicitly
-                if (chb_form == 1) { // gaussian: -dE exp(-k_C r^2), model.py:428-431
+                if (FORM == 1) { // gaussian: -dE exp(-k_C r^2), model.py:428-431
                     const float ex = m * __expf(-P.chb_kc * r2);
                     e -= ex;
                     fs = -2.f * P.chb_kc * ex;
