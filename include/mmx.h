@@ -32,6 +32,7 @@ extern "C" {
 #define MMX_ERR_RCCL (-3)
 #define MMX_ERR_NAN (-4)   /* non-finite energy met by the minimizer / compute */
 #define MMX_ERR_STATE (-5) /* call made in the wrong order (e.g. compute before set_positions) */
+#define MMX_ERR_NOMEM (-6) /* host allocation failed inside the library */
 
 /* Energy-term slots of mmx_compute()/mmx_stats (order of model.py:812-857 collapsed on kernels). */
 enum {

@@ -660,13 +660,19 @@ int prepare(mmx_handle_s *h) {
 } // namespace
 
 // =================================================================================================
+// No C++ exception may cross the C ABI: every entry point is a function-try-block ending in MMX_CATCH.
+#define MMX_CATCH(H)                                                                                       \
+    catch (const std::bad_alloc &) { return fail((H), MMX_ERR_NOMEM, "out of host memory"); }              \
+    catch (const std::exception &e) { return fail((H), MMX_ERR_STATE, std::string("internal error: ") + e.what()); } \
+    catch (...) { return fail((H), MMX_ERR_STATE, "internal error"); }
+
 extern "C" {
 
 int mmx_abi_version(void) { return 1; }
 
 const char *mmx_last_error(mmx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) {
+static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) try {
     if (!out) return MMX_ERR_BAD_ARG;
     *out = nullptr;
     if (n_beads < 1 || n_beads > (1 << 28)) {
@@ -758,24 +764,24 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
     h->P.bond_r0 = 0.1f;
     *out = h;
     return MMX_OK;
-}
+} MMX_CATCH(nullptr)
 
 int mmx_create(int32_t n_beads, int32_t device_id, mmx_handle *out) { return create_impl(n_beads, 0, 1, device_id, out); }
 
-int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) {
+int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out) try {
     return create_impl(n_beads, rank, world, device_id, out);
-}
+} MMX_CATCH(nullptr)
 
-int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world) {
+int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world) try {
     if (!h) return MMX_ERR_BAD_ARG;
     if (own_lo) *own_lo = h->own_lo;
     if (n_own) *n_own = h->n_own;
     if (rank) *rank = h->rank;
     if (world) *world = h->world;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_comm_unique_id(uint8_t *id128) {
+int mmx_comm_unique_id(uint8_t *id128) try {
     if (!id128) return MMX_ERR_BAD_ARG;
     if (!load_rccl(g_create_error)) return MMX_ERR_RCCL;
     ncclUniqueId id;
@@ -786,9 +792,9 @@ int mmx_comm_unique_id(uint8_t *id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(id128, &id, 128);
     return MMX_OK;
-}
+} MMX_CATCH(nullptr)
 
-int mmx_comm_init(mmx_handle h, const uint8_t *id128) {
+int mmx_comm_init(mmx_handle h, const uint8_t *id128) try {
     if (!h || !id128) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (h->comm) return fail(h, MMX_ERR_STATE, "communicator already initialised");
     if (!load_rccl(h->err)) return MMX_ERR_RCCL;
@@ -801,9 +807,9 @@ int mmx_comm_init(mmx_handle h, const uint8_t *id128) {
         return fail(h, MMX_ERR_RCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
     }
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_comm_init_local(mmx_handle *handles, int32_t world) {
+int mmx_comm_init_local(mmx_handle *handles, int32_t world) try {
     if (!handles || world < 1) return MMX_ERR_BAD_ARG;
     for (int r = 0; r < world; ++r) {
         mmx_handle_s *h = handles[r];
@@ -840,9 +846,9 @@ int mmx_comm_init_local(mmx_handle *handles, int32_t world) {
         h->coll_failed = false;
     }
     return MMX_OK;
-}
+} MMX_CATCH(nullptr)
 
-int mmx_destroy(mmx_handle h) {
+int mmx_destroy(mmx_handle h) try {
     if (!h) return MMX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -870,9 +876,9 @@ int mmx_destroy(mmx_handle h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MMX_OK;
-}
+} MMX_CATCH(nullptr)
 
-int mmx_set_positions(mmx_handle h, const float *xyz) {
+int mmx_set_positions(mmx_handle h, const float *xyz) try {
     if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
@@ -888,9 +894,9 @@ int mmx_set_positions(mmx_handle h, const float *xyz) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_pos = true;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_get_positions(mmx_handle h, float *xyz) {
+int mmx_get_positions(mmx_handle h, float *xyz) try {
     if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set");
     HIPCHK(h, hipSetDevice(h->device));
@@ -913,9 +919,9 @@ int mmx_get_positions(mmx_handle h, float *xyz) {
     }
     HIPCHK(h, hipMemcpy(xyz + (size_t)3 * h->own_lo, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_labels(mmx_handle h, const int8_t *s) {
+int mmx_set_labels(mmx_handle h, const int8_t *s) try {
     if (!h || !s) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     for (int i = 0; i < h->n; ++i)
@@ -924,10 +930,10 @@ int mmx_set_labels(mmx_handle h, const int8_t *s) {
     HIPCHK(h, hipMemcpy(h->labels, s, (size_t)h->n, hipMemcpyHostToDevice));
     if (h->xg) h->pos4_dirty = true;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, float bond_k, float angle_theta0,
-                           float angle_k, int32_t use_bond, int32_t use_angle) {
+                           float angle_k, int32_t use_bond, int32_t use_angle) try {
     if (!h || !flags) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     const int n = h->n;
@@ -945,10 +951,10 @@ int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, fl
     h->P.use_bond = use_bond ? 1 : 0;
     h->P.use_angle = use_angle ? 1 : 0;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, float bond_r0, float bond_k,
-                     float angle_theta0, float angle_k, int32_t use_bond, int32_t use_angle) {
+                     float angle_theta0, float angle_k, int32_t use_bond, int32_t use_angle) try {
     if (!h || (!chr_ends && n_ends > 0) || n_ends < 0) return fail(h, MMX_ERR_BAD_ARG, "bad chr_ends");
     const int n = h->n;
     // model.py:629 "i not in chr_ends" ; model.py:712 "(i not in chr_ends) and (i not in chr_ends - 1)"
@@ -967,9 +973,9 @@ int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, floa
         flags[i] = f;
     }
     return mmx_set_backbone_masks(h, flags.data(), bond_r0, bond_k, angle_theta0, angle_k, use_bond, use_angle);
-}
+} MMX_CATCH(h)
 
-int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop) {
+int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop) try {
     if (!h || n_loops < 0 || (n_loops > 0 && (!m || !n || !r0))) return fail(h, MMX_ERR_BAD_ARG, "bad loop arrays");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
@@ -1026,9 +1032,9 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
         HIPCHK(h, hipMemcpy(h->loop_r0, er0.data(), er0.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) {
+int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) try {
     if (!h) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power))
@@ -1040,9 +1046,9 @@ int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small,
     h->P.ev_power = power;
     h->ev_cut = cutoff_nm;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm) {
+int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm) try {
     if (!h || !E || !(rc > 0.f)) return fail(h, MMX_ERR_BAD_ARG, "bad compartment parameters");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     auto idx = [](int si, int sj) { return (si + 2) * 5 + (sj + 2); };
@@ -1067,9 +1073,9 @@ int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, f
     h->g_cut = cutoff_nm;
     h->P.use_gauss = 1;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]) {
+int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]) try {
     if (!h || !centre) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     h->P.use_container = 1;
@@ -1080,9 +1086,9 @@ int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float cen
     h->P.cy = centre[1];
     h->P.cz = centre[2];
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]) {
+int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]) try {
     if (!h || !centre || !(R2 != R1)) return fail(h, MMX_ERR_BAD_ARG, "bad lamina parameters");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     h->P.use_lamina = 1;
@@ -1093,9 +1099,9 @@ int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre
     h->P.cy = centre[1];
     h->P.cz = centre[2];
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w) {
+int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w) try {
     if (!h || !centre || !w) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     HIPCHK(h, hipSetDevice(h->device));
@@ -1108,9 +1114,9 @@ int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], cons
     h->P.cy = centre[1];
     h->P.cz = centre[2];
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom) {
+int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom) try {
     if (!h || !chrom) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     if ((h->n + 255) / 256 > kPartStride) return fail(h, MMX_ERR_BAD_ARG, "too many beads for the chromosomal-block kernel");
@@ -1144,9 +1150,9 @@ int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t 
     h->P.chb_kc = k_C;
     h->P.chb_de = dE;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form) {
+int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form) try {
     if (!h) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false;
     static const int n_forms[MMX_N_SELECTORS] = {2, 3, 3, 3, 4, 3, 3}; // EV, COB, SCB, CHB, LAMINA, CENTRAL, LOOPS
@@ -1154,9 +1160,9 @@ int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form) {
     if (form < 0 || form >= n_forms[selector]) return fail(h, MMX_ERR_BAD_ARG, "unknown functional form for this term");
     h->forms[selector] = form;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_disable_term(mmx_handle h, int32_t term) {
+int mmx_disable_term(mmx_handle h, int32_t term) try {
     if (!h) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     switch (term) {
@@ -1172,9 +1178,9 @@ int mmx_disable_term(mmx_handle h, int32_t term) {
     default: return fail(h, MMX_ERR_BAD_ARG, "unknown term");
     }
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_option(mmx_handle h, const char *key, double value) {
+int mmx_set_option(mmx_handle h, const char *key, double value) try {
     if (!h || !key) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
     const std::string k(key);
@@ -1184,9 +1190,9 @@ int mmx_set_option(mmx_handle h, const char *key, double value) {
     else if (k == "nb_variant") h->nb_variant = (int)value;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_get_option(mmx_handle h, const char *key, double *value) {
+int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     if (!h || !key || !value) return MMX_ERR_BAD_ARG;
     const std::string k(key);
     if (k == "deterministic") *value = h->deterministic;
@@ -1195,9 +1201,9 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) {
     else if (k == "nb_variant") *value = h->nb_variant;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
+int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) try {
     if (!h) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false;
     int rc = prepare(h);
@@ -1220,9 +1226,9 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) {
     const double f = h->st_host->ftrial;
     if (!(f - f == 0.0)) return fail(h, MMX_ERR_NAN, "non-finite energy");
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) {
+int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) try {
     if (!h || max_iters < 0 || !(tolerance >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad minimize arguments");
     h->md_forces_valid = false;
     int rc = prepare(h);
@@ -1295,7 +1301,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     if (out) *out = local;
     if (s.status == MMX_MIN_NAN) return fail(h, MMX_ERR_NAN, "non-finite energy during minimization");
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 // ---- molecular dynamics ---------------------------------------------------------------
 static const double kBoltz = 0.008314462618; // kJ/(mol K), the constant of model.py:967
@@ -1324,7 +1330,7 @@ static void md_refresh(mmx_handle_s *h) {
 }
 
 int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temperature_K, double friction_per_ps,
-                     double mass_amu, uint64_t seed) {
+                     double mass_amu, uint64_t seed) try {
     if (!h) return MMX_ERR_BAD_ARG;
     if (integrator < MMX_INT_LANGEVIN || integrator > MMX_INT_BROWNIAN)
         return fail(h, MMX_ERR_BAD_ARG, "integrator must be MMX_INT_LANGEVIN, MMX_INT_VERLET or MMX_INT_BROWNIAN");
@@ -1348,9 +1354,9 @@ int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temp
     h->md_forces_valid = false;
     md_refresh(h);
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uint64_t seed) {
+int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uint64_t seed) try {
     if (!h || !(temperature_K >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad temperature");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1360,26 +1366,26 @@ int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uin
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_set_velocities(mmx_handle h, const float *vel) {
+int mmx_set_velocities(mmx_handle h, const float *vel) try {
     if (!h || !vel) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(h->v, vel + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyHostToDevice));
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_get_velocities(mmx_handle h, float *vel) {
+int mmx_get_velocities(mmx_handle h, float *vel) try {
     if (!h || !vel) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(vel + (size_t)3 * h->own_lo, h->v, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) {
+int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     if (!h || n_steps < 0) return fail(h, MMX_ERR_BAD_ARG, "bad step count");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     int rc = prepare(h);
@@ -1436,9 +1442,9 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) {
         out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
-int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) {
+int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) try {
     if (!h || reps < 1 || !mean_us) return fail(h, MMX_ERR_BAD_ARG, "bad arguments");
     h->md_forces_valid = false;
     if (kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE)
@@ -1518,7 +1524,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
     *mean_us = (double)ms * 1e3 / reps;
     if (algorithmic_bytes) *algorithmic_bytes = bytes;
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 // Census of the pair work at the current positions (diagnostics for DESIGN.md / bench): one thread
 // per bead walks its 27-cell stencil.
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float
 }
 
 int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidate, double *tiles_accepted,
-                       double *beads_swept) {
+                       double *beads_swept) try {
     if (!h) return MMX_ERR_BAD_ARG;
     int rc = prepare(h);
     if (rc) return rc;
@@ -1628,10 +1634,10 @@ int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidat
     if (tiles_accepted) *tiles_accepted = res[1];
     if (beads_swept) *beads_swept = res[2];
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double *cell_edge, double *pair_candidates,
-                  double *pairs_within_cutoff) {
+                  double *pairs_within_cutoff) try {
     if (!h) return MMX_ERR_BAD_ARG;
     int rc = prepare(h);
     if (rc) return rc;
@@ -1654,6 +1660,6 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
     if (pair_candidates) *pair_candidates = res[0];
     if (pairs_within_cutoff) *pairs_within_cutoff = res[1] - (double)h->n; // minus self pairs
     return MMX_OK;
-}
+} MMX_CATCH(h)
 
 } // extern "C"
