@@ -50,6 +50,8 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 static bool load_rccl(std::string &err) {
+    static std::mutex mu; // handles may be driven from several threads (one per rank in loopback runs)
+    std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.lib) return true;
     void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -300,7 +302,6 @@ void prof_collect(mmx_handle_s *h, mmx_stats *out) {
 template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
-    const bool rank2 = h->has_cob && !h->has_scb; // amplitude table = Ea*[A][A] + Eb*[B][B] only
 #define NBJ(PM, EV, GA, SC, OPT)                                                                            \
     hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
                        h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part)
@@ -456,6 +457,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
+    const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h) && mode != PACK_MD;
     if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
         MdParams M = h->md;
         M.step_lo = (uint32_t)h->md_step;
@@ -467,6 +469,14 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
         else if (h->md_kind == MD_VERLET) MDP(MD_VERLET);
         else MDP(MD_BROWNIAN);
 #undef MDP
+    } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
+        GridParams *cur = h->grid + (h->build_idx & 1);
+        if (mode == PACK_MOVE)
+            hipLaunchKernelGGL((k_pack<true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
+                               h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
+        else
+            hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
+                               h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
     } else if (mode == PACK_MOVE)
         hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
@@ -481,8 +491,9 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
         if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
             hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
                                dd ? hm : 0.f, cur, h->st);
-        hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4, cur,
-                           h->cell_of, h->rank_in_cell, h->count, h->st);
+        if (!fuse_count)
+            hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
+                               cur, h->cell_of, h->rank_in_cell, h->count, h->st);
         hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox_part, gb, hm,
                            h->maxcells, h->count, h->start, h->istart, h->cstart, cur, next, h->st);
         hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,

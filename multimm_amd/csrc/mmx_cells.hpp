@@ -5,13 +5,39 @@
 
 namespace mmx {
 
+// Slot of a bead inside its cell: group the lanes of the wave by cell with ballots only (no memory traffic inside
+// the loop), then let the first lane of every group issue its atomicAdd in ONE instruction -- one round trip per
+// wave instead of one per distinct cell (Hilbert-ordered beads: ~3 distinct cells per wave).  Whole wave must call.
+__device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long pending = __ballot(todo), mine = 0ull;
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int c0 = __shfl(c, leader, 64);
+        const unsigned long long same = __ballot(todo && c == c0);
+        if (todo && c == c0) mine = same;
+        pending &= ~same;
+    }
+    const int first = todo ? __ffsll((long long)mine) - 1 : lane;
+    int base = 0;
+    if (todo && lane == first) base = atomicAdd(&count[c], __popcll(mine));
+    base = __shfl(base, first, 64);
+    if (todo) rank[i] = base + __popcll(mine & lt);
+}
+
 // x = xp + step*d (MOVE) or x as given; builds pos4 = {x,y,z, bits((bead<<3)|(label+2))} and the bbox.
 // One thread per bead.  Algorithmic traffic: read 12(+24 when MOVE) B, write 16(+12) B per bead.
-template <bool MOVE>
+// COUNT (single-GPU runs): the cell assignment of k_cell_count is done here as well -- the grid of this build
+// was fixed by the previous build's scan, so nothing between the two kernels is needed and one launch goes away.
+template <bool MOVE, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__restrict__ x,
                                               const float *__restrict__ xp, const float *__restrict__ d,
                                               const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
-                                              float *__restrict__ bbox_part, const MinState *__restrict__ st) {
+                                              float *__restrict__ bbox_part, const MinState *__restrict__ st,
+                                              const GridParams *__restrict__ grid = nullptr,
+                                              int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
+                                              int *__restrict__ count = nullptr) {
     if (st->phase == PH_DONE) return;
     __shared__ float s_bb[6][4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
@@ -34,6 +60,16 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__re
         const int bead = own_lo + i;
         const int w = (bead << 3) | ((int)labels[bead] + 2);
         pos4[bead] = make_float4(px, py, pz, __int_as_float(w));
+    }
+    if (COUNT) { // own_lo == 0 and n_own == n_all here: every bead is owned
+        const GridParams G = *grid;
+        int c = 0;
+        if (act) {
+            c = (cell_coord(pz, G.oz, G.inv_h, G.nz) * G.ny + cell_coord(py, G.oy, G.inv_h, G.ny)) * G.nx +
+                cell_coord(px, G.ox, G.inv_h, G.nx);
+            cell_of[i] = c;
+        }
+        cell_rank(act, c, i, rank, count);
     }
     // Block bounding box -> bbox_part[k][block] (k = minx,miny,minz,maxx,maxy,maxz); no atomics.
     const float big = 3.0e38f;
@@ -119,7 +155,6 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
     if (st->phase == PH_DONE) return;
     const GridParams G = *grid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
     bool todo = i < n_all;
     int c = 0;
     if (todo) {
@@ -138,21 +173,7 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
         }
         cell_of[i] = todo ? c : -1;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned long long pending = __ballot(todo);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int c0 = __shfl(c, leader, 64);
-        const unsigned long long same = __ballot(todo && c == c0);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&count[c0], __popcll(same));
-        base = __shfl(base, leader, 64);
-        if (todo && c == c0) {
-            rank[i] = base + __popcll(same & lt);
-            todo = false;
-        }
-        pending &= ~same;
-    }
+    cell_rank(todo, c, i, rank, count);
 }
 
 // Single-block exclusive scan of the cell populations (bead offsets) and of the per-cell chunk
@@ -181,27 +202,50 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bb
         sc += (k + 7) >> 3;
         mx = max(mx, k);
     }
-    s_a[t] = sa;
-    s_b[t] = sb;
-    s_c[t] = sc;
     mx = wave_max_i(mx);
     if ((t & 63) == 0) s_m[t >> 6] = mx;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials.
-    for (int o = 1; o < 1024; o <<= 1) {
-        int va = 0, vb = 0, vc = 0;
-        if (t >= o) {
-            va = s_a[t - o];
-            vb = s_b[t - o];
-            vc = s_c[t - o];
+    // inclusive scan over the 1024 partials: shuffles inside each wave, then the 16 wave totals by wave 0
+    const int lane = t & 63, wave = t >> 6;
+    int ia = sa, ib = sb, ic = sc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64), uc = __shfl_up(ic, o, 64);
+        if (lane >= o) {
+            ia += ua;
+            ib += ub;
+            ic += uc;
         }
-        __syncthreads();
-        s_a[t] += va;
-        s_b[t] += vb;
-        s_c[t] += vc;
-        __syncthreads();
     }
-    int ra = s_a[t] - sa, rb = s_b[t] - sb, rcl = s_c[t] - sc; // exclusive prefixes
+    if (lane == 63) {
+        s_a[wave] = ia;
+        s_b[wave] = ib;
+        s_c[wave] = ic;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int wa = lane < 16 ? s_a[lane] : 0, wb = lane < 16 ? s_b[lane] : 0, wc = lane < 16 ? s_c[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int ua = __shfl_up(wa, o, 64), ub = __shfl_up(wb, o, 64), uc = __shfl_up(wc, o, 64);
+            if (lane >= o) {
+                wa += ua;
+                wb += ub;
+                wc += uc;
+            }
+        }
+        if (lane < 16) { // inclusive totals up to and including wave `lane`
+            s_a[32 + lane] = wa;
+            s_b[32 + lane] = wb;
+            s_c[32 + lane] = wc;
+        }
+    }
+    __syncthreads();
+    const int oa = wave ? s_a[32 + wave - 1] : 0, ob = wave ? s_b[32 + wave - 1] : 0, oc = wave ? s_c[32 + wave - 1] : 0;
+    const int tot_a = s_a[32 + 15], tot_b = s_b[32 + 15], tot_c = s_c[32 + 15];
+    ia += oa;
+    ib += ob;
+    ic += oc;
+    int ra = ia - sa, rb = ib - sb, rcl = ic - sc; // exclusive prefixes
     for (int c = c0; c < c1; ++c) {
         const int k = count[c];
         start[c] = ra;
@@ -212,14 +256,14 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bb
         rcl += (k + 7) >> 3;
     }
     if (t == 1023) {
-        start[G.ncells] = s_a[1023];
-        istart[G.ncells] = s_b[1023];
-        cstart[G.ncells] = s_c[1023];
-        st->n_clusters = s_c[1023];
+        start[G.ncells] = tot_a;
+        istart[G.ncells] = tot_b;
+        cstart[G.ncells] = tot_c;
+        st->n_clusters = tot_c;
         *grid_next = GN;
         int m = 0;
         for (int w = 0; w < 16; ++w) m = max(m, s_m[w]);
-        st->n_items = s_b[1023];
+        st->n_items = tot_b;
         st->ncells = G.ncells;
         st->max_per_cell = m;
         st->cell_edge = (double)G.h;
