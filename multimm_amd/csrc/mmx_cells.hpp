@@ -270,17 +270,6 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bb
     }
 }
 
-// Scatter bead ids into their cell's slice (arrival order; k_cell_order makes it canonical).
-__global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restrict__ cell_of,
-                                                   const int *__restrict__ rank, const int *__restrict__ start,
-                                                   int *__restrict__ perm, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_all) return;
-    const int c = cell_of[i];
-    if (c >= 0) perm[start[c] + rank[i]] = i;
-}
-
 // 12-bit Morton code of a position inside its cell (16 sub-cells per axis).
 __device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00d
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
@@ -298,12 +287,33 @@ __device__ __forceinline__ unsigned long long order_key(const float4 p, const Gr
     return (ghost << 63) | ((unsigned long long)m << 32) | (unsigned)bead;
 }
 
+// Scatter bead ids AND their 64-bit sort keys into their cell's slice (arrival order; k_cell_order makes it
+// canonical).  Writing the key here -- where the position is read coalesced by bead -- takes the perm -> pos4 gather
+// out of the latency chain of the per-cell sort.
+__global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restrict__ cell_of,
+                                                   const int *__restrict__ rank, const int *__restrict__ start,
+                                                   int *__restrict__ perm, unsigned long long *__restrict__ okeys,
+                                                   const float4 *__restrict__ pos4, const GridParams *__restrict__ grid,
+                                                   int own_lo, int n_own, const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    const GridParams G = *grid;
+    const int slot = start[c] + rank[i];
+    perm[slot] = i;
+    okeys[slot] = order_key(pos4[i], G, c % G.nx, (c / G.nx) % G.ny, c / (G.nx * G.ny), i, own_lo, n_own);
+}
+
 // Orders every cell's beads along a Morton curve of 16^3 sub-cells (ties by bead id: bitwise
 // reproducible summation order, and 8 consecutive entries form a spatially compact cluster), emits the
 // cell's work items {cell, chunk}, the padded cluster positions and cluster boxes and clears count for
 // the next build.  Two grid-stride passes in one launch: cells of <= 64 beads are sorted by ONE WAVE in
-// registers (bitonic over __shfl_xor); larger cells by the WHOLE BLOCK in LDS (bitonic, <= 4096 beads).
-constexpr int kOrderLds = 4096;
+// registers (bitonic over __shfl_xor); larger cells by the WHOLE BLOCK in LDS (bitonic, <= CAP beads).  CAP is
+// 1024 (8 KB of LDS: 8 blocks per CU, one cell per block in flight for ~2000 cells) when the largest cell of the
+// previous poll leaves >= 60 % headroom, else 4096; a cell above CAP keeps arrival order (still correct, not
+// bitwise reproducible) and is counted in st->order_fallbacks.
 
 // padded cluster positions + boxes of one sorted cell; `nthr` cooperating threads, thread index `tid`
 __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, const int *__restrict__ perm,
@@ -340,7 +350,7 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
     }
 }
 
-template <int CHUNK>
+template <int CHUNK, int CAP>
 __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
                                                     const int *__restrict__ start, const int *__restrict__ istart,
                                                     int *__restrict__ count,
@@ -348,9 +358,10 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const int *__restrict__ cstart,
                                                     const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
-                                                    int own_lo, int n_own, const MinState *__restrict__ st) {
+                                                    int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
+                                                    MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ unsigned long long s_buf[kOrderLds];
+    __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
     const int ncells = G.ncells;
@@ -366,10 +377,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         if (cnt > 1) {
             unsigned long long v = kmax;
-            if (lane < cnt) {
-                const int b = perm[s + lane];
-                v = order_key(pos4[b], G, cx, cy, cz, b, own_lo, n_own);
-            }
+            if (lane < cnt) v = okeys[s + lane];
 #pragma unroll
             for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
@@ -393,17 +401,12 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
         for (int k = threadIdx.x; k < nchunk; k += 256) items[ib + k] = make_int2(c, k);
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
-        if (cnt <= kOrderLds) {
+        if (cnt <= CAP) {
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
             __syncthreads(); // s_buf free
             for (int q = threadIdx.x; q < n2; q += 256) {
-                unsigned long long v = kmax;
-                if (q < cnt) {
-                    const int b = perm[s + q];
-                    v = order_key(pos4[b], G, cx, cy, cz, b, own_lo, n_own);
-                }
-                s_buf[q] = v;
+                s_buf[q] = q < cnt ? okeys[s + q] : kmax;
             }
             __syncthreads();
             // bitonic network; stages with j < 128 stay inside 128-element segments, each owned by one wave
@@ -443,7 +446,8 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             __threadfence_block();
             __syncthreads();
         }
-        // cells above kOrderLds beads keep arrival order (still correct, not bitwise reproducible)
+        else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
+        // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
         emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
     }
 }

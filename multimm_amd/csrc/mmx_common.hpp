@@ -81,6 +81,8 @@ struct MinState {
     int ncells, max_per_cell;
     int nan_seen;
     int n_clusters; // 8-bead clusters of the last cell build
+    int order_fallbacks; // cells too large for the in-LDS sort since the state was pushed (arrival order kept)
+    int pad0_;
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;

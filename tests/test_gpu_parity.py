@@ -115,6 +115,14 @@ def test_deterministic_bitwise():
             outs.append((et.copy(), F.copy()))
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
+    # a whole minimization is reproducible too, and no cell ever outgrew the in-LDS sort (the guarantee's condition)
+    runs = []
+    for _ in range(2):
+        with engine_for(s) as eng:
+            st = eng.minimize(tolerance=0.0, max_iters=80)
+            assert eng.get_option("order_fallbacks") == 0
+            runs.append((st.e_final, st.evaluations, eng.get_positions()))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and np.array_equal(runs[0][2], runs[1][2])
 
 
 def test_minimize_small_matches_oracle_quality():
@@ -308,6 +316,9 @@ def test_edge_cases_tiny_coincident_and_crowded():
     crowded = ChromatinSystem(n, rng.random((n, 3)) * 0.4, np.array([0, n]), rng.integers(-2, 3, n).astype(np.int8),
                               ff=ForceFieldParams(LE_USE_HARMONIC_BOND=False, COB_USE_COMPARTMENT_BLOCKS=True, NB_CUTOFF=0.6))
     _check(crowded, 0.6, "crowded: one cell")
+    with engine_for(crowded) as eng:   # 5000 beads in one cell: beyond the in-LDS sort, reported as such
+        eng.compute()
+        assert eng.get_option("order_fallbacks") >= 1
     sparse = ChromatinSystem(300, rng.random((300, 3)) * 40.0, np.array([0, 300]), np.zeros(300, np.int8),
                              ff=ForceFieldParams(LE_USE_HARMONIC_BOND=False, NB_CUTOFF=0.6))
     _check(sparse, 0.6, "sparse: one bead per cell")
