@@ -459,14 +459,21 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
-    const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h) && mode != PACK_MD;
+    const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h);
     if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
         MdParams M = h->md;
         M.step_lo = (uint32_t)h->md_step;
         M.step_hi = (uint32_t)(h->md_step >> 32);
 #define MDP(K)                                                                                              \
-    hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xlo,   \
-                       h->v, h->g, h->labels, h->pos4, h->bbox_part, M)
+    do {                                                                                                    \
+        if (fuse_count)                                                                                     \
+            hipLaunchKernelGGL((k_md_pack<K, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M,                      \
+                               h->grid + (h->build_idx & 1), h->cell_of, h->rank_in_cell, h->count);        \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,   \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M);                     \
+    } while (0)
         if (h->md_kind == MD_LANGEVIN) MDP(MD_LANGEVIN);
         else if (h->md_kind == MD_VERLET) MDP(MD_VERLET);
         else MDP(MD_BROWNIAN);

@@ -10,7 +10,7 @@
 // a bead at a step does not depend on the launch geometry or on how beads are split over GPUs.
 // (OpenMM's own generator cannot be reproduced bit-for-bit: trajectories agree with it in distribution only.)
 #pragma once
-#include "mmx_common.hpp"
+#include "mmx_cells.hpp"
 
 namespace mmx {
 
@@ -60,11 +60,14 @@ __device__ __forceinline__ void normal3(uint32_t bead, uint32_t step_lo, uint32_
 // reads the gradient of the current positions, advances v and x (x carried as hi + lo: a step moves a bead
 // by ~1e-5 nm while an fp32 ulp at 10 nm is 1e-6 nm), writes pos4 and the per-block bounding box.
 // Algorithmic traffic: read 12 B x + 12 B xlo + 12 B v + 12 B g + 1 B label, write 12+12+12+16 B = 101 B/bead.
-template <int KIND>
+template <int KIND, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *__restrict__ x, float *__restrict__ xlo,
                                                  float *__restrict__ v, const float *__restrict__ g,
                                                  const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
-                                                 float *__restrict__ bbox_part, const MdParams M) {
+                                                 float *__restrict__ bbox_part, const MdParams M,
+                                                 const GridParams *__restrict__ grid = nullptr,
+                                                 int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
+                                                 int *__restrict__ count = nullptr) {
     __shared__ float s_bb[6][4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n_own;
@@ -95,6 +98,16 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
             v[3 * i + k] = vel;
         }
         pos4[bead] = make_float4(p[0], p[1], p[2], __int_as_float((bead << 3) | ((int)labels[bead] + 2)));
+    }
+    if (COUNT) { // single GPU: cell assignment of k_cell_count fused in (see k_pack)
+        const GridParams G = *grid;
+        int c = 0;
+        if (act) {
+            c = (cell_coord(p[2], G.oz, G.inv_h, G.nz) * G.ny + cell_coord(p[1], G.oy, G.inv_h, G.ny)) * G.nx +
+                cell_coord(p[0], G.ox, G.inv_h, G.nx);
+            cell_of[i] = c;
+        }
+        cell_rank(act, c, i, rank, count);
     }
     const float big = 3.0e38f;
     const bool fin = act && fabsf(p[0]) < big && fabsf(p[1]) < big && fabsf(p[2]) < big;
