@@ -62,6 +62,34 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
     __syncthreads();
 }
 
+// Fold of the Gram-row partials: NQ rows of nblk (<= 256) block partials each, rows kPartStride apart.  Wave w
+// takes rows w, w+16, w+32: every lane issues all its loads (<= 4 per row) back to back -- one latency round for
+// the whole fold -- then three shuffle trees.  Fixed order => deterministic.  s_out valid after the barrier.
+template <int NQ>
+__device__ __forceinline__ void rows_sum(const double *__restrict__ rows, int nblk, double *s_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = wave + 16 * j;
+        if (r < NQ) {
+            const double *p = rows + (size_t)r * kPartStride;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k;
+                acc[j] += i < nblk ? p[i] : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = wave + 16 * j;
+        const double v = wave_sum(acc[j]);
+        if (r < NQ && lane == 0) s_out[r] = v;
+    }
+    __syncthreads();
+}
+
 // Line-search controller, run by ONE thread after every evaluation on the folded (and, in a multi-GPU
 // run, all-reduced) slot sums: exactly liblbfgs' line_search_backtracking with
 // LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE.  Every rank executes it on identical inputs.
@@ -344,12 +372,9 @@ __global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double 
                                                          MinState *__restrict__ st) {
     if (st->phase == PH_DONE || !st->accepted) return;
     constexpr int NQ = MMX_NROWS * MMX_NBASIS;
-    __shared__ double s_task[kMaxTasks];
+    static_assert(NQ <= 48, "rows_sum covers 3 rows per wave");
     __shared__ double s_rows[NQ];
-    __shared__ int s_n[NQ], s_first[NQ + 1];
-    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
-    __syncthreads();
-    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
+    rows_sum<NQ>(rows, nblk, s_rows); // nblk <= 256 (enqueue_accept)
     if (threadIdx.x != 0) return;
     coef_decide(st, s_rows);
 }
@@ -362,12 +387,8 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(int nblk, const double *__
         if (threadIdx.x <= NQ) st->rowsum[threadIdx.x] = 0.0;
         return;
     }
-    __shared__ double s_task[kMaxTasks];
     __shared__ double s_rows[NQ];
-    __shared__ int s_n[NQ], s_first[NQ + 1];
-    if (threadIdx.x < NQ) s_n[threadIdx.x] = nblk;
-    __syncthreads();
-    multi_slot_sum<NQ>(rows, kPartStride, s_n, s_task, s_first, s_rows);
+    rows_sum<NQ>(rows, nblk, s_rows);
     if (threadIdx.x < NQ) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
 }
 __global__ void k_direction_coef_decide(MinState *__restrict__ st) {
