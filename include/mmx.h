@@ -185,6 +185,8 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "profile"           k>0: HIP-event time every k-th launch of each kernel slot       0
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0
+ * "fused_bonded"      1: backbone + loops + confinement in one kernel (booked in the "confine"
+ *                     timing slot); 0: the three kernels separately (per-kernel timing)       1
  * "order_fallbacks"   (get only) cells of the last call that were too large for the in-LDS sort and
  *                     kept arrival order: 0 means the summation order was bitwise reproducible
  */

@@ -159,6 +159,7 @@ struct mmx_handle_s {
     // loops (CSR over beads carrying a loop end)
     int n_loops = 0, n_rows = 0;
     int *row_bead = nullptr, *row_start = nullptr, *partner = nullptr;
+    int *lstart = nullptr; // [n_own + 1] loop entries per owned bead (same partner / r0 arrays; fused bonded kernel)
     float *loop_r0 = nullptr;
     // all-pairs scratch
     float4 *fpart = nullptr;
@@ -180,7 +181,7 @@ struct mmx_handle_s {
     FormParams Q{};               // derived constants of the non-default forms (host copy)
     FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
     // options
-    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0;
+    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1;
     // profiling
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};
@@ -556,24 +557,12 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
     prof_end(h, on, ep);
 
     const int gb = grid_beads(h->n_own);
-    if (h->flags && (h->P.use_bond || h->P.use_angle)) {
-        on = prof_begin(h, MMX_K_BACKBONE, ep);
-        hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
-                           h->st);
-        prof_end(h, on, ep);
-        A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
-    }
-    if (h->n_rows > 0) {
-        const int gl = std::min((h->n_rows + 255) / 256, 1024);
-        on = prof_begin(h, MMX_K_LOOPS, ep);
-        hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
-                           h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
-        prof_end(h, on, ep);
-        A.nblk[P_LOOP] = gl;
-    }
-    if (h->P.use_chb && h->chrom_of) {
+    const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+    const bool loops_on = h->n_rows > 0 && h->lstart;
+    auto launch_chb = [&]() {
+        if (!(h->P.use_chb && h->chrom_of)) return;
         const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
-        on = prof_begin(h, MMX_K_CHB, ep);
+        bool onc = prof_begin(h, MMX_K_CHB, ep);
 #define CHB(F)                                                                                              \
     hipLaunchKernelGGL((k_chb<F>), dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,    \
                        h->chrom_hi, h->g, h->part, h->st)
@@ -581,13 +570,40 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
         else if (h->Q.chb_form == 1) CHB(1);
         else CHB(2);
 #undef CHB
-        prof_end(h, on, ep);
+        prof_end(h, onc, ep);
         A.nblk[P_CHB] = std::min(gc, kPartStride);
+    };
+    if (h->fused_bonded) {
+        // backbone + loops + confinement (+ line-search dots) in one pass; booked in the "confine" timing slot
+        launch_chb();
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL((k_bonded_fused<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4,
+                           bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w,
+                           h->g, h->d, h->part, h->st, h->Q.loop_form, h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
+    } else {
+        if (bb_on) {
+            on = prof_begin(h, MMX_K_BACKBONE, ep);
+            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                               h->st);
+            prof_end(h, on, ep);
+            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
+        }
+        if (h->n_rows > 0) {
+            const int gl = std::min((h->n_rows + 255) / 256, 1024);
+            on = prof_begin(h, MMX_K_LOOPS, ep);
+            hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
+                               h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
+            prof_end(h, on, ep);
+            A.nblk[P_LOOP] = gl;
+        }
+        launch_chb();
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
+                           h->part, h->st, h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
     }
-    on = prof_begin(h, MMX_K_CONFINE, ep);
-    hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
-                       h->part, h->st, h->Q.lam_form, h->Q.cf_form);
-    prof_end(h, on, ep);
     A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
 
     on = prof_begin(h, MMX_K_REDUCE, ep);
@@ -883,7 +899,7 @@ int mmx_destroy(mmx_handle h) try {
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
-                    (void *)h->lbox[1], (void *)h->okeys})
+                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
@@ -1042,9 +1058,9 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
             er0[q] = r0[l];
         }
     }
-    for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0})
+    for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0, (void *)h->lstart})
         if (p) (void)hipFree(p);
-    h->row_bead = h->row_start = h->partner = nullptr;
+    h->row_bead = h->row_start = h->partner = h->lstart = nullptr;
     h->loop_r0 = nullptr;
     h->n_rows = (int)row_bead.size();
     h->n_loops = n_loops;
@@ -1058,6 +1074,11 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
         HIPCHK(h, hipMemcpy(h->row_start, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->loop_r0, er0.data(), er0.size() * sizeof(float), hipMemcpyHostToDevice));
+        // the same entries addressed per owned bead (rows are in bead order): offsets for the fused bonded kernel
+        std::vector<int> lstart((size_t)h->n_own + 1, 0);
+        for (int li = 0; li < h->n_own; ++li) lstart[(size_t)li + 1] = lstart[li] + deg[h->own_lo + li];
+        HIPCHK(h, dalloc(&h->lstart, lstart.size()));
+        HIPCHK(h, hipMemcpy(h->lstart, lstart.data(), lstart.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     return MMX_OK;
 } MMX_CATCH(h)
@@ -1216,6 +1237,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "profile") h->profile = (int)value;
     else if (k == "poll_interval") h->poll_interval = std::max(1, (int)value);
     else if (k == "nb_variant") h->nb_variant = (int)value;
+    else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -1227,6 +1249,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "profile") *value = h->profile;
     else if (k == "poll_interval") *value = h->poll_interval;
     else if (k == "nb_variant") *value = h->nb_variant;
+    else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;

@@ -80,51 +80,58 @@ __device__ __forceinline__ float angle_forces(F3 pi, F3 pj, F3 pk, float th0, fl
 }
 
 // K3.  flags[i] bit0: bond (i,i+1) present, bit1: angle (i,i+1,i+2) present.
+// Per-bead gather of the <= 2 bonds and <= 3 angles bead i takes part in; (gx,gy,gz) receive dE/dx_i, the bead
+// books the energy of the bond / angle it starts.  Neighbours i-2..i+2 may belong to other ranks: pos4 holds all.
+__device__ __forceinline__ void backbone_bead(const FFParams &P, const float4 *__restrict__ pos4,
+                                              const uint8_t *__restrict__ flags, int i, double &eb, double &ea,
+                                              float &gx, float &gy, float &gz) {
+    const int n = P.n;
+    const int f0 = flags[i];
+    const int fm1 = i >= 1 ? flags[i - 1] : 0;
+    const int fm2 = i >= 2 ? flags[i - 2] : 0;
+    const F3 p0 = f3(pos4[i]);
+    F3 pm1 = p0, pm2 = p0, pp1 = p0, pp2 = p0;
+    if (i >= 1) pm1 = f3(pos4[i - 1]);
+    if (i >= 2) pm2 = f3(pos4[i - 2]);
+    if (i + 1 < n) pp1 = f3(pos4[i + 1]);
+    if (i + 2 < n) pp2 = f3(pos4[i + 2]);
+    if (P.use_bond) {
+        if (fm1 & 1) (void)bond_grad(p0, pm1, P.bond_r0, P.bond_k, gx, gy, gz);
+        if (f0 & 1) eb += (double)bond_grad(p0, pp1, P.bond_r0, P.bond_k, gx, gy, gz);
+    }
+    if (P.use_angle) {
+        F3 fi, fk;
+        if (fm2 & 2) { // angle (i-2,i-1,i): this bead is the k end
+            (void)angle_forces(pm2, pm1, p0, P.ang_th0, P.ang_k, fi, fk);
+            gx -= fk.x;
+            gy -= fk.y;
+            gz -= fk.z;
+        }
+        if (fm1 & 2) { // angle (i-1,i,i+1): this bead is the middle
+            (void)angle_forces(pm1, p0, pp1, P.ang_th0, P.ang_k, fi, fk);
+            gx += fi.x + fk.x;
+            gy += fi.y + fk.y;
+            gz += fi.z + fk.z;
+        }
+        if (f0 & 2) { // angle (i,i+1,i+2): this bead is the i end; it also owns the energy
+            ea += (double)angle_forces(p0, pp1, pp2, P.ang_th0, P.ang_k, fi, fk);
+            gx -= fi.x;
+            gy -= fi.y;
+            gz -= fi.z;
+        }
+    }
+}
+
 // Algorithmic traffic: read 12 B position + 1 B flag, read-modify-write 12 B gradient = 25 B/bead (+12 RMW read).
 __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4 *__restrict__ pos4,
                                                   const uint8_t *__restrict__ flags, float *__restrict__ g,
                                                   double *__restrict__ part, const MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ double s_w[4];
-    const int n = P.n;
     double eb = 0.0, ea = 0.0;
     for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
-        const int i = P.own_lo + li; // neighbours i-2..i+2 may belong to other ranks: pos4 holds every bead
-        const int f0 = flags[i];
-        const int fm1 = i >= 1 ? flags[i - 1] : 0;
-        const int fm2 = i >= 2 ? flags[i - 2] : 0;
-        const F3 p0 = f3(pos4[i]);
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        F3 pm1 = p0, pm2 = p0, pp1 = p0, pp2 = p0;
-        if (i >= 1) pm1 = f3(pos4[i - 1]);
-        if (i >= 2) pm2 = f3(pos4[i - 2]);
-        if (i + 1 < n) pp1 = f3(pos4[i + 1]);
-        if (i + 2 < n) pp2 = f3(pos4[i + 2]);
-        if (P.use_bond) {
-            if (fm1 & 1) (void)bond_grad(p0, pm1, P.bond_r0, P.bond_k, gx, gy, gz);
-            if (f0 & 1) eb += (double)bond_grad(p0, pp1, P.bond_r0, P.bond_k, gx, gy, gz);
-        }
-        if (P.use_angle) {
-            F3 fi, fk;
-            if (fm2 & 2) { // angle (i-2,i-1,i): this bead is the k end
-                (void)angle_forces(pm2, pm1, p0, P.ang_th0, P.ang_k, fi, fk);
-                gx -= fk.x;
-                gy -= fk.y;
-                gz -= fk.z;
-            }
-            if (fm1 & 2) { // angle (i-1,i,i+1): this bead is the middle
-                (void)angle_forces(pm1, p0, pp1, P.ang_th0, P.ang_k, fi, fk);
-                gx += fi.x + fk.x;
-                gy += fi.y + fk.y;
-                gz += fi.z + fk.z;
-            }
-            if (f0 & 2) { // angle (i,i+1,i+2): this bead is the i end; it also owns the energy
-                ea += (double)angle_forces(p0, pp1, pp2, P.ang_th0, P.ang_k, fi, fk);
-                gx -= fi.x;
-                gy -= fi.y;
-                gz -= fi.z;
-            }
-        }
+        backbone_bead(P, pos4, flags, P.own_lo + li, eb, ea, gx, gy, gz);
         g[3 * li] += gx;
         g[3 * li + 1] += gy;
         g[3 * li + 2] += gz;
@@ -166,6 +173,75 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
 // (model.py:584-586) on r = |x - centre|; afterwards the gradient of bead i is final, so the kernel
 // also produces the three reductions the line search needs: g.d, g.g, x.x.
 // Algorithmic traffic: read 16 B pos4, read-modify-write 12 B gradient (+12 B d when DOTS).
+// External terms of one bead (container, lamina in form lam_form, central force in form cf_form, weight w_i) on
+// r = |x - centre|: energies into (ec, el, ef), dE/dx added to (gx,gy,gz).
+__device__ __forceinline__ void confine_bead(const FFParams &P, const float4 p, const float w_i, const int lam_form,
+                                             const int cf_form, double &ec, double &el, double &ef, float &gx,
+                                             float &gy, float &gz) {
+    const float dx = p.x - P.cx, dy = p.y - P.cy, dz = p.z - P.cz;
+    const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    const float r = r2 * rinv;
+    float dEdr = 0.f;
+    if (P.use_container) {
+        const float o = fmaxf(r - P.sc_R2, 0.f), in = fmaxf(P.sc_R1 - r, 0.f);
+        ec += (double)(P.sc_C * (o * o + in * in));
+        dEdr += 2.f * P.sc_C * (o - in);
+    }
+    if (P.use_lamina) {
+        const int s = (__float_as_int(p.w) & 7) - 2;
+        if (s < 0) {
+            const float span = P.ibl_R2 - P.ibl_R1;
+            if (lam_form == 0) { // sin^8 shell, model.py:503-505
+                const float w = 3.14159265358979f / span;
+                float sn, cs;
+                sincosf(w * (r - P.ibl_R1), &sn, &cs);
+                const float s2 = sn * sn, s4 = s2 * s2;
+                el += (double)(P.ibl_B * (s4 * s4 - 1.f));
+                dEdr += P.ibl_B * 8.f * s4 * s2 * sn * cs * w;
+            } else if (lam_form == 1) { // gaussian_shell, sigma = 0.1 (R2-R1), model.py:511-518
+                const float is2 = 100.f / (span * span);
+                const float a = r - P.ibl_R1, b = r - P.ibl_R2;
+                const float e1 = __expf(-0.5f * a * a * is2), e2 = __expf(-0.5f * b * b * is2);
+                el += (double)(-P.ibl_B * (e1 + e2));
+                dEdr += P.ibl_B * is2 * (a * e1 + b * e2);
+            } else if (lam_form == 2) { // harmonic_shell, r0 = (R1+R2)/2, model.py:521-528
+                const float u = r - 0.5f * (P.ibl_R1 + P.ibl_R2);
+                el += (double)(P.ibl_B * u * u);
+                dEdr += 2.f * P.ibl_B * u;
+            } else { // logistic_shell, lambda = 0.05 (R2-R1), model.py:531-539
+                const float il = 20.f / span;
+                const float a = 1.f / (1.f + __expf((r - P.ibl_R2) * il));
+                const float b = 1.f / (1.f + __expf(-(r - P.ibl_R1) * il));
+                el += (double)(-P.ibl_B * (a + b));
+                dEdr += -P.ibl_B * il * (b * (1.f - b) - a * (1.f - a));
+            }
+        }
+    }
+    if (P.use_central) {
+        const float gw = P.cf_G * w_i;
+        if (cf_form == 0) { // harmonic, model.py:579-586
+            const float q = r - P.cf_R1;
+            ef += (double)(gw * q * q);
+            dEdr += 2.f * gw * q;
+        } else if (cf_form == 1) { // gaussian, sigma = R1/2, model.py:591-599
+            const float is2 = 4.f / (P.cf_R1 * P.cf_R1);
+            const float e1 = __expf(-0.5f * r2 * is2);
+            ef += (double)(-gw * e1);
+            dEdr += gw * r * is2 * e1;
+        } else { // logistic, lambda = 0.2 R1, model.py:604-612
+            const float il = 5.f / P.cf_R1;
+            const float a = 1.f / (1.f + __expf((r - P.cf_R1) * il));
+            ef += (double)(-gw * a);
+            dEdr += gw * il * a * (1.f - a);
+        }
+    }
+    const float s = dEdr * rinv; // r == 0 => (dx,dy,dz) == 0 => zero gradient
+    gx = fmaf(s, dx, gx);
+    gy = fmaf(s, dy, gy);
+    gz = fmaf(s, dz, gz);
+}
+
 template <bool DOTS>
 __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 *__restrict__ pos4,
                                                  const float *__restrict__ cf_w, float *__restrict__ g,
@@ -180,68 +256,7 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
         const float4 p = pos4[P.own_lo + i];
         float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
         if (any) {
-            const float dx = p.x - P.cx, dy = p.y - P.cy, dz = p.z - P.cz;
-            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-            const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
-            const float r = r2 * rinv;
-            float dEdr = 0.f;
-            if (P.use_container) {
-                const float o = fmaxf(r - P.sc_R2, 0.f), in = fmaxf(P.sc_R1 - r, 0.f);
-                ec += (double)(P.sc_C * (o * o + in * in));
-                dEdr += 2.f * P.sc_C * (o - in);
-            }
-            if (P.use_lamina) {
-                const int s = (__float_as_int(p.w) & 7) - 2;
-                if (s < 0) {
-                    const float span = P.ibl_R2 - P.ibl_R1;
-                    if (lam_form == 0) { // sin^8 shell, model.py:503-505
-                        const float w = 3.14159265358979f / span;
-                        float sn, cs;
-                        sincosf(w * (r - P.ibl_R1), &sn, &cs);
-                        const float s2 = sn * sn, s4 = s2 * s2;
-                        el += (double)(P.ibl_B * (s4 * s4 - 1.f));
-                        dEdr += P.ibl_B * 8.f * s4 * s2 * sn * cs * w;
-                    } else if (lam_form == 1) { // gaussian_shell, sigma = 0.1 (R2-R1), model.py:511-518
-                        const float is2 = 100.f / (span * span);
-                        const float a = r - P.ibl_R1, b = r - P.ibl_R2;
-                        const float e1 = __expf(-0.5f * a * a * is2), e2 = __expf(-0.5f * b * b * is2);
-                        el += (double)(-P.ibl_B * (e1 + e2));
-                        dEdr += P.ibl_B * is2 * (a * e1 + b * e2);
-                    } else if (lam_form == 2) { // harmonic_shell, r0 = (R1+R2)/2, model.py:521-528
-                        const float u = r - 0.5f * (P.ibl_R1 + P.ibl_R2);
-                        el += (double)(P.ibl_B * u * u);
-                        dEdr += 2.f * P.ibl_B * u;
-                    } else { // logistic_shell, lambda = 0.05 (R2-R1), model.py:531-539
-                        const float il = 20.f / span;
-                        const float a = 1.f / (1.f + __expf((r - P.ibl_R2) * il));
-                        const float b = 1.f / (1.f + __expf(-(r - P.ibl_R1) * il));
-                        el += (double)(-P.ibl_B * (a + b));
-                        dEdr += -P.ibl_B * il * (b * (1.f - b) - a * (1.f - a));
-                    }
-                }
-            }
-            if (P.use_central) {
-                const float gw = P.cf_G * cf_w[P.own_lo + i];
-                if (cf_form == 0) { // harmonic, model.py:579-586
-                    const float q = r - P.cf_R1;
-                    ef += (double)(gw * q * q);
-                    dEdr += 2.f * gw * q;
-                } else if (cf_form == 1) { // gaussian, sigma = R1/2, model.py:591-599
-                    const float is2 = 4.f / (P.cf_R1 * P.cf_R1);
-                    const float e1 = __expf(-0.5f * r2 * is2);
-                    ef += (double)(-gw * e1);
-                    dEdr += gw * r * is2 * e1;
-                } else { // logistic, lambda = 0.2 R1, model.py:604-612
-                    const float il = 5.f / P.cf_R1;
-                    const float a = 1.f / (1.f + __expf((r - P.cf_R1) * il));
-                    ef += (double)(-gw * a);
-                    dEdr += gw * il * a * (1.f - a);
-                }
-            }
-            const float s = dEdr * rinv; // r == 0 => (dx,dy,dz) == 0 => zero gradient
-            gx = fmaf(s, dx, gx);
-            gy = fmaf(s, dy, gy);
-            gz = fmaf(s, dz, gz);
+            confine_bead(P, p, P.use_central ? cf_w[P.own_lo + i] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
             g[3 * i] = gx;
             g[3 * i + 1] = gy;
             g[3 * i + 2] = gz;
@@ -270,6 +285,67 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
             part[P_GG * kPartStride + blockIdx.x] = s2;
             part[P_XX * kPartStride + blockIdx.x] = s3;
         }
+    }
+}
+
+// K3 + K4 + K5 in ONE pass over the owned beads (default; the separate kernels above stay selectable with the
+// option "fused_bonded" = 0 and are what mmx_time_kernel measures): one read-modify-write of the gradient instead
+// of three, two launches fewer per evaluation.  Same per-bead arithmetic and the same order of the fp32 additions
+// (g + backbone + loops, then the confinement terms), so the result is bitwise the one of the separate kernels.
+// lstart[li] .. lstart[li+1]: loop entries (partner, r0) of owned bead li in the CSR of mmx_set_loops.
+template <bool DOTS>
+__global__ __launch_bounds__(256) void k_bonded_fused(const FFParams P, const float4 *__restrict__ pos4,
+                                                      const uint8_t *__restrict__ flags, const int *__restrict__ lstart,
+                                                      const int *__restrict__ partner, const float *__restrict__ r0,
+                                                      const float *__restrict__ cf_w, float *__restrict__ g,
+                                                      const float *__restrict__ d, double *__restrict__ part,
+                                                      const MinState *__restrict__ st, const int loop_form,
+                                                      const int lam_form, const int cf_form) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    double eb = 0.0, ea = 0.0, elp = 0.0, ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
+    const bool bb = flags != nullptr && (P.use_bond | P.use_angle);
+    const bool any = P.use_container | P.use_lamina | P.use_central;
+    for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
+        const int i = P.own_lo + li;
+        const float4 p = pos4[i];
+        float gx = g[3 * li], gy = g[3 * li + 1], gz = g[3 * li + 2];
+        if (bb) {
+            float tx = 0.f, ty = 0.f, tz = 0.f;
+            backbone_bead(P, pos4, flags, i, eb, ea, tx, ty, tz);
+            gx += tx;
+            gy += ty;
+            gz += tz;
+        }
+        if (lstart) {
+            const int q0 = lstart[li], q1 = lstart[li + 1];
+            if (q1 > q0) {
+                const F3 pb = f3(p);
+                float tx = 0.f, ty = 0.f, tz = 0.f;
+                for (int q = q0; q < q1; ++q)
+                    elp += 0.5 * (double)loop_grad(loop_form, pb, f3(pos4[partner[q]]), r0[q], P.loop_k, tx, ty, tz);
+                gx += tx;
+                gy += ty;
+                gz += tz;
+            }
+        }
+        if (any) confine_bead(P, p, P.use_central ? cf_w[i] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
+        g[3 * li] = gx;
+        g[3 * li + 1] = gy;
+        g[3 * li + 2] = gz;
+        if (DOTS) {
+            const float d0 = d[3 * li], d1 = d[3 * li + 1], d2 = d[3 * li + 2];
+            gd += (double)gx * d0 + (double)gy * d1 + (double)gz * d2;
+            gg += (double)gx * gx + (double)gy * gy + (double)gz * gz;
+            xx += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
+        }
+    }
+    const double v[9] = {eb, ea, elp, ec, el, ef, gd, gg, xx};
+    const int slot[9] = {P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT, P_GD, P_GG, P_XX};
+#pragma unroll
+    for (int k = 0; k < (DOTS ? 9 : 6); ++k) {
+        const double r = block_sum<256>(v[k], s_w);
+        if (threadIdx.x == 0) part[slot[k] * kPartStride + blockIdx.x] = r;
     }
 }
 

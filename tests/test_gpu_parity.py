@@ -384,3 +384,19 @@ def test_shipped_genome_wide_example_settings_run(tmp_path):
     for t in (0, 1, 2, 5, 6, 7, 8):  # ev, scb gaussians, bonds, container, lamina, central, chb
         assert et[t] != 0.0, TERM_NAMES[t]
     print(f"config_gw-like 500k: {st.iterations} iterations in {st.seconds:.2f} s")
+
+
+def test_fused_bonded_kernel_equals_separate_kernels_bitwise():
+    """Default = backbone + loops + confinement in one kernel; option fused_bonded = 0 runs the three kernels one
+    after the other.  Same per-bead arithmetic in the same order: forces and per-term energies are bit-identical,
+    and so is a whole minimization."""
+    s = synthetic_system("gw_200k", n_beads=20000, jitter=0.03, seed=6, CHB_USE_CHROMOSOMAL_BLOCKS=False, **ALL_ON)
+    res = []
+    for fused in (1, 0):
+        with engine_for(s) as eng:
+            eng.set_option("fused_bonded", fused)
+            et, F = eng.compute()
+            st = eng.minimize(tolerance=0.0, max_iters=60)
+            res.append((et.copy(), F.copy(), st.e_final, st.evaluations, eng.get_positions()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and np.array_equal(res[0][4], res[1][4])
