@@ -173,6 +173,11 @@ def main():
                 roofline["valu_view"] = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                          "frac": tf / VALU_PEAK_TFLOPS, "pairs_within_cutoff": pairs,
                                          "pair_candidates": census["pair_candidates"]}
+                if n == 200000:  # issue-slot occupancy of the same kernel from the committed PMC pass
+                    try:
+                        roofline["valu_view"]["issue"] = json.load(open(os.path.join(ROOT, "profiles", "nb_valu.json")))
+                    except Exception:
+                        pass
         kern = {k: v for k, v in d["kernel_us_mean"].items() if v}
         # default: backbone + loops + confinement run as ONE kernel booked under "confine" (sum of the three
         # kernels' algorithmic bytes); --separate-bonded times them individually
