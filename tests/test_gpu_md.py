@@ -74,6 +74,23 @@ def test_short_trajectory_matches_restatement(kind, dt, friction):
     assert abs(st.temperature - sr.temperature) <= 1e-4 * sr.temperature + 1e-6
 
 
+def test_md_with_exact_all_pairs_forces():
+    """NB_CUTOFF <= 0 (the reference's NoCutoff semantics): MD on the all-pairs kernel, against the restatement."""
+    from oracle.oracle import Oracle, md_velocities
+    s = _relaxed(n=1500, iters=150, NB_CUTOFF=0.0)
+    v0 = md_velocities(s.n_beads, 310.0, BEAD_MASS_AMU, 3).astype(np.float32)
+    with engine_for(s) as eng:
+        eng.md_configure("langevin", dt_ps=0.01, seed=5)
+        eng.set_velocities(v0)
+        st = eng.md_step(40)
+        x = eng.get_positions().astype(np.float64)
+    xr, vr, sr = Oracle(s).md_step(s.positions, v0.astype(np.float64), 40, kind="langevin", dt=0.01, seed=5,
+                                   mass=BEAD_MASS_AMU)
+    travelled = np.abs(xr - s.positions).max()
+    assert np.abs(x - xr).max() <= 2e-6 + 1e-3 * travelled
+    assert abs(st.kinetic - sr.kinetic) <= 1e-4 * sr.kinetic
+
+
 def test_step_calls_compose_bitwise():
     """step(20) == step(7) + step(13): the step counter indexes the noise, forces are cached between calls."""
     s = _relaxed(n=3000, iters=100)
