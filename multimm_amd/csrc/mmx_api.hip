@@ -392,6 +392,8 @@ __global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const f
 
 enum PackMode { PACK_PLAIN = 0, PACK_MOVE = 1, PACK_MD = 2 };
 
+DirArgs dir_args(const mmx_handle_s *h) { return DirArgs{h->g, h->gp, h->S, h->Y, (size_t)h->n4 * 4}; }
+
 
 bool has_comm(const mmx_handle_s *h) { return h->comm != nullptr || h->lcomm != nullptr; }
 
@@ -481,15 +483,17 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
 #undef MDP
     } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
         GridParams *cur = h->grid + (h->build_idx & 1);
-        if (mode == PACK_MOVE)
-            hipLaunchKernelGGL((k_pack<true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
-                               h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
+        if (mode == PACK_MOVE) // trial move of the minimizer: also forms the new direction after an accepted step
+            hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+                               h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
+                               h->count, dir_args(h));
         else
             hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
                                h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
     } else if (mode == PACK_MOVE)
-        hipLaunchKernelGGL((k_pack<true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
-                           h->labels, h->pos4, h->bbox_part, h->st);
+        hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+                           h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h));
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
@@ -617,10 +621,9 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
     prof_end(h, on, ep);
 }
 
-// History update + direction; every kernel is a no-op unless the controller accepted the step.
+// History update + direction coefficients; every kernel is a no-op unless the controller accepted the step.
 void enqueue_accept(mmx_handle_s *h) {
     EventPair ep{};
-    const int g4 = std::min((h->n4 + 255) / 256, 1024);
     bool on = prof_begin(h, MMX_K_LBFGS, ep);
     const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
     hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
@@ -633,9 +636,7 @@ void enqueue_accept(mmx_handle_s *h) {
         coll_allreduce(h, h->st->rowsum, MMX_NROWS * MMX_NBASIS + 1);
         hipLaunchKernelGGL(k_direction_coef_decide, dim3(1), dim3(64), 0, h->stream, h->st);
     }
-    hipLaunchKernelGGL(k_direction, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x, (float4 *)h->xp,
-                       (const float4 *)h->g, (float4 *)h->gp, (const float4 *)h->S, (const float4 *)h->Y,
-                       (float4 *)h->d, h->st);
+    // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
     prof_end(h, on, ep);
 }
 

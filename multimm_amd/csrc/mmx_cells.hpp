@@ -30,25 +30,83 @@ __device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restri
 // One thread per bead.  Algorithmic traffic: read 12(+24 when MOVE) B, write 16(+12) B per bead.
 // COUNT (single-GPU runs): the cell assignment of k_cell_count is done here as well -- the grid of this build
 // was fixed by the previous build's scan, so nothing between the two kernels is needed and one launch goes away.
-template <bool MOVE, bool COUNT = false>
-__global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__restrict__ x,
-                                              const float *__restrict__ xp, const float *__restrict__ d,
-                                              const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
-                                              float *__restrict__ bbox_part, const MinState *__restrict__ st,
+// DIR (minimizer, trial moves): when the previous evaluation ended an iteration (st->accepted) the new L-BFGS
+// direction d = sum_a coef[a] B_a over the basis {S_0..5, Y_0..5, g} is formed here, per bead, right before it
+// is used -- with xp <- x and gp <- g -- instead of in a separate elementwise kernel (same fp32 operations in
+// the same order as k_direction, so the same bits; one launch and one pass over xp, d fewer per iteration).
+struct DirArgs {
+    const float *g;
+    float *gp;
+    const float *S, *Y; // [MMX_M] vectors of nv floats
+    size_t nv;
+};
+
+template <bool MOVE, bool COUNT = false, bool DIR = false>
+__global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__restrict__ x, float *__restrict__ xp,
+                                              float *__restrict__ d, const int8_t *__restrict__ labels,
+                                              float4 *__restrict__ pos4, float *__restrict__ bbox_part,
+                                              const MinState *__restrict__ st,
                                               const GridParams *__restrict__ grid = nullptr,
                                               int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
-                                              int *__restrict__ count = nullptr) {
+                                              int *__restrict__ count = nullptr, const DirArgs D = DirArgs{}) {
     if (st->phase == PH_DONE) return;
     __shared__ float s_bb[6][4];
+    __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
     float px = 0.f, py = 0.f, pz = 0.f;
     const bool act = i < n_own;
+    if (MOVE) {
+        // the 256 beads of a block own 768 consecutive floats = 192 float4 of the flat vectors: threads 0..191
+        // fetch (or, after an accepted step, form) them with coalesced 16-byte accesses and hand them over in LDS
+        const int n4 = (3 * n_own + 3) >> 2;
+        const int e4 = blockIdx.x * 192 + threadIdx.x;
+        if (threadIdx.x < 192 && e4 < n4) {
+            float4 xp4, d4;
+            if (DIR && st->accepted && st->phase != PH_IDLE) {
+                float c[MMX_NBASIS];
+#pragma unroll
+                for (int b = 0; b < MMX_NBASIS; ++b) c[b] = (float)st->coef[b];
+                const float4 G = reinterpret_cast<const float4 *>(D.g)[e4];
+                float4 o = make_float4(c[2 * MMX_M] * G.x, c[2 * MMX_M] * G.y, c[2 * MMX_M] * G.z, c[2 * MMX_M] * G.w);
+#pragma unroll
+                for (int a = 0; a < MMX_M; ++a) {
+                    if (c[a] != 0.f) {
+                        const float4 sv = reinterpret_cast<const float4 *>(D.S + (size_t)a * D.nv)[e4];
+                        o.x = fmaf(c[a], sv.x, o.x);
+                        o.y = fmaf(c[a], sv.y, o.y);
+                        o.z = fmaf(c[a], sv.z, o.z);
+                        o.w = fmaf(c[a], sv.w, o.w);
+                    }
+                    if (c[MMX_M + a] != 0.f) {
+                        const float4 yv = reinterpret_cast<const float4 *>(D.Y + (size_t)a * D.nv)[e4];
+                        o.x = fmaf(c[MMX_M + a], yv.x, o.x);
+                        o.y = fmaf(c[MMX_M + a], yv.y, o.y);
+                        o.z = fmaf(c[MMX_M + a], yv.z, o.z);
+                        o.w = fmaf(c[MMX_M + a], yv.w, o.w);
+                    }
+                }
+                xp4 = reinterpret_cast<const float4 *>(x)[e4];
+                d4 = o;
+                reinterpret_cast<float4 *>(xp)[e4] = xp4;
+                reinterpret_cast<float4 *>(D.gp)[e4] = G;
+                reinterpret_cast<float4 *>(d)[e4] = o;
+            } else {
+                xp4 = reinterpret_cast<const float4 *>(xp)[e4];
+                d4 = reinterpret_cast<const float4 *>(d)[e4];
+            }
+            s_xp[threadIdx.x] = xp4;
+            s_d[threadIdx.x] = d4;
+        }
+        __syncthreads();
+    }
     if (act) {
         if (MOVE) {
             const double step = st->step;
-            px = (float)((double)xp[3 * i] + step * (double)d[3 * i]);
-            py = (float)((double)xp[3 * i + 1] + step * (double)d[3 * i + 1]);
-            pz = (float)((double)xp[3 * i + 2] + step * (double)d[3 * i + 2]);
+            const float *lx = reinterpret_cast<const float *>(s_xp) + 3 * threadIdx.x;
+            const float *ld = reinterpret_cast<const float *>(s_d) + 3 * threadIdx.x;
+            px = (float)((double)lx[0] + step * (double)ld[0]);
+            py = (float)((double)lx[1] + step * (double)ld[1]);
+            pz = (float)((double)lx[2] + step * (double)ld[2]);
             x[3 * i] = px;
             x[3 * i + 1] = py;
             x[3 * i + 2] = pz;
