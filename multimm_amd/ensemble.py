@@ -1,0 +1,53 @@
+"""Ensemble generation (BASELINE config 4): the replica loop of ``run.py:471-485`` on ``PLATFORM = MI355X``.
+
+The reference runs ``N_ENSEMBLE`` replicas one after the other in one process, each with ``SHUFFLING_SEED = i`` and
+``OUT_PATH = <name>/run_<i, zero padded>``, and compresses every run directory afterwards (``archive_run``,
+run.py:423-445).  The replicas are independent, so with several GPUs replica i goes to rank i mod world (one
+process per GPU, no data-path collective: what ``bench.py --gpus N`` times).
+"""
+from __future__ import annotations
+
+import copy
+import os
+import shutil
+import tarfile
+from typing import Optional
+
+from .config import SimulationConfig, load_config
+from .model import MultiMM
+
+
+def archive_run(run_path: str) -> str:
+    """<run_path>.tar.gz of the run directory, then the directory is removed (run.py:423-445)."""
+    tar_path = run_path + ".tar.gz"
+    with tarfile.open(tar_path, "w:gz") as tar:
+        tar.add(run_path, arcname=os.path.basename(run_path))
+    if not (os.path.exists(tar_path) and os.path.getsize(tar_path) > 0):
+        raise RuntimeError(f"Archive creation failed ({tar_path}). Original directory was NOT deleted.")
+    shutil.rmtree(run_path)
+    return tar_path
+
+
+def run_ensemble(args: SimulationConfig | str | dict, n_ensemble: Optional[int] = None, rank: int = 0, world: int = 1,
+                 archive: bool = True, device: Optional[int] = None, **model_inputs) -> list:
+    """Runs replicas ``i = rank, rank + world, ...`` of ``n_ensemble`` (default ``args.N_ENSEMBLE``); returns
+    ``[(i, run_path_or_archive, stats)]`` of the replicas this rank ran.  ``model_inputs`` are passed to ``MultiMM``
+    (``ms, ns, ds, chr_ends, Cs``) when the tensors are given instead of files."""
+    base = args if isinstance(args, SimulationConfig) else load_config(args)
+    n = int(n_ensemble if n_ensemble is not None else (base.N_ENSEMBLE or 1))
+    name = base.OUT_PATH
+    width = len(str(max(n - 1, 0)))
+    out = []
+    for i in range(rank, n, max(world, 1)):
+        cfg = copy.deepcopy(base)
+        cfg.SHUFFLING_SEED = i
+        cfg.DEVICE = device if device is not None else (base.DEVICE if world == 1 else rank)  # one GPU per rank
+        run_path = os.path.join(name, f"run_{i:0{width}d}")
+        cfg.OUT_PATH = run_path
+        os.makedirs(run_path, exist_ok=True)
+        md = MultiMM(cfg, **model_inputs)
+        stats = md.run()
+        if md.engine is not None:
+            md.engine.close()
+        out.append((i, archive_run(run_path) if archive else run_path, stats))
+    return out

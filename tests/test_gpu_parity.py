@@ -400,3 +400,24 @@ def test_fused_bonded_kernel_equals_separate_kernels_bitwise():
             res.append((et.copy(), F.copy(), st.e_final, st.evaluations, eng.get_positions()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and np.array_equal(res[0][4], res[1][4])
+
+
+def test_ensemble_loop_like_the_reference(tmp_path):
+    """run.py:471-485: replicas with SHUFFLING_SEED = i in <name>/run_<i>, archived as .tar.gz; different seeds give
+    different inputs (loops / labels) and therefore different structures."""
+    import os
+    import tarfile
+    from multimm_amd.ensemble import run_ensemble
+    cfg = {"PLATFORM": "MI355X", "N_BEADS": 1500, "OUT_PATH": str(tmp_path / "ens"), "N_ENSEMBLE": 3,
+           "MIN_MAX_ITERATIONS": 60}
+    res = run_ensemble(cfg)
+    assert [i for i, _, _ in res] == [0, 1, 2]
+    for i, path, st in res:
+        assert path.endswith(f"run_{i}.tar.gz") and os.path.getsize(path) > 0 and not os.path.exists(path[:-7])
+        names = tarfile.open(path).getnames()
+        assert f"run_{i}/model/MultiMM_minimized.cif" in names and f"run_{i}/metadata/parameters.txt" in names
+        assert st.iterations == 60
+    assert len({round(st.e_final, 3) for _, _, st in res}) == 3
+    # rank 1 of 2 takes replica 1 only
+    res1 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens2")), rank=1, world=2, archive=False, device=0)
+    assert [i for i, _, _ in res1] == [1]
