@@ -137,6 +137,11 @@ def test_hilbert_curve_properties(oracle_lib):
     assert len({tuple(r) for r in p}) == len(p)
     for k in (1, 2, 3, 4):                                           # first 8^k points tile a 2^k cube
         assert p[:8 ** k].max() == 2 ** k - 1
+    # the documented first-order curves of the hilbertcurve package (its README example for p = 1, n = 2, and the
+    # same Gray-code walk in three dimensions): points_from_distances(range(2^n))
+    assert hilbert_points(4, p=1, n=2).tolist() == [[0, 0], [0, 1], [1, 1], [1, 0]]
+    assert hilbert_points(8, p=1, n=3).tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 1, 0], [1, 1, 1],
+                                                    [1, 0, 1], [1, 0, 0]]
 
 
 def test_gw_chr_ends_and_strength():
