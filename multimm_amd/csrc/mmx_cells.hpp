@@ -33,7 +33,7 @@ __device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restri
 // DIR (minimizer, trial moves): when the previous evaluation ended an iteration (st->accepted) the new L-BFGS
 // direction d = sum_a coef[a] B_a over the basis {S_0..5, Y_0..5, g} is formed here, per bead, right before it
 // is used -- with xp <- x and gp <- g -- instead of in a separate elementwise kernel (same fp32 operations in
-// the same order as k_direction, so the same bits; one launch and one pass over xp, d fewer per iteration).
+// the same order as the former stand-alone direction kernel, so the same bits; one launch and one pass over xp, d fewer per iteration).
 struct DirArgs {
     const float *g;
     float *gp;

@@ -3,8 +3,8 @@
 //
 // The two-loop recursion is done in coefficient space over the basis B = {S_0..S_5, Y_0..Y_5, g}:
 // one streaming pass (k_history) stores the new (s,y) pair and produces the three Gram rows that
-// changed, a single thread runs the recursion on the 13x13 Gram matrix (k_direction_coef), and one
-// more streaming pass (k_direction) forms d = sum_a c_a B_a.  No host round trip, two reductions per
+// changed, a single thread runs the recursion on the 13x13 Gram matrix (k_direction_coef), and the
+// next trial move (k_pack<.., DIR>) forms d = sum_a c_a B_a while it packs the positions.  No host round trip, two reductions per
 // iteration instead of 2m sequential ones; the same Gram rows are what a multi-GPU run all-reduces.
 #pragma once
 #include "mmx_common.hpp"
@@ -226,7 +226,7 @@ __global__ void k_controller_decide(MinState *__restrict__ st) {
 // against the whole basis as block partials rows[(r*13 + b)*stride + blockIdx.x].
 // 2-D grid: blockIdx.y picks a group of <= 4 basis columns (12 fp64 accumulators per thread instead of
 // 39: full occupancy); every group re-reads x, xp, g, gp (L2/MALL resident), only the last group
-// stores the new pair.  xp <- x and gp <- g are done afterwards by k_direction (no intra-kernel race).
+// stores the new pair.  xp <- x and gp <- g are done afterwards by the next trial move (no intra-kernel race).
 constexpr int kHistGroups = 4;
 __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restrict__ x, const float4 *__restrict__ xp,
                                                  const float4 *__restrict__ g, const float4 *__restrict__ gp,
@@ -396,49 +396,8 @@ __global__ void k_direction_coef_decide(MinState *__restrict__ st) {
     coef_decide(st, st->rowsum);
 }
 
-// d = sum_a coef[a] * B_a.  Streams 13 vectors in, one out.
-__global__ __launch_bounds__(256) void k_direction(int n4, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                                   const float4 *__restrict__ g, float4 *__restrict__ gp,
-                                                   const float4 *__restrict__ S, const float4 *__restrict__ Y,
-                                                   float4 *__restrict__ d, const MinState *__restrict__ st) {
-    // runs whenever a step was accepted (also when k_direction_coef then stopped the minimizer): the accepted
-    // point becomes the previous point of the next line search
-    if (!st->accepted || st->phase == PH_IDLE) return;
-    if (st->phase == PH_DONE) {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-            xp[i] = x[i];
-            gp[i] = g[i];
-        }
-        return;
-    }
-    float c[MMX_NBASIS];
-#pragma unroll
-    for (int b = 0; b < MMX_NBASIS; ++b) c[b] = (float)st->coef[b];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-        const float4 G = g[i];
-        xp[i] = x[i];
-        gp[i] = G;
-        float4 o = make_float4(c[2 * MMX_M] * G.x, c[2 * MMX_M] * G.y, c[2 * MMX_M] * G.z, c[2 * MMX_M] * G.w);
-#pragma unroll
-        for (int a = 0; a < MMX_M; ++a) {
-            if (c[a] != 0.f) {
-                const float4 s = S[(size_t)a * n4 + i];
-                o.x = fmaf(c[a], s.x, o.x);
-                o.y = fmaf(c[a], s.y, o.y);
-                o.z = fmaf(c[a], s.z, o.z);
-                o.w = fmaf(c[a], s.w, o.w);
-            }
-            if (c[MMX_M + a] != 0.f) {
-                const float4 y = Y[(size_t)a * n4 + i];
-                o.x = fmaf(c[MMX_M + a], y.x, o.x);
-                o.y = fmaf(c[MMX_M + a], y.y, o.y);
-                o.z = fmaf(c[MMX_M + a], y.z, o.z);
-                o.w = fmaf(c[MMX_M + a], y.w, o.w);
-            }
-        }
-        d[i] = o;
-    }
-}
+// d = sum_a coef[a] * B_a (with xp <- x, gp <- g) is formed per bead by the next trial move: k_pack<.., DIR> in
+// mmx_cells.hpp -- no stand-alone direction kernel.
 
 __global__ __launch_bounds__(256) void k_copy4(int n4, const float4 *__restrict__ src, float4 *__restrict__ dst) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) dst[i] = src[i];
