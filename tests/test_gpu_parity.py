@@ -226,6 +226,14 @@ def test_full_size_properties_200k():
         eng.set_positions(shifted)
         et2, F2 = eng.compute()
         assert np.all(np.abs(et2 - et0) <= 5e-5 * np.abs(et0).sum() + 1e-2)
+        # rigid rotation: energies unchanged, forces co-rotate (different cells, clusters and summation order)
+        q, _ = np.linalg.qr(np.random.default_rng(3).normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        eng.set_positions(internal.positions @ q.T)
+        et3, F3 = eng.compute()
+        assert np.all(np.abs(et3 - et0) <= 5e-5 * np.abs(et0).sum() + 1e-2)
+        assert np.abs(F3 - F0 @ q.T.astype(np.float32)).max() <= 5e-4 * fmax + 5e-2
     with engine_for(s) as eng:
         e_prev = None
         for _ in range(4):

@@ -343,3 +343,51 @@ def test_form_name_tables_agree_and_unknown_names_raise():
     with pytest.raises(ValueError, match="Unknown EV_FORCE_TYPE"):
         load_config({"EV_FORCE_TYPE": "soft_lj"})
     assert load_config({"COB_FORCE_TYPE": "yukawa"}).ff.COB_FORCE_TYPE == "yukawa"
+
+
+# ---- invariances (size-independent properties of the path) ----------------------------------------------
+def test_oracle_invariances_translation_rotation_newton3(oracle_lib):
+    """Internal terms (pair, backbone, loops, chromosomal blocks) are invariant under rigid motions and their
+    forces sum to zero with zero net torque; the external terms move with the centre, which the reference ties
+    to the mass centre of the START structure (model.py:759) -- so the whole energy is translation invariant
+    when the system is rebuilt from the moved start."""
+    from dataclasses import replace
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=400, jitter=0.03, seed=9, NB_CUTOFF=0.0, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
+                         COB_USE_COMPARTMENT_BLOCKS=True, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.5,
+                         SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
+    et, F = Oracle(s, as_float32_inputs=False).eval()
+    scale = np.abs(F).max()
+    assert np.abs(F.sum(0)).max() < 1e-9 * scale * len(F)                        # Newton's third law
+    x = s.positions - s.positions.mean(0)
+    assert np.abs(np.cross(x, F).sum(0)).max() < 1e-8 * scale * len(F)          # no net torque
+    rng = np.random.default_rng(1)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    moved = replace(s, positions=s.positions @ q.T + np.array([3.0, -2.0, 0.5]))
+    et2, F2 = Oracle(moved, as_float32_inputs=False).eval()
+    assert np.allclose(et2, et, rtol=1e-10, atol=1e-8)
+    assert np.allclose(F2, F @ q.T, rtol=1e-8, atol=1e-8 * scale)
+    # with the external terms on: translation of the start moves the centre with it
+    full = synthetic_system("gw_200k", n_beads=400, jitter=0.03, seed=9, NB_CUTOFF=0.6, CF_USE_CENTRAL_FORCE=True)
+    shifted = replace(full, positions=full.positions + np.array([1.0, 2.0, -3.0]))
+    e_a, F_a = Oracle(full, as_float32_inputs=False).eval()
+    e_b, F_b = Oracle(shifted, as_float32_inputs=False).eval()
+    assert np.allclose(e_a, e_b, rtol=1e-9, atol=1e-7) and np.allclose(F_a, F_b, rtol=1e-7, atol=1e-7 * np.abs(F_a).max())
+
+
+def test_oracle_cutoff_is_plain_truncation(oracle_lib):
+    """CutoffNonPeriodic semantics: enlarging the cutoff only ADDS pairs; at a cutoff beyond the system size the
+    cell-list path equals the all-pairs path exactly."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=300, jitter=0.02, seed=2)
+    e = [Oracle(s, cutoff=rc, as_float32_inputs=False).eval()[0] for rc in (0.3, 0.45, 0.6, 0.9)]
+    ev = [t[0] for t in e]
+    assert ev[0] < ev[1] < ev[2] < ev[3]                     # EV is repulsive: every added pair adds energy
+    gauss = [t[1] for t in e]
+    assert gauss[0] > gauss[1] > gauss[2] >= gauss[3]        # the Gaussians are attractive
+    big = np.linalg.norm(s.positions.max(0) - s.positions.min(0)) + 1.0
+    e_all = Oracle(s, cutoff=0.0, as_float32_inputs=False).eval()[0]
+    e_big = Oracle(s, cutoff=big, as_float32_inputs=False).eval()[0]
+    assert np.allclose(e_all, e_big, rtol=1e-12, atol=1e-10)
