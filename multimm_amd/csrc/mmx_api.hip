@@ -142,6 +142,7 @@ struct mmx_handle_s {
     int2 *items = nullptr;
     int *cstart = nullptr;                       // cluster offsets per cell
     unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
+    int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
     int last_clusters = -1;
@@ -509,18 +510,18 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
             hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
                                cur, h->cell_of, h->rank_in_cell, h->count, h->st);
         hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox_part, gb, hm,
-                           h->maxcells, h->count, h->start, h->istart, h->cstart, cur, next, h->st);
+                           h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next, h->st);
         hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                            h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order
         if (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(2048), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(1024), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
         h->gcur = cur;
         h->build_idx++;
     }
@@ -780,6 +781,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->items, (size_t)h->max_items));
         HIPCHK(h, dalloc(&h->cstart, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->okeys, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->biglist, (size_t)h->maxcells + 1));
         // clusters hold >= 1 bead; a rank only bins its owned beads and the ghosts inside its grid, but the
         // bound that needs no host knowledge is "every bead": n_all clusters
         HIPCHK(h, dalloc(&h->spos4, (size_t)h->n_all * 8));
@@ -900,7 +902,7 @@ int mmx_destroy(mmx_handle h) try {
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
-                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart})
+                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,

@@ -82,7 +82,7 @@ struct MinState {
     int nan_seen;
     int n_clusters; // 8-bead clusters of the last cell build
     int order_fallbacks; // cells too large for the in-LDS sort since the state was pushed (arrival order kept)
-    int pad0_;
+    int n_big;           // cells of > 64 beads in the last cell build (sorted by a whole block each)
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;
