@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     __shared__ float4 s_ring[4][BEADCULL ? 128 : 1];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ float s_tabc[FORMS ? 40 : 1], s_tabs[FORMS ? 40 : 1]; // COB / SCB tables of the generic forms
+    __shared__ float s_arow[4][kCl * 8]; // per wave: amplitude row of each of its 8 i beads (address = s*8 + label_j)
     __shared__ double s_e[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 3, slot = lane & 7;
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     __syncthreads();
     int *list = s_list[wave];
     float4 *ring = s_ring[wave];
+    const float *arow = s_arow[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float rc2 = P.rc2max;
     const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
@@ -344,6 +346,12 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
             yi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), s));
             zi[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.z), s));
             wi[s] = __builtin_amdgcn_readlane(__float_as_int(pv.w), s);
+        }
+        if (GAUSS && !FORMS) { // lane l: row (l >> 3) = i bead, column (l & 7) = label of the j bead
+            const int wrow = __shfl(__float_as_int(pv.w), lane >> 3, 64) & 7;
+            wave_lds_sync(); // the previous i-cluster's sweeps have finished reading the rows
+            s_arow[wave][lane] = s_tab[wrow * 8 + (lane & 7)];
+            wave_lds_sync();
         }
         float fx[kCl], fy[kCl], fz[kCl], ee[kCl], eg[kCl], aA[kCl], aB[kCl];
 #pragma unroll
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                     if (GAUSS) {
                         float A;
                         if (RANK2) A = fmaf(aA[s], alpha_j, aB[s] * beta_j);
-                        else A = s_tab[(wi[s] & 7) * 8 + lj];
+                        else A = arow[s * 8 + lj]; // ds_read_b32 with an immediate offset: no address arithmetic per pair
                         float gg = A * __builtin_amdgcn_exp2f(r2 * P.g_c2);
                         if (SATMASK) gg *= SAMECUT ? in : fma_sat(r2, nbig, cut_g);
                         else gg = (r2 < (SAMECUT ? rc2 : P.g_rc2)) ? gg : 0.f;
