@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     constexpr bool ESPLIT = (OPT & 4) == 0;  // per-i energy accumulators (else one pair per lane)
     constexpr bool BEADCULL = (OPT & 8) != 0; // per-bead second-level cull + LDS ring compaction
     constexpr bool NOSWEEP = (OPT & 16) != 0; // diagnosis only: skip the pair arithmetic (times culls + fold)
+    // LEAN: the default configuration gets a pair loop with the mask and the power factored out (see below)
+    constexpr bool LEAN = SATMASK && SAMECUT && !ESPLIT && !RANK2 && !FORMS && !NOSWEEP;
     constexpr bool XCDMAP = (OPT & 128) != 0; // blocks of one XCD (blockIdx % 8) take contiguous cluster ranges
     constexpr bool P1ONLY = (OPT & 64) != 0;  // diagnosis only: cluster cull + fold, no j stream at all
     constexpr bool SAMEJ = (OPT & 32) != 0;   // diagnosis only: every j load hits the same 64 clusters (L1-resident)
@@ -306,6 +308,10 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
     const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
     const float ev_c = P.ev_eps * s3 * s3; // eps*sigma^6 (PMODE 6)
+    const float tiny = 1e-20f;              // keeps r = 0 finite (self pair, coincident beads)
+    // LEAN: forces are accumulated divided by the power p (EV on) and multiplied back at the fold
+    const float pscale = (LEAN && EV) ? P.ev_power : 1.f;
+    const float g_k = P.g_inv_rc2 / pscale;
     // step(rc^2 - r^2) = sat(1e30*(rc^2 - r^2)): exact for every representable r^2 (1 ulp of 0.36 * 1e30 >> 1)
     const float nbig = -1e30f;
     const float cut_all = 1e30f * fminf(rc2, 1e6f), cut_ev = 1e30f * fminf(P.ev_rc2, 1e6f),
@@ -469,7 +475,38 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
 #pragma unroll
                 for (int s = 0; s < kCl; ++s) {
                     const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
-                    const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                    const float r2 = LEAN ? 0.f : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                    if (LEAN) {
+                        // lean form of the default path (clamp mask, one cutoff, merged energies): the mask is applied
+                        // ONCE to the force scale and rides on the energy FMAs, the power p is factored out of the
+                        // pair loop (forces are accumulated as F/p and scaled at the fold): 3 VALU ops fewer per pair
+                        const float r2t = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, tiny))); // r^2 + 1e-20 in the FMA chain
+                        const float in = fma_sat(r2t, nbig, cut_all);
+                        const float rinv = __builtin_amdgcn_rsqf(r2t);
+                        float fs = 0.f;
+                        if (EV) {
+                            const float u = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, P.ev_rs));
+                            float E;
+                            if (PMODE == 6) {
+                                const float u2 = u * u;
+                                E = ((u2 * u2) * u2) * ev_c;
+                            } else {
+                                E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                            }
+                            ee[0] = fmaf(E, in, ee[0]);
+                            fs = E * (u * rinv);
+                        }
+                        if (GAUSS) {
+                            const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(r2t * P.g_c2);
+                            eg[0] = fmaf(-gg, in, eg[0]);
+                            fs = fmaf(-gg, g_k, fs);
+                        }
+                        fs *= in;
+                        fx[s] = fmaf(fs, dx, fx[s]);
+                        fy[s] = fmaf(fs, dy, fy[s]);
+                        fz[s] = fmaf(fs, dz, fz[s]);
+                        continue;
+                    }
                     // exact step function of the cutoff without v_cmp/v_cndmask: sat(BIG*(rc^2 - r^2))
                     const float in = SATMASK ? fma_sat(r2, nbig, cut_all) : (r2 < rc2 ? 1.f : 0.f);
                     const float r2s = r2 + 1e-20f;
@@ -515,9 +552,9 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
         for (int s = 0; s < kCl; ++s) {
             const float a0 = wave_sum(fx[s]), a1 = wave_sum(fy[s]), a2 = wave_sum(fz[s]);
             if (lane == s) {
-                ofx = a0;
-                ofy = a1;
-                ofz = a2;
+                ofx = a0 * pscale;
+                ofy = a1 * pscale;
+                ofz = a2 * pscale;
                 ow = wi[s];
             }
         }
