@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     const float ev_c = P.ev_eps * s3 * s3; // eps*sigma^6 (PMODE 6)
     const float tiny = 1e-20f;              // keeps r = 0 finite (self pair, coincident beads)
     // LEAN: forces are accumulated divided by the power p (EV on) and multiplied back at the fold
-    const float pscale = (LEAN && EV) ? P.ev_power : 1.f;
+    const float escale = (LEAN && EV && PMODE == 6) ? ev_c : 1.f; // unit of the EV energies summed in the loop
+    const float pscale = (LEAN && EV) ? P.ev_power * escale : 1.f;
     const float g_k = P.g_inv_rc2 / pscale;
     // step(rc^2 - r^2) = sat(1e30*(rc^2 - r^2)): exact for every representable r^2 (1 ulp of 0.36 * 1e30 >> 1)
     const float nbig = -1e30f;
@@ -487,9 +488,9 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                         if (EV) {
                             const float u = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, P.ev_rs));
                             float E;
-                            if (PMODE == 6) {
+                            if (PMODE == 6) { // in units of eps*sigma^6: the constant joins the scale applied at the fold
                                 const float u2 = u * u;
-                                E = ((u2 * u2) * u2) * ev_c;
+                                E = (u2 * u2) * u2;
                             } else {
                                 E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
                             }
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
             tev += ee[s];
             teg += eg[s];
         }
+        tev *= escale; // LEAN, p = 6: the loop summed (sigma-free) u^6
         const int bead = ow >> 3; // -1 for padding slots and for lanes >= 8
         const bool own = bead >= 0;
         if (own) {
