@@ -142,6 +142,7 @@ struct mmx_handle_s {
     int2 *items = nullptr;
     int *cstart = nullptr;                       // cluster offsets per cell
     unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
+    float nb_scale = 1.f;                        // length scale of spos4 / cluster boxes (see k_nb_clusters_j, LEAN)
     int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
@@ -224,6 +225,18 @@ float hmin_of(const mmx_handle_s *h) {
     return rc * 1.001f;
 }
 
+// OPT template bits of the cluster-kernel instance that nb_variant selects (see launch_nb_cells_p).
+int nb_launch_opt(const mmx_handle_s *h) {
+    const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) | ((h->nb_variant & 128) ? 0 : 8) |
+                    ((h->nb_variant & 256) ? 16 : 0) | ((h->nb_variant & 512) ? 32 : 0) |
+                    ((h->nb_variant & 1024) ? 64 : 0) | ((h->nb_variant & 2048) ? 128 : 0);
+    if (opt == 142) return 142;
+    switch (opt & 127) {
+    case 14: case 30: case 46: case 22: case 78: case 62: case 6: case 12: case 10: return opt & 127;
+    default: return 0;
+    }
+}
+
 // Derived constants refreshed before every launch sequence.
 void refresh_params(mmx_handle_s *h) {
     FFParams &P = h->P;
@@ -269,6 +282,12 @@ void refresh_params(mmx_handle_s *h) {
     Q.chb_form = h->forms[MMX_SEL_CHB];
     Q.generic_pairs = ((P.use_ev && Q.ev_form != 0) || (h->has_cob && Q.cob_form != 0) ||
                        (h->has_scb && Q.scb_form != 0)) ? 1 : 0;
+    // the default cluster-kernel instance with Gaussians on works in scaled length units (exp2(-r'^2))
+    // (the kernel's LEAN condition: clamp mask, one cutoff, merged energies, no rank-2 / no-sweep variant)
+    const int lo = nb_launch_opt(h);
+    const bool lean = !Q.generic_pairs && h->nb_variant != 1 && !all_pairs(h) &&
+                      (!(P.use_ev && P.use_gauss) || P.ev_rc2 == P.g_rc2) && (lo & 2) && (lo & 4) && !(lo & 1) && !(lo & 16);
+    h->nb_scale = (lean && P.use_gauss) ? std::sqrt(-P.g_c2) : 1.f;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
@@ -308,25 +327,22 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
 #define NBJ(PM, EV, GA, SC, OPT)                                                                            \
     hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
-                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part)
+                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part, h->nb_scale)
 #define NBC(EV, GA)                                                                                         \
     do {                                                                                                    \
         if (h->Q.generic_pairs) { /* non-default functional forms: one generic instance per term combination */ \
             hipLaunchKernelGGL((k_nb_clusters_j<0, EV, GA, false, 14, true>), dim3(grid), dim3(256), 0,       \
                                h->stream, P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g,  \
-                               h->part, h->formp);                                                          \
+                               h->part, 1.f, h->formp);                                                     \
         } else if (h->nb_variant == 1)                                                                      \
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
         else if (!(EV && GA) || P.ev_rc2 == P.g_rc2) {                                                      \
             /* default: cutoff by v_fma clamp + one energy accumulator pair per lane + per-bead cull;       \
                nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
-            const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) |               \
-                            ((h->nb_variant & 128) ? 0 : 8) | ((h->nb_variant & 256) ? 16 : 0) |           \
-                            ((h->nb_variant & 512) ? 32 : 0) | ((h->nb_variant & 1024) ? 64 : 0) |         \
-                            ((h->nb_variant & 2048) ? 128 : 0);                                            \
+            const int opt = nb_launch_opt(h);                                                               \
             if (opt == 142) { NBJ(PMODE, EV, GA, true, 142); break; }                                       \
-            switch (opt & 127) { /* A/B and diagnosis instances keep the plain block -> cluster mapping */  \
+            switch (opt) { /* A/B and diagnosis instances keep the plain block -> cluster mapping */        \
             case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
             case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
             case 46: NBJ(PMODE, EV, GA, true, 46); break;                                                   \
@@ -517,11 +533,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
         if (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(2048), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(1024), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
         h->gcur = cur;
         h->build_idx++;
     }
@@ -1679,7 +1695,7 @@ int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidat
     HIPCHK(h, dalloc(&dout, 3));
     const int ncl = h->st_host->n_clusters;
     hipLaunchKernelGGL(k_tile_census, dim3(1024), dim3(256), 0, h->stream, ncl, h->cl_lo, h->cl_hi, h->cstart,
-                       h->spos4, h->gcur, h->P.rc2max, dout);
+                       h->spos4, h->gcur, h->P.rc2max * h->nb_scale * h->nb_scale, dout);
     double res[3] = {0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

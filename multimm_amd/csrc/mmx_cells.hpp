@@ -390,7 +390,7 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, int own_lo, int n_own,
-                                              const unsigned long long *keys = nullptr) {
+                                              const unsigned long long *keys = nullptr, const float scale = 1.f) {
     const int ncl = (cnt + 7) >> 3;
     for (int e = tid; e < ncl * 8; e += nthr) {
         float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
@@ -399,6 +399,10 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
             const int b = keys ? (int)(unsigned)(keys[e] & 0xffffffffull) : perm[s + e];
             p = pos4[b];
+            // the pair kernel may work in scaled length units (see k_nb_clusters_j, LEAN): scale = 1 otherwise
+            p.x *= scale;
+            p.y *= scale;
+            p.z *= scale;
             nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
         }
         spos4[(size_t)cb * 8 + e] = p;
@@ -507,7 +511,8 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
-                                                    const int *__restrict__ biglist, MinState *__restrict__ st) {
+                                                    const int *__restrict__ biglist, const float scale,
+                                                    MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own, nullptr, scale);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -558,7 +563,8 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf);
+            emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf,
+                          scale);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -608,7 +614,8 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
         }
         else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
         // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, nullptr,
+                      scale);
     }
 }
 
