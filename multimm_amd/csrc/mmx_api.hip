@@ -143,6 +143,7 @@ struct mmx_handle_s {
     int *cstart = nullptr;                       // cluster offsets per cell
     unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
     float nb_scale = 1.f;                        // length scale of spos4 / cluster boxes (see k_nb_clusters_j, LEAN)
+    bool nb_skip_energy = false;                 // MD steps between reports: pair forces only (default instance)
     int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
@@ -342,6 +343,7 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
                nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
             const int opt = nb_launch_opt(h);                                                               \
             if (opt == 142) { NBJ(PMODE, EV, GA, true, 142); break; }                                       \
+            if (opt == 14 && h->nb_skip_energy) { NBJ(PMODE, EV, GA, true, 14 | 512); break; }              \
             switch (opt) { /* A/B and diagnosis instances keep the plain block -> cluster mapping */        \
             case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
             case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
@@ -1472,10 +1474,14 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         enqueue_eval(h, PACK_PLAIN);
         h->md_forces_valid = true;
     }
+    const int poll_every = 8 * std::max(1, h->poll_interval);
     for (int s = 0; s < n_steps; ++s) {
+        // pair energies are only needed where they are read: at the last step (report) and at the polls (NaN check)
+        h->nb_skip_energy = !(s + 1 == n_steps || (s + 1) % poll_every == 0);
         enqueue_eval(h, PACK_MD);
+        h->nb_skip_energy = false;
         h->md_step++;
-        if ((s + 1) % (8 * std::max(1, h->poll_interval)) == 0) { // bound the queue depth; learn the cluster count
+        if ((s + 1) % poll_every == 0) { // bound the queue depth; learn the cluster count
             if ((rc = pull_state(h))) return rc;
             const double f = h->st_host->ftrial;
             if (!(f - f == 0.0)) {

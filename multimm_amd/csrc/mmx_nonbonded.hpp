@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     constexpr bool NOSWEEP = (OPT & 16) != 0; // diagnosis only: skip the pair arithmetic (times culls + fold)
     // LEAN: the default configuration gets a pair loop with the mask and the power factored out (see below)
     constexpr bool LEAN = SATMASK && SAMECUT && !ESPLIT && !RANK2 && !FORMS && !NOSWEEP;
+    constexpr bool NOENERGY = (OPT & 512) != 0; // MD steps between reports: forces only (LEAN instances)
     constexpr bool XCDMAP = (OPT & 128) != 0; // blocks of one XCD (blockIdx % 8) take contiguous cluster ranges
     constexpr bool P1ONLY = (OPT & 64) != 0;  // diagnosis only: cluster cull + fold, no j stream at all
     constexpr bool SAMEJ = (OPT & 32) != 0;   // diagnosis only: every j load hits the same 64 clusters (L1-resident)
@@ -500,12 +501,12 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                             } else {
                                 E = P.ev_eps * ev_pow<PMODE>(sigma_s * u, P.ev_power);
                             }
-                            ee[0] = fmaf(E, in, ee[0]);
+                            if (!NOENERGY) ee[0] = fmaf(E, in, ee[0]);
                             fs = E * (u * rinv);
                         }
                         if (GAUSS) {
                             const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(-r2t); // scaled units: sc^2 = -g_c2
-                            eg[0] = fmaf(-gg, in, eg[0]);
+                            if (!NOENERGY) eg[0] = fmaf(-gg, in, eg[0]);
                             fs = fmaf(-gg, g_k, fs);
                         }
                         fs *= in;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
         const bool own = bead >= 0;
         if (own) {
             // the self pair (r = 0, zero force) was swept with everything else: remove its energy
-            if (EV && !FORMS) {
+            if (EV && !FORMS && !NOENERGY) {
                 const float u = __builtin_amdgcn_rcpf(fmaf(1e-20f, __builtin_amdgcn_rsqf(1e-20f), P.ev_rs));
                 if (PMODE == 6) {
                     const float u2 = u * u;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                     tev -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
                 }
             }
-            if (GAUSS && !FORMS) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
+            if (GAUSS && !FORMS && !NOENERGY) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
             g[3 * (bead - P.own_lo)] = -ofx;
             g[3 * (bead - P.own_lo) + 1] = -ofy;
             g[3 * (bead - P.own_lo) + 2] = -ofz;
