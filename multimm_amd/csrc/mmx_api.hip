@@ -802,7 +802,16 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->biglist, (size_t)h->maxcells + 1));
         // clusters hold >= 1 bead; a rank only bins its owned beads and the ghosts inside its grid, but the
         // bound that needs no host knowledge is "every bead": n_all clusters
-        HIPCHK(h, dalloc(&h->spos4, (size_t)h->n_all * 8));
+        HIPCHK(h, dalloc(&h->spos4, ((size_t)h->n_all + 1) * 8)); // + one all-padding cluster at index n_all
+        {
+            float4 farc[8];
+            for (auto &f : farc) {
+                f.x = f.y = f.z = -1e18f;
+                const int w = -8 + 2;
+                std::memcpy(&f.w, &w, 4);
+            }
+            HIPCHK(h, hipMemcpy(h->spos4 + (size_t)h->n_all * 8, farc, sizeof(farc), hipMemcpyHostToDevice));
+        }
         HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all));
         HIPCHK(h, dalloc(&h->cl_hi, (size_t)h->n_all));
         HIPCHK(h, dalloc(&h->grid, 2));

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
     const float sc2 = sc * sc;
     const float rc2 = P.rc2max * sc2;
     const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
+    const int far_cl = P.n_all; // cluster slot n_all of spos4 holds 8 copies of far4 (written once by mmx_create)
     const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
     const float ev_c = P.ev_eps * s3 * s3; // eps*sigma^6 (PMODE 6)
     const float tiny = 1e-20f;              // keeps r = 0 finite (self pair, coincident beads)
@@ -421,19 +422,19 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
             }
             if (nlist == 0 && (!BEADCULL || rcount == 0)) break;
             // pad to a multiple of 8 clusters with "no cluster" (also gives the ring its flush step)
-            if (lane < 8) list[nlist + lane] = -1;
+            if (lane < 8) list[nlist + lane] = far_cl; // a resident all-padding cluster: loads need no predicate
             wave_lds_sync();
             const int nsteps = max((nlist + 7) >> 3, 1);
             // ---- sweep: 8 j-clusters (64 j beads) per step against the 8 scalar i beads
             int jn = list[sub];
-            if (SAMEJ && jn >= 0) jn &= 63;
-            float4 qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
+            if (SAMEJ) jn &= 63;
+            float4 qn = spos4[(size_t)jn * kCl + slot];
             for (int t = 0; t < nsteps; ++t) {
                 float4 q = qn;
                 if (t + 1 < nsteps) { // prefetch the next 8 clusters
                     jn = list[(t + 1) * 8 + sub];
-                    if (SAMEJ && jn >= 0) jn &= 63;
-                    qn = jn >= 0 ? spos4[(size_t)jn * kCl + slot] : far4;
+                    if (SAMEJ) jn &= 63;
+                    qn = spos4[(size_t)jn * kCl + slot];
                 }
                 if (BEADCULL) {
                     // second-level cull per j BEAD against the i-cluster box; survivors are compacted
