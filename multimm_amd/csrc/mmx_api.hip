@@ -812,8 +812,8 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             }
             HIPCHK(h, hipMemcpy(h->spos4 + (size_t)h->n_all * 8, farc, sizeof(farc), hipMemcpyHostToDevice));
         }
-        HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all));
-        HIPCHK(h, dalloc(&h->cl_hi, (size_t)h->n_all));
+        HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all * 2)); // interleaved {lo, hi} box records
+        HIPCHK(h, dalloc(&h->cl_hi, (size_t)1));             // (kept as a kernel argument, unused)
         HIPCHK(h, dalloc(&h->grid, 2));
         HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n_own + 255) / 256 + 1)));
         HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double cand = 0.0, acc = 0.0, beads = 0.0;
     for (int icl = blockIdx.x * 4 + wave; icl < ncl; icl += gridDim.x * 4) {
-        const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
+        const float4 lo_i = cl_lo[2 * icl], hi_i = cl_lo[2 * icl + 1];
         const int c = __float_as_int(lo_i.w);
         const int cx = c % G.nx, cy = (c / G.nx) % G.ny, cz = c / (G.nx * G.ny);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.nx - 1);
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(256) static void k_tile_census(int ncl, const float
                 const int row = (zz * G.ny + yy) * G.nx;
                 const int c0 = cstart[row + x0], c1 = cstart[row + x1 + 1];
                 for (int jc = c0 + lane; jc < c1; jc += 64) {
-                    const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
+                    const float4 lo_j = cl_lo[2 * jc], hi_j = cl_lo[2 * jc + 1];
                     const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
                     const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
                     const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);

@@ -420,8 +420,10 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
             nown += __shfl_xor(nown, o, 64);
         }
         if ((e & 7) == 0) { // lo.w = cell id, hi.w = (owned beads << 8) | beads of the cluster
-            cl_lo[cb + (e >> 3)] = make_float4(lx, ly, lz, __int_as_float(c));
-            cl_hi[cb + (e >> 3)] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | min(8, cnt - e)));
+            // one 32-byte record per cluster: {lo, hi} interleaved in cl_lo (cl_hi is unused: both halves of a box are
+            // then fetched by two back-to-back 16-byte loads from one address)
+            cl_lo[2 * (cb + (e >> 3))] = make_float4(lx, ly, lz, __int_as_float(c));
+            cl_lo[2 * (cb + (e >> 3)) + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | min(8, cnt - e)));
         }
     }
 }

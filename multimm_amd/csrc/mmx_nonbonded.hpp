@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
         const int vb = !XCDMAP ? j : (j < per16 ? xcd * per16 + j : (8 + xcd) * per16 + (j - per16));
         const int icl = vb * 4 + wave;
         if (icl >= ncl) continue;
-        const float4 lo_i = cl_lo[icl], hi_i = cl_hi[icl];
+        const float4 lo_i = cl_lo[2 * icl], hi_i = cl_lo[2 * icl + 1];
         // wave-uniform values are moved to scalar registers explicitly (v_readfirstlane): hipcc cannot prove
         // uniformity of loaded / ballot-derived values and would otherwise run the loop control on the VALU
         const int c = __builtin_amdgcn_readfirstlane(__float_as_int(lo_i.w));
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                 const int jc = base + lane;
                 bool ok = false;
                 if (jc < c1) {
-                    const float4 lo_j = cl_lo[jc], hi_j = cl_hi[jc];
+                    float4 lo_j = cl_lo[2 * jc], hi_j = cl_lo[2 * jc + 1]; // one 32-byte box record
                     const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
                     const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
                     const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
