@@ -22,7 +22,8 @@ KERNEL_NAMES = ("cell_build", "nonbonded", "backbone", "loops", "confine", "lbfg
 K_CELL_BUILD, K_NONBONDED, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE = range(7)
 COMP_COB, COMP_SCB = 0, 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmmx.so")
+# MMX_LIB: A/B timing of two builds of the library on the same box (scripts/); not a fallback mechanism
+_LIB_PATH = os.environ.get("MMX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmmx.so")
 
 
 class MMXError(RuntimeError):
