@@ -703,6 +703,9 @@ int prepare(mmx_handle_s *h) {
     refresh_params(h);
     if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
         return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
+    if (has_nb(h) && !all_pairs(h) && h->n_all > (1 << 24)) // the cluster kernel addresses spos4 with 32-bit offsets
+        return fail(h, MMX_ERR_BAD_ARG, "the cell-list pair kernel supports up to 2^24 beads (the largest Hilbert start the "
+                                        "reference can build)");
     if (h->Q.generic_pairs && h->nb_variant == 1 && has_nb(h) && !all_pairs(h))
         return fail(h, MMX_ERR_STATE, "nb_variant 1 only implements the default functional forms");
     int rc = ensure_allpairs_scratch(h);

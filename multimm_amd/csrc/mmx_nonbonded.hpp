@@ -255,11 +255,16 @@ __device__ __forceinline__ float fma_sat(float a, float b_sgpr, float c) {
     return r;
 }
 
+// Number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi (2 ops instead of 2 ands + 2 bcnts).
+__device__ __forceinline__ int prefix_count(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
 template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT, bool FORMS = false>
-__global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+__global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
                                                        const int *__restrict__ cstart,
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                     ok = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
                 }
                 const unsigned long long mask = __ballot(ok);
-                if (ok) list[nlist + __popcll(mask & lt)] = jc;
+                if (ok) list[nlist + prefix_count(mask)] = jc;
                 nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
                 base += 64;
             }
@@ -428,13 +433,13 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
             // ---- sweep: 8 j-clusters (64 j beads) per step against the 8 scalar i beads
             int jn = list[sub];
             if (SAMEJ) jn &= 63;
-            float4 qn = spos4[(size_t)jn * kCl + slot];
+            float4 qn = spos4[(unsigned)jn * kCl + slot]; // 32-bit offsets: n_all <= 2^24 beads (checked on the host)
             for (int t = 0; t < nsteps; ++t) {
                 float4 q = qn;
                 if (t + 1 < nsteps) { // prefetch the next 8 clusters
                     jn = list[(t + 1) * 8 + sub];
                     if (SAMEJ) jn &= 63;
-                    qn = spos4[(size_t)jn * kCl + slot];
+                    qn = spos4[(unsigned)jn * kCl + slot];
                 }
                 if (BEADCULL) {
                     // second-level cull per j BEAD against the i-cluster box; survivors are compacted
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 5) void k_nb_clusters_j(const FFPa
                     const float bz = fmaxf(fmaxf(lo_i.z - q.z, q.z - hi_i.z), 0.f);
                     const bool okb = fmaf(bx, bx, fmaf(by, by, bz * bz)) < rc2;
                     const unsigned long long mb = __ballot(okb);
-                    if (okb) ring[(rhead + rcount + __popcll(mb & lt)) & 127] = q;
+                    if (okb) ring[(rhead + rcount + prefix_count(mb)) & 127] = q;
                     rcount += __builtin_amdgcn_readfirstlane(__popcll(mb));
                 }
                 const bool last = !more && (t + 1 == nsteps);
