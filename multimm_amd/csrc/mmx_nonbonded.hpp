@@ -434,12 +434,13 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
             int jn = list[sub];
             if (SAMEJ) jn &= 63;
             float4 qn = spos4[(unsigned)jn * kCl + slot]; // 32-bit offsets: n_all <= 2^24 beads (checked on the host)
+            jn = nsteps > 1 ? list[8 + sub] : far_cl;     // cluster ids are read TWO steps ahead, positions one
             for (int t = 0; t < nsteps; ++t) {
                 float4 q = qn;
-                if (t + 1 < nsteps) { // prefetch the next 8 clusters
-                    jn = list[(t + 1) * 8 + sub];
+                if (t + 1 < nsteps) { // prefetch the next 8 clusters (their ids are already in a register)
                     if (SAMEJ) jn &= 63;
                     qn = spos4[(unsigned)jn * kCl + slot];
+                    jn = t + 2 < nsteps ? list[(t + 2) * 8 + sub] : far_cl;
                 }
                 if (BEADCULL) {
                     // second-level cull per j BEAD against the i-cluster box; survivors are compacted
@@ -457,7 +458,10 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
                 for (int pass = 0; BEADCULL ? (rcount >= 64 || (last && rcount > 0)) : (pass == 0); ++pass) {
                 if (BEADCULL) {
                     wave_lds_sync();
-                    q = lane < rcount ? ring[(rhead + lane) & 127] : far4;
+                    q = ring[(rhead + lane) & 127]; // one 16-byte LDS read; stale slots are replaced below
+                    if (rcount < 64) {              // wave-uniform: only the very last, partial batch
+                        if (lane >= rcount) q = far4;
+                    }
                     const int took = min(rcount, 64);
                     rhead = (rhead + took) & 127;
                     rcount -= took;
