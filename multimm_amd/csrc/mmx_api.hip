@@ -372,9 +372,13 @@ void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
     dim3 b(256), gdim((h->n + 255) / 256, h->ap_slices);
 #define NBA(EV, GA)                                                                                         \
     do {                                                                                                    \
+        const bool nocut = (!(EV) || std::isinf(P.ev_rc2)) && (!(GA) || std::isinf(P.g_rc2));               \
         if (h->Q.generic_pairs)                                                                             \
             hipLaunchKernelGGL((k_nb_allpairs<0, EV, GA, true>), gdim, b, 0, h->stream, P, h->pos4,          \
                                tiles_per_slice, h->fpart, h->epart, h->st, h->formp);                       \
+        else if (nocut) /* the pure NoCutoff case (the reference's semantics): no masks in the pair loop */  \
+            hipLaunchKernelGGL((k_nb_allpairs_lean<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4,       \
+                               tiles_per_slice, h->fpart, h->epart, h->st);                                 \
         else                                                                                                \
             hipLaunchKernelGGL((k_nb_allpairs<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4,            \
                                tiles_per_slice, h->fpart, h->epart, h->st);                                 \

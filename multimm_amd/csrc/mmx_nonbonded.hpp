@@ -7,6 +7,7 @@
 // halved): no atomics, no write conflicts, summation order fixed by the in-cell bead order.
 #pragma once
 #include "mmx_common.hpp"
+#include <type_traits>
 
 namespace mmx {
 
@@ -667,6 +668,88 @@ __global__ __launch_bounds__(256) void k_nb_allpairs(const FFParams P, const flo
         const size_t o = (size_t)blockIdx.y * (size_t)n + (size_t)i;
         fpart[o] = make_float4(a.fx, a.fy, a.fz, 0.f);
         epart[o] = make_float2(a.eev, a.eg);
+    }
+}
+
+// Lean form of K2x for the pure NoCutoff case (no cutoff mask at all: every pair counts, which is exactly what the
+// reference evaluates).  Same factoring as the LEAN cluster loop: eps*sigma^6 and the power p leave the pair loop, the
+// r = 0 guard sits in the r^2 FMA chain, the self pair is masked in the one diagonal tile only:
+// 17 VALU operations per pair with EV only, 21 with the Gaussians, against ~30 of the masked general form.
+template <int PMODE, bool EV, bool GAUSS>
+__global__ __launch_bounds__(256) void k_nb_allpairs_lean(const FFParams P, const float4 *__restrict__ pos4,
+                                                          int tiles_per_slice, float4 *__restrict__ fpart,
+                                                          float2 *__restrict__ epart, const MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ float4 s_tile[256];
+    __shared__ float s_tab[32];
+    if (threadIdx.x < 25) s_tab[threadIdx.x] = P.table[threadIdx.x];
+    const int n = P.n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < n;
+    float4 pi = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(2)); // inactive lanes: far away, label 0
+    if (act) pi = pos4[i];
+    const int li = __float_as_int(pi.w) & 7;
+    __syncthreads();
+    const float *tab5 = s_tab + 5 * li;
+    const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
+    const float ev_c = P.ev_eps * s3 * s3, tiny = 1e-20f;
+    const float escale = (EV && PMODE == 6) ? ev_c : 1.f;
+    const float pscale = EV ? P.ev_power * escale : 1.f;
+    const float g_k = P.g_inv_rc2 / pscale;
+    float fx = 0.f, fy = 0.f, fz = 0.f, eev = 0.f, eg = 0.f;
+    const int t0 = blockIdx.y * tiles_per_slice;
+    for (int tt = 0; tt < tiles_per_slice; ++tt) {
+        const int jb = (t0 + tt) * 256;
+        if (jb >= n) break;
+        const int j = jb + threadIdx.x;
+        __syncthreads();
+        s_tile[threadIdx.x] = pos4[min(j, n - 1)]; // unpredicated load; the loop below stops at the last real bead
+        __syncthreads();
+        const int cnt = min(256, n - jb);
+        // the one tile that holds this block's own beads masks the self pair (adding and removing eps*(sigma/r_s)^p
+        // = 6400 kJ/mol per bead would cost the small pair energies their last digits); all other tiles run unmasked
+        const bool diag = (t0 + tt) == (int)blockIdx.x; // block-uniform
+        auto sweep = [&](auto DIAG) {
+#pragma unroll 4
+            for (int t = 0; t < cnt; ++t) {
+                const float4 q = s_tile[t];
+                const float dx = pi.x - q.x, dy = pi.y - q.y, dz = pi.z - q.z;
+                const float r2t = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, tiny)));
+                const float rinv = __builtin_amdgcn_rsqf(r2t);
+                const float m = (decltype(DIAG)::value && t == (int)threadIdx.x) ? 0.f : 1.f;
+                float fs = 0.f;
+                if (EV) {
+                    const float u = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, P.ev_rs));
+                    float E;
+                    if (PMODE == 6) {
+                        const float u2 = u * u;
+                        E = (u2 * u2) * u2;
+                    } else {
+                        E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
+                    }
+                    if (decltype(DIAG)::value) E *= m;
+                    eev += E;
+                    fs = E * (u * rinv);
+                }
+                if (GAUSS) {
+                    float gg = tab5[__float_as_int(q.w) & 7] * __builtin_amdgcn_exp2f(r2t * P.g_c2);
+                    if (decltype(DIAG)::value) gg *= m;
+                    eg -= gg;
+                    fs = fmaf(-gg, g_k, fs);
+                }
+                fx = fmaf(fs, dx, fx);
+                fy = fmaf(fs, dy, fy);
+                fz = fmaf(fs, dz, fz);
+            }
+        };
+        if (diag) sweep(std::true_type{});
+        else sweep(std::false_type{});
+    }
+    if (act) {
+        eev *= escale;
+        const size_t o = (size_t)blockIdx.y * (size_t)n + (size_t)i;
+        fpart[o] = make_float4(fx * pscale, fy * pscale, fz * pscale, 0.f);
+        epart[o] = make_float2(eev, eg);
     }
 }
 
