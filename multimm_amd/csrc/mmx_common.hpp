@@ -108,6 +108,23 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave total by DPP (no LDS crossbar): butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, 8),
+// then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (gfx9 DPP controls).  The total is valid in
+// lanes 48..63; the result is broadcast from lane 63 through a scalar register.  Fixed order => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0xb1, 0xf>(v);  // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);  // quad_perm:[2,3,0,1]
+    v = dpp_add<0x124, 0xf>(v); // row_ror:4
+    v = dpp_add<0x128, 0xf>(v); // row_ror:8
+    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

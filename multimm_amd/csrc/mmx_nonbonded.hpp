@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
         int ow = -8;
 #pragma unroll
         for (int s = 0; s < kCl; ++s) {
-            const float a0 = wave_sum(fx[s]), a1 = wave_sum(fy[s]), a2 = wave_sum(fz[s]);
+            const float a0 = wave_sum_dpp(fx[s]), a1 = wave_sum_dpp(fy[s]), a2 = wave_sum_dpp(fz[s]);
             if (lane == s) {
                 ofx = a0 * pscale;
                 ofy = a1 * pscale;
