@@ -143,6 +143,7 @@ struct mmx_handle_s {
     int *cstart = nullptr;                       // cluster offsets per cell
     unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
     float nb_scale = 1.f;                        // length scale of spos4 / cluster boxes (see k_nb_clusters_j, LEAN)
+    bool nb_force_plain = false;                 // scaled units unusable (extreme r_comp): unscaled, non-lean instance
     bool nb_skip_energy = false;                 // MD steps between reports: pair forces only (default instance)
     int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
@@ -231,6 +232,7 @@ int nb_launch_opt(const mmx_handle_s *h) {
     const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) | ((h->nb_variant & 128) ? 0 : 8) |
                     ((h->nb_variant & 256) ? 16 : 0) | ((h->nb_variant & 512) ? 32 : 0) |
                     ((h->nb_variant & 1024) ? 64 : 0) | ((h->nb_variant & 2048) ? 128 : 0);
+    if (h->nb_force_plain) return 10; // clamp mask + per-bead cull, per-bead energies: not LEAN, length scale 1
     if (opt == 142) return 142;
     switch (opt & 127) {
     case 14: case 30: case 46: case 22: case 78: case 62: case 6: case 12: case 10: return opt & 127;
@@ -285,10 +287,14 @@ void refresh_params(mmx_handle_s *h) {
                        (h->has_scb && Q.scb_form != 0)) ? 1 : 0;
     // the default cluster-kernel instance with Gaussians on works in scaled length units (exp2(-r'^2))
     // (the kernel's LEAN condition: clamp mask, one cutoff, merged energies, no rank-2 / no-sweep variant)
+    h->nb_force_plain = false;
     const int lo = nb_launch_opt(h);
     const bool lean = !Q.generic_pairs && h->nb_variant != 1 && !all_pairs(h) &&
                       (!(P.use_ev && P.use_gauss) || P.ev_rc2 == P.g_rc2) && (lo & 2) && (lo & 4) && !(lo & 1) && !(lo & 16);
     h->nb_scale = (lean && P.use_gauss) ? std::sqrt(-P.g_c2) : 1.f;
+    // the clamp mask needs (scaled cutoff)^2 well below 1e6: an extreme r_comp falls back to a non-lean instance
+    h->nb_force_plain = lean && P.use_gauss && !(P.rc2max * h->nb_scale * h->nb_scale < 1e5f);
+    if (h->nb_force_plain) h->nb_scale = 1.f;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }

@@ -429,3 +429,14 @@ def test_ensemble_loop_like_the_reference(tmp_path):
     # rank 1 of 2 takes replica 1 only
     res1 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens2")), rank=1, world=2, archive=False, device=0)
     assert [i for i, _, _ in res1] == [1]
+
+
+def test_extreme_compartment_radius_falls_back_to_unscaled_kernel():
+    """The default pair-kernel instance works in length units scaled by sqrt(log2(e)/2)/r_comp; a tiny r_comp (here
+    POL_HARMONIC_BOND_R0 = 1e-4 nm => r_comp = 1.5e-4 nm) would push the scaled cutoff beyond what the clamp mask
+    represents, so the engine must pick the unscaled instance -- and still agree with the oracle."""
+    s = synthetic_system("gw_200k", n_beads=1500, jitter=0.03, seed=8, COB_USE_COMPARTMENT_BLOCKS=True,
+                         POL_HARMONIC_BOND_R0=1e-4, POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False,
+                         SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
+    assert s.radii[2] == pytest.approx(1.5e-4)
+    _check(s, 0.6, "tiny r_comp")
