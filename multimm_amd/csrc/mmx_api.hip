@@ -1129,9 +1129,10 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
 int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) try {
     if (!h) return MMX_ERR_BAD_ARG;
     h->md_forces_valid = false; // forces cached for the MD integrator are stale now
-    if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power))
-        return fail(h, MMX_ERR_BAD_ARG, "bad excluded-volume parameters");
-    h->P.use_ev = 1;
+    if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power) || !(power > 0.f))
+        return fail(h, MMX_ERR_BAD_ARG, "bad excluded-volume parameters (sigma > 0, r_small >= 0, power > 0)");
+    // eps == 0 is a term that contributes nothing: it is left out (the pair kernels factor eps out of the pair loop)
+    h->P.use_ev = eps != 0.f ? 1 : 0;
     h->P.ev_eps = eps;
     h->P.ev_sigma = sigma;
     h->P.ev_rs = r_small;

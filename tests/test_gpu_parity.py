@@ -440,3 +440,18 @@ def test_extreme_compartment_radius_falls_back_to_unscaled_kernel():
                          SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
     assert s.radii[2] == pytest.approx(1.5e-4)
     _check(s, 0.6, "tiny r_comp")
+
+
+def test_zero_strength_terms_are_left_out():
+    """EV_EPSILON = 0 must behave as "no excluded volume" (the pair kernels factor eps out of the pair loop and would
+    otherwise divide by it), and a zero compartment amplitude as no attraction."""
+    s0 = synthetic_system("gw_200k", n_beads=2000, jitter=0.03, seed=1, COB_USE_COMPARTMENT_BLOCKS=True, EV_EPSILON=0.0)
+    et, F = _check(s0, 0.6, "eps = 0")
+    assert et[0] == 0.0 and et[1] != 0.0 and np.all(np.isfinite(F))
+    s1 = synthetic_system("gw_200k", n_beads=2000, jitter=0.03, seed=1, COB_USE_COMPARTMENT_BLOCKS=True, COB_EA=0.0, COB_EB=0.0)
+    et, F = _check(s1, 0.6, "Ea = Eb = 0")
+    assert et[1] == 0.0 and et[0] != 0.0
+    from multimm_amd.engine import MMXError
+    with engine_for(s1) as eng:
+        with pytest.raises(MMXError):
+            eng.set_excluded_volume(100.0, 0.1, 0.05, 0.0, 0.6)   # power must be positive
