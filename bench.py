@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
                     help="N > 1: 'ensemble' = one replica per GPU (config 4, weak scaling, no collective); "
                          "'dd' = ONE system decomposed over the GPUs (config 5, strong scaling, RCCL)")
+    ap.add_argument("--serial-bonded", action="store_true",
+                    help="bonded terms on the main stream instead of beside the cell build (A/B of the overlap)")
     ap.add_argument("--separate-bonded", action="store_true",
                     help="run backbone / loops / confinement as three kernels (per-kernel timing) instead of the "
                          "fused default")
@@ -119,6 +121,8 @@ def main():
         eng = engine_for(system, device=local_rank)
     eng.set_option("profile", 0)
     eng.set_option("fused_bonded", 0 if args.separate_bonded else 1)
+    if args.serial_bonded:
+        eng.set_option("overlap_bonded", 0)
 
     def barrier():
         if world > 1:

@@ -185,7 +185,7 @@ struct mmx_handle_s {
     FormParams Q{};               // derived constants of the non-default forms (host copy)
     FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
     // options
-    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1;
+    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
     // profiling
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};
@@ -487,7 +487,12 @@ void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
     }
 }
 
-void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
+void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
+
+// Pack (+ trial move / integrator step), then the cell build.  With `bonded` set, the bonded terms of the evaluation
+// -- which only need pos4 -- are enqueued with it: inside the launch of the cell scan ("overlap_bonded", default), or
+// right behind the pack.
+void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
@@ -528,6 +533,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
                            h->labels, h->pos4, h->bbox_part, h->st);
     if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
         coll_allgather_pos4(h);
+    const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
+    if (bonded && !in_scan) enqueue_bonded(h, *bonded, false);
     if (has_nb(h) && !all_pairs(h)) {
         const float hm = hmin_of(h);
         GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
@@ -537,8 +544,18 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
         if (!fuse_count)
             hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
                                cur, h->cell_of, h->rank_in_cell, h->count, h->st);
-        hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, h->bbox_part, gb, hm,
-                           h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next, h->st);
+        const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next};
+        if (in_scan) { // block 0 scans, the others are the bonded pass (four virtual 256-thread blocks each)
+            const int nvb = grid_beads(h->n_own);
+            const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+            const bool loops_on = h->n_rows > 0 && h->lstart;
+            hipLaunchKernelGGL((k_scan_bonded<kChunk>), dim3(1 + (nvb + 3) / 4), dim3(1024), 0, h->stream, sa, h->st,
+                               h->P, h->pos4, bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner,
+                               h->loop_r0, h->cf_w, h->g, h->part, h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb);
+            enqueue_bonded(h, *bonded, true);
+        } else {
+            hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
+        }
         hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                            h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order
@@ -555,17 +572,79 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false) {
     }
 }
 
-// One full energy+gradient evaluation followed by the line-search controller.
-void enqueue_eval(mmx_handle_s *h, int mode) {
+// Bonded terms + confinement (+ chromosomal blocks): the FIRST writers of the gradient in an evaluation (they read
+// pos4 only); the pair kernel adds its forces afterwards.  in_scan: the fused bonded pass already went out inside
+// k_scan_bonded, only its bookkeeping and the chromosomal blocks are left.
+void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan) {
+    EventPair ep{};
+    const int gb = grid_beads(h->n_own);
+    const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+    const bool loops_on = h->n_rows > 0 && h->lstart;
+    bool on;
+    if (in_scan) {
+        h->launches[MMX_K_CONFINE]++;
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
+    } else if (h->fused_bonded) {
+        // backbone + loops + confinement in one pass; booked in the "confine" timing slot
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL(k_bonded_fused, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, bb_on ? h->flags : nullptr,
+                           loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part, h->st,
+                           h->Q.loop_form, h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
+    } else {
+        (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
+        if (bb_on) {
+            on = prof_begin(h, MMX_K_BACKBONE, ep);
+            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                               h->st);
+            prof_end(h, on, ep);
+            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
+        }
+        if (h->n_rows > 0) {
+            const int gl = std::min((h->n_rows + 255) / 256, 1024);
+            on = prof_begin(h, MMX_K_LOOPS, ep);
+            hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
+                               h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
+            prof_end(h, on, ep);
+            A.nblk[P_LOOP] = gl;
+        }
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL(k_confine, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part, h->st,
+                           h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
+    }
+    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = gb;
+    if (h->P.use_chb && h->chrom_of) {
+        const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
+        on = prof_begin(h, MMX_K_CHB, ep);
+#define CHB(F)                                                                                              \
+    hipLaunchKernelGGL((k_chb<F>), dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,    \
+                       h->chrom_hi, h->g, h->part, h->st)
+        if (h->Q.chb_form == 0) CHB(0);
+        else if (h->Q.chb_form == 1) CHB(1);
+        else CHB(2);
+#undef CHB
+        prof_end(h, on, ep);
+        A.nblk[P_CHB] = std::min(gc, kPartStride);
+    }
+}
+
+// What follows the forces of an evaluation.
+enum { FOLD_NONE = 0, // nothing (MD steps whose energies nobody reads)
+       FOLD_PLAIN,    // fold the energies (mmx_compute, MD reports)
+       FOLD_MIN };    // minimizer: history pass, then energies + line search + direction coefficients
+
+// One full energy+gradient evaluation: pack/move, [bonded terms || cell build], pair kernel, fold.
+void enqueue_eval(mmx_handle_s *h, int mode, int fold) {
     EventPair ep{};
     CtlArgs A{};
     bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
-    enqueue_build(h, mode);
+    enqueue_build(h, mode, false, &A);
     prof_end(h, on, ep);
-
     on = prof_begin(h, MMX_K_NONBONDED, ep);
     if (!has_nb(h)) {
-        (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
+        // the bonded pass wrote the whole gradient
     } else if (all_pairs(h)) {
         const int tiles = (h->n + 255) / 256;
         const int tps = (tiles + h->ap_slices - 1) / h->ap_slices;
@@ -588,84 +667,35 @@ void enqueue_eval(mmx_handle_s *h, int mode) {
         A.nblk[P_EV] = A.nblk[P_GAUSS] = gn;
     }
     prof_end(h, on, ep);
+    if (fold == FOLD_NONE) return;
 
-    const int gb = grid_beads(h->n_own);
-    const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
-    const bool loops_on = h->n_rows > 0 && h->lstart;
-    auto launch_chb = [&]() {
-        if (!(h->P.use_chb && h->chrom_of)) return;
-        const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
-        bool onc = prof_begin(h, MMX_K_CHB, ep);
-#define CHB(F)                                                                                              \
-    hipLaunchKernelGGL((k_chb<F>), dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,    \
-                       h->chrom_hi, h->g, h->part, h->st)
-        if (h->Q.chb_form == 0) CHB(0);
-        else if (h->Q.chb_form == 1) CHB(1);
-        else CHB(2);
-#undef CHB
-        prof_end(h, onc, ep);
-        A.nblk[P_CHB] = std::min(gc, kPartStride);
-    };
-    if (h->fused_bonded) {
-        // backbone + loops + confinement (+ line-search dots) in one pass; booked in the "confine" timing slot
-        launch_chb();
-        on = prof_begin(h, MMX_K_CONFINE, ep);
-        hipLaunchKernelGGL((k_bonded_fused<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4,
-                           bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w,
-                           h->g, h->d, h->part, h->st, h->Q.loop_form, h->Q.lam_form, h->Q.cf_form);
-        prof_end(h, on, ep);
-        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
-    } else {
-        if (bb_on) {
-            on = prof_begin(h, MMX_K_BACKBONE, ep);
-            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
-                               h->st);
-            prof_end(h, on, ep);
-            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
-        }
-        if (h->n_rows > 0) {
-            const int gl = std::min((h->n_rows + 255) / 256, 1024);
-            on = prof_begin(h, MMX_K_LOOPS, ep);
-            hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
-                               h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
-            prof_end(h, on, ep);
-            A.nblk[P_LOOP] = gl;
-        }
-        launch_chb();
-        on = prof_begin(h, MMX_K_CONFINE, ep);
-        hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->d,
-                           h->part, h->st, h->Q.lam_form, h->Q.cf_form);
+    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
+    if (fold == FOLD_MIN) {
+        // (s, y) of the step this evaluation would accept, its Gram rows, g.d and x.x: before the decision, so that
+        // decision and direction coefficients are ONE launch (and, multi-GPU, one all-reduce)
+        on = prof_begin(h, MMX_K_LBFGS, ep);
+        hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
+                           (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (const float4 *)h->d,
+                           (float4 *)h->S, (float4 *)h->Y, h->rows, h->st);
         prof_end(h, on, ep);
     }
-    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = A.nblk[P_GD] = A.nblk[P_GG] = A.nblk[P_XX] = gb;
-
     on = prof_begin(h, MMX_K_REDUCE, ep);
-    if (!has_comm(h)) {
+    if (fold == FOLD_MIN) {
+        if (!has_comm(h)) {
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
+        } else { // energies, Gram rows, g.d, x.x of all ranks: ONE fp64 all-reduce of 57 doubles per evaluation
+            hipLaunchKernelGGL(k_reduce_all, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
+            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
+        }
+        // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
+    } else if (!has_comm(h)) {
         hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
-    } else { // energies + g.d, g.g, x.x of all ranks: one fp64 all-reduce of 16 doubles per evaluation
+    } else { // energies of all ranks: one fp64 all-reduce of 16 doubles
         hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
         coll_allreduce(h, h->st->sums, 16);
         hipLaunchKernelGGL(k_controller_decide, dim3(1), dim3(64), 0, h->stream, h->st);
     }
-    prof_end(h, on, ep);
-}
-
-// History update + direction coefficients; every kernel is a no-op unless the controller accepted the step.
-void enqueue_accept(mmx_handle_s *h) {
-    EventPair ep{};
-    bool on = prof_begin(h, MMX_K_LBFGS, ep);
-    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
-    hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
-                       (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (float4 *)h->S,
-                       (float4 *)h->Y, h->rows, h->st);
-    if (!has_comm(h)) {
-        hipLaunchKernelGGL(k_direction_coef, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
-    } else { // the 39 Gram-row entries of all ranks: one fp64 all-reduce per accepted iteration
-        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kCtlThreads), 0, h->stream, gh, h->rows, h->st);
-        coll_allreduce(h, h->st->rowsum, MMX_NROWS * MMX_NBASIS + 1);
-        hipLaunchKernelGGL(k_direction_coef_decide, dim3(1), dim3(64), 0, h->stream, h->st);
-    }
-    // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
     prof_end(h, on, ep);
 }
 
@@ -830,7 +860,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->grid, 2));
         HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n_own + 255) / 256 + 1)));
         HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
-        HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWS * MMX_NBASIS * kPartStride));
+        HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWSUM * kPartStride));
         HIPCHK(h, dalloc(&h->st, 1));
         HIPCHK(h, hipHostMalloc((void **)&h->st_host, sizeof(MinState), hipHostMallocDefault));
         std::memset(h->st_host, 0, sizeof(MinState));
@@ -1282,6 +1312,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "poll_interval") h->poll_interval = std::max(1, (int)value);
     else if (k == "nb_variant") h->nb_variant = (int)value;
     else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
+    else if (k == "overlap_bonded") h->overlap_bonded = value != 0.0;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -1294,6 +1325,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "poll_interval") *value = h->poll_interval;
     else if (k == "nb_variant") *value = h->nb_variant;
     else if (k == "fused_bonded") *value = h->fused_bonded;
+    else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
@@ -1308,7 +1340,7 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) try {
     h->st_host->phase = PH_IDLE;
     if ((rc = push_state(h))) return rc;
     if ((rc = prime_items(h))) return rc;
-    enqueue_eval(h, PACK_PLAIN);
+    enqueue_eval(h, PACK_PLAIN, FOLD_PLAIN);
     if ((rc = pull_state(h))) return rc;
     HIPCHK(h, hipGetLastError());
     prof_collect(h, nullptr);
@@ -1359,16 +1391,14 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
-    enqueue_eval(h, PACK_PLAIN);
-    enqueue_accept(h);
+    enqueue_eval(h, PACK_PLAIN, FOLD_MIN);
     if ((rc = pull_state(h))) return rc;
     local.e_initial = h->st_host->fx;
     while (h->st_host->phase != PH_DONE) {
         int batch = h->poll_interval;
         if (max_iters > 0) batch = std::max(1, std::min(batch, max_iters - h->st_host->iters));
         for (int b = 0; b < batch; ++b) {
-            enqueue_eval(h, PACK_MOVE);
-            enqueue_accept(h);
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN);
         }
         if ((rc = pull_state(h))) return rc;
         if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
@@ -1494,14 +1524,15 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         // positions / parameters changed: low-order position bits restart at zero, forces are recomputed
         HIPCHK(h, hipMemsetAsync(h->xlo, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream));
         if ((rc = prime_items(h))) return rc;
-        enqueue_eval(h, PACK_PLAIN);
+        enqueue_eval(h, PACK_PLAIN, FOLD_PLAIN);
         h->md_forces_valid = true;
     }
     const int poll_every = 8 * std::max(1, h->poll_interval);
     for (int s = 0; s < n_steps; ++s) {
         // pair energies are only needed where they are read: at the last step (report) and at the polls (NaN check)
-        h->nb_skip_energy = !(s + 1 == n_steps || (s + 1) % poll_every == 0);
-        enqueue_eval(h, PACK_MD);
+        const bool report = s + 1 == n_steps || (s + 1) % poll_every == 0;
+        h->nb_skip_energy = !report;
+        enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE);
         h->nb_skip_energy = false;
         h->md_step++;
         if ((s + 1) % poll_every == 0) { // bound the queue depth; learn the cluster count
@@ -1555,7 +1586,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
     h->st_host->phase = PH_IDLE;
     if ((rc = push_state(h))) return rc;
     if ((rc = prime_items(h))) return rc;
-    enqueue_eval(h, PACK_PLAIN); // warm: builds cells, fills every buffer the slot reads
+    enqueue_eval(h, PACK_PLAIN, FOLD_PLAIN); // warm: builds cells, fills every buffer the slot reads
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
@@ -1607,8 +1638,8 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             bytes = 64.0 * h->n_loops;
             break;
         case MMX_K_CONFINE:
-            hipLaunchKernelGGL((k_confine<true>), dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g,
-                               h->d, h->part, h->st, h->Q.lam_form, h->Q.cf_form);
+            hipLaunchKernelGGL(k_confine, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part,
+                               h->st, h->Q.lam_form, h->Q.cf_form);
             bytes = 25.0 * h->n;
             break;
         }

@@ -3,6 +3,7 @@
 // the gradient of bead i itself (neighbours come from L1/L2), so there are no atomics and the result
 // is bitwise reproducible.  Each does g[i] += dE/dx_i.
 #pragma once
+#include "mmx_cells.hpp"
 #include "mmx_common.hpp"
 
 namespace mmx {
@@ -170,9 +171,9 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
 }
 
 // K5.  Container (model.py:454-456), B-lamina "sin" shell (model.py:503-505), central force
-// (model.py:584-586) on r = |x - centre|; afterwards the gradient of bead i is final, so the kernel
-// also produces the three reductions the line search needs: g.d, g.g, x.x.
-// Algorithmic traffic: read 16 B pos4, read-modify-write 12 B gradient (+12 B d when DOTS).
+// (model.py:584-586) on r = |x - centre|.
+// Algorithmic traffic: read 16 B pos4, read-modify-write 12 B gradient.  (The reductions of the line search --
+// g.d, g.g, x.x -- are taken by k_history once every term has been added.)
 // External terms of one bead (container, lamina in form lam_form, central force in form cf_form, weight w_i) on
 // r = |x - centre|: energies into (ec, el, ef), dE/dx added to (gx,gy,gz).
 __device__ __forceinline__ void confine_bead(const FFParams &P, const float4 p, const float w_i, const int lam_form,
@@ -242,31 +243,22 @@ __device__ __forceinline__ void confine_bead(const FFParams &P, const float4 p, 
     gz = fmaf(s, dz, gz);
 }
 
-template <bool DOTS>
 __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 *__restrict__ pos4,
                                                  const float *__restrict__ cf_w, float *__restrict__ g,
-                                                 const float *__restrict__ d, double *__restrict__ part,
-                                                 const MinState *__restrict__ st, const int lam_form,
-                                                 const int cf_form) {
+                                                 double *__restrict__ part, const MinState *__restrict__ st,
+                                                 const int lam_form, const int cf_form) {
     if (st->phase == PH_DONE) return;
     __shared__ double s_w[4];
-    double ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
+    double ec = 0.0, el = 0.0, ef = 0.0;
     const bool any = P.use_container | P.use_lamina | P.use_central;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < P.n_own; i += gridDim.x * 256) { // i: local index
+        if (!any) break;
         const float4 p = pos4[P.own_lo + i];
         float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
-        if (any) {
-            confine_bead(P, p, P.use_central ? cf_w[P.own_lo + i] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
-            g[3 * i] = gx;
-            g[3 * i + 1] = gy;
-            g[3 * i + 2] = gz;
-        }
-        if (DOTS) {
-            const float d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2];
-            gd += (double)gx * d0 + (double)gy * d1 + (double)gz * d2;
-            gg += (double)gx * gx + (double)gy * gy + (double)gz * gz;
-            xx += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
-        }
+        confine_bead(P, p, P.use_central ? cf_w[P.own_lo + i] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
+        g[3 * i] = gx;
+        g[3 * i + 1] = gy;
+        g[3 * i + 2] = gz;
     }
     const double sc = block_sum<256>(ec, s_w);
     const double sl = block_sum<256>(el, s_w);
@@ -276,40 +268,33 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
         part[P_LAM * kPartStride + blockIdx.x] = sl;
         part[P_CENT * kPartStride + blockIdx.x] = sf;
     }
-    if (DOTS) {
-        const double s1 = block_sum<256>(gd, s_w);
-        const double s2 = block_sum<256>(gg, s_w);
-        const double s3 = block_sum<256>(xx, s_w);
-        if (threadIdx.x == 0) {
-            part[P_GD * kPartStride + blockIdx.x] = s1;
-            part[P_GG * kPartStride + blockIdx.x] = s2;
-            part[P_XX * kPartStride + blockIdx.x] = s3;
-        }
-    }
 }
 
 // K3 + K4 + K5 in ONE pass over the owned beads (default; the separate kernels above stay selectable with the
-// option "fused_bonded" = 0 and are what mmx_time_kernel measures): one read-modify-write of the gradient instead
-// of three, two launches fewer per evaluation.  Same per-bead arithmetic and the same order of the fp32 additions
-// (g + backbone + loops, then the confinement terms), so the result is bitwise the one of the separate kernels.
+// option "fused_bonded" = 0 and are what mmx_time_kernel measures): one write of the gradient instead of three
+// read-modify-writes, two launches fewer per evaluation.  The bonded terms are the FIRST writers of the gradient in an
+// evaluation (they only need pos4, so they run beside the cell build on a second stream); the pair kernels add to
+// it afterwards.  Same per-bead arithmetic and the same order of the fp32 additions (0 + backbone + loops, then the
+// confinement terms), so the result is bitwise the one of the separate kernels after a memset.
 // lstart[li] .. lstart[li+1]: loop entries (partner, r0) of owned bead li in the CSR of mmx_set_loops.
-template <bool DOTS>
-__global__ __launch_bounds__(256) void k_bonded_fused(const FFParams P, const float4 *__restrict__ pos4,
-                                                      const uint8_t *__restrict__ flags, const int *__restrict__ lstart,
-                                                      const int *__restrict__ partner, const float *__restrict__ r0,
-                                                      const float *__restrict__ cf_w, float *__restrict__ g,
-                                                      const float *__restrict__ d, double *__restrict__ part,
-                                                      const MinState *__restrict__ st, const int loop_form,
-                                                      const int lam_form, const int cf_form) {
-    if (st->phase == PH_DONE) return;
-    __shared__ double s_w[4];
-    double eb = 0.0, ea = 0.0, elp = 0.0, ec = 0.0, el = 0.0, ef = 0.0, gd = 0.0, gg = 0.0, xx = 0.0;
+// The work of one VIRTUAL block of 256 threads (vb of nvb): either a real 256-thread block (k_bonded_fused) or one
+// quarter of a 1024-thread block of k_scan_bonded.  Partials are per virtual block, so both launches give bitwise
+// the same sums.  Must be called by every thread of the real block (barriers); s_w holds one double per wave.
+template <int NT>
+__device__ __forceinline__ void bonded_fused_block(const FFParams &P, const float4 *__restrict__ pos4,
+                                                   const uint8_t *__restrict__ flags, const int *__restrict__ lstart,
+                                                   const int *__restrict__ partner, const float *__restrict__ r0,
+                                                   const float *__restrict__ cf_w, float *__restrict__ g,
+                                                   double *__restrict__ part, const int loop_form, const int lam_form,
+                                                   const int cf_form, const int vb, const int nvb, double *s_w) {
+    double eb = 0.0, ea = 0.0, elp = 0.0, ec = 0.0, el = 0.0, ef = 0.0;
     const bool bb = flags != nullptr && (P.use_bond | P.use_angle);
     const bool any = P.use_container | P.use_lamina | P.use_central;
-    for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
+    const int tv = threadIdx.x & 255;
+    for (int li = vb < nvb ? vb * 256 + tv : P.n_own; li < P.n_own; li += nvb * 256) {
         const int i = P.own_lo + li;
         const float4 p = pos4[i];
-        float gx = g[3 * li], gy = g[3 * li + 1], gz = g[3 * li + 2];
+        float gx = 0.f, gy = 0.f, gz = 0.f; // first writer of the gradient: the pair kernels add to it afterwards
         if (bb) {
             float tx = 0.f, ty = 0.f, tz = 0.f;
             backbone_bead(P, pos4, flags, i, eb, ea, tx, ty, tz);
@@ -333,20 +318,58 @@ __global__ __launch_bounds__(256) void k_bonded_fused(const FFParams P, const fl
         g[3 * li] = gx;
         g[3 * li + 1] = gy;
         g[3 * li + 2] = gz;
-        if (DOTS) {
-            const float d0 = d[3 * li], d1 = d[3 * li + 1], d2 = d[3 * li + 2];
-            gd += (double)gx * d0 + (double)gy * d1 + (double)gz * d2;
-            gg += (double)gx * gx + (double)gy * gy + (double)gz * gz;
-            xx += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
+    }
+    const double v[6] = {eb, ea, elp, ec, el, ef};
+    const int slot[6] = {P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double w = wave_sum(v[k]);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = w;
+        __syncthreads();
+        if (tv == 0 && vb < nvb) { // the four waves of this virtual block, in order (== block_sum<256>)
+            const double *q = s_w + (wave & ~3);
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r += q[j];
+            part[slot[k] * kPartStride + vb] = r;
         }
     }
-    const double v[9] = {eb, ea, elp, ec, el, ef, gd, gg, xx};
-    const int slot[9] = {P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT, P_GD, P_GG, P_XX};
-#pragma unroll
-    for (int k = 0; k < (DOTS ? 9 : 6); ++k) {
-        const double r = block_sum<256>(v[k], s_w);
-        if (threadIdx.x == 0) part[slot[k] * kPartStride + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void k_bonded_fused(const FFParams P, const float4 *__restrict__ pos4,
+                                                      const uint8_t *__restrict__ flags, const int *__restrict__ lstart,
+                                                      const int *__restrict__ partner, const float *__restrict__ r0,
+                                                      const float *__restrict__ cf_w, float *__restrict__ g,
+                                                      double *__restrict__ part, const MinState *__restrict__ st,
+                                                      const int loop_form, const int lam_form, const int cf_form) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_w[4];
+    bonded_fused_block<256>(P, pos4, flags, lstart, partner, r0, cf_w, g, part, loop_form, lam_form, cf_form,
+                            (int)blockIdx.x, (int)gridDim.x, s_w);
+}
+
+// Horizontal fusion of the cell build's single-block scan with the bonded pass: block 0 scans the cell populations
+// (k_cell_scan's work, 1024 threads), every other block is four virtual bonded blocks.  The scan would otherwise
+// leave 255 CUs idle for ~10 us per evaluation and the bonded pass only needs pos4, so the two share one launch
+// (option "overlap_bonded"; a second stream was measured instead and lost more in cross-stream events than it hid).
+template <int CHUNK>
+__global__ __launch_bounds__(1024) void k_scan_bonded(const ScanArgs a, MinState *__restrict__ st, const FFParams P,
+                                                      const float4 *__restrict__ pos4,
+                                                      const uint8_t *__restrict__ flags, const int *__restrict__ lstart,
+                                                      const int *__restrict__ partner, const float *__restrict__ r0,
+                                                      const float *__restrict__ cf_w, float *__restrict__ g,
+                                                      double *__restrict__ part, const int loop_form,
+                                                      const int lam_form, const int cf_form, const int nvb) {
+    if (st->phase == PH_DONE) return;
+    if (blockIdx.x == 0) {
+        cell_scan_block<CHUNK>(a, st);
+        return;
     }
+    __shared__ double s_w[16];
+    bonded_fused_block<1024>(P, pos4, flags, lstart, partner, r0, cf_w, g, part, loop_form, lam_form, cf_form,
+                             ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 8), nvb, s_w);
 }
 
 // K7.  Chromosomal blocks (model.py:416-419): E = dE*(k_C r^4 - r^3 + r^2) for every pair of beads of the

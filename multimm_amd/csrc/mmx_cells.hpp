@@ -236,14 +236,26 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
 
 // Single-block exclusive scan of the cell populations (bead offsets) and of the per-cell chunk
 // counts (work-item offsets); publishes the item count and the grid of the next build.
+struct ScanArgs {
+    const float *bbox_part;
+    int nblk;
+    float hmin;
+    int maxcells;
+    const int *count;
+    int *start, *istart, *cstart, *biglist;
+    const GridParams *grid;
+    GridParams *grid_next;
+};
 template <int CHUNK>
-__global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bbox_part, int nblk, float hmin,
-                                                    int maxcells, const int *__restrict__ count,
-                                                    int *__restrict__ start, int *__restrict__ istart,
-                                                    int *__restrict__ cstart, int *__restrict__ biglist,
-                                                    const GridParams *__restrict__ grid,
-                                                    GridParams *__restrict__ grid_next, MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+__device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__restrict__ st) {
+    const float *__restrict__ bbox_part = a.bbox_part;
+    const int nblk = a.nblk, maxcells = a.maxcells;
+    const float hmin = a.hmin;
+    const int *__restrict__ count = a.count;
+    int *__restrict__ start = a.start, *__restrict__ istart = a.istart, *__restrict__ cstart = a.cstart,
+                      *__restrict__ biglist = a.biglist;
+    const GridParams *__restrict__ grid = a.grid;
+    GridParams *__restrict__ grid_next = a.grid_next;
     __shared__ int s_a[64], s_b[64], s_c[64], s_d[64], s_m[16];
     __shared__ float s_red[6 * 16];
     const GridParams G = *grid;
@@ -338,6 +350,11 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const float *__restrict__ bb
         st->max_per_cell = m;
         st->cell_edge = (double)G.h;
     }
+}
+template <int CHUNK>
+__global__ __launch_bounds__(1024) void k_cell_scan(const ScanArgs a, MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    cell_scan_block<CHUNK>(a, st);
 }
 
 // 12-bit Morton code of a position inside its cell (16 sub-cells per axis).

@@ -1,11 +1,17 @@
 // mmx_common.hpp -- shared device/host structures and wave-level helpers (gfx950, wave64).
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define MMX_M 6                    // L-BFGS history (liblbfgs default m, used by OpenMM)
 #define MMX_NBASIS (2 * MMX_M + 1) // basis {S_0..S_5, Y_0..Y_5, g}
 #define MMX_NROWS 3                // Gram rows recomputed per accepted iteration: s_new, y_new, g
+// k_history's block partials: the MMX_NROWS x MMX_NBASIS Gram entries, then the two line-search reductions that are
+// not Gram entries (g.g is): g.d and x.x.
+#define MMX_ROW_GD (MMX_NROWS * MMX_NBASIS)
+#define MMX_ROW_XX (MMX_NROWS * MMX_NBASIS + 1)
+#define MMX_NROWSUM (MMX_NROWS * MMX_NBASIS + 2)
 
 namespace mmx {
 
@@ -93,9 +99,10 @@ struct MinState {
     double ys[MMX_M];
     double gram[MMX_NBASIS * MMX_NBASIS];
     double coef[MMX_NBASIS];
-    double sums[16];                         // folded slot sums (all-reduced across ranks in a multi-GPU run)
-    double rowsum[MMX_NROWS * MMX_NBASIS + 1]; // folded Gram rows (same)
+    double sums[16];             // folded slot sums (all-reduced across ranks in a multi-GPU run)
+    double rowsum[MMX_NROWSUM];  // folded k_history rows (same; directly behind sums: ONE all-reduce covers both)
 };
+static_assert(offsetof(MinState, rowsum) == offsetof(MinState, sums) + 16 * sizeof(double), "sums and rowsum are reduced as one array");
 
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -2,10 +2,11 @@
 // backtracking strong-Wolfe line search) as a state machine advanced once per evaluation.
 //
 // The two-loop recursion is done in coefficient space over the basis B = {S_0..S_5, Y_0..Y_5, g}:
-// one streaming pass (k_history) stores the new (s,y) pair and produces the three Gram rows that
-// changed, a single thread runs the recursion on the 13x13 Gram matrix (k_direction_coef), and the
-// next trial move (k_pack<.., DIR>) forms d = sum_a c_a B_a while it packs the positions.  No host round trip, two reductions per
-// iteration instead of 2m sequential ones; the same Gram rows are what a multi-GPU run all-reduces.
+// one streaming pass (k_history) right after the evaluation stores the (s,y) pair the step WOULD add and produces
+// the three Gram rows that would change plus the line search's g.d and x.x; one block (k_decide) folds the energies
+// and those rows, runs the line-search controller and -- when the step is accepted -- the recursion on the 13x13 Gram
+// matrix; the next trial move (k_pack<.., DIR>) forms d = sum_a c_a B_a while it packs the positions.  No host
+// round trip, ONE reduction point per evaluation (a multi-GPU run: one all-reduce of 57 doubles).
 #pragma once
 #include "mmx_common.hpp"
 
@@ -62,13 +63,14 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
     __syncthreads();
 }
 
-// Fold of the Gram-row partials: NQ rows of nblk (<= 256) block partials each, rows kPartStride apart.  Wave w
-// takes rows w, w+16, w+32: every lane issues all its loads (<= 4 per row) back to back -- one latency round for
-// the whole fold -- then three shuffle trees.  Fixed order => deterministic.  s_out valid after the barrier.
+// Fold of k_history's partials: NQ rows of nblk (<= 256) block partials each, rows kPartStride apart.  Wave w
+// takes rows w, w+16, w+32: every lane issues all its loads (<= 4 per row) back to back (rows_load; the caller puts
+// the slot fold between load and finish, so both folds share one latency round), then three shuffle trees
+// (rows_finish).  Fixed order => deterministic.  s_out valid after the barrier.
 template <int NQ>
-__device__ __forceinline__ void rows_sum(const double *__restrict__ rows, int nblk, double *s_out) {
+__device__ __forceinline__ void rows_load(const double *__restrict__ rows, int nblk, double (&acc)[3]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double acc[3] = {0.0, 0.0, 0.0};
+    acc[0] = acc[1] = acc[2] = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = wave + 16 * j;
@@ -81,6 +83,10 @@ __device__ __forceinline__ void rows_sum(const double *__restrict__ rows, int nb
             }
         }
     }
+}
+template <int NQ>
+__device__ __forceinline__ void rows_finish(const double (&acc)[3], double *s_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = wave + 16 * j;
@@ -183,59 +189,29 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
 }
 
 
-// Single-GPU: fold the block partials and decide in one launch.
-__global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
-                                                     MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
-    __shared__ double s_task[kMaxTasks];
-    __shared__ double s_out[P_NSLOTS];
-    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
-    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
-    __syncthreads();
-    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    if (threadIdx.x != 0) return;
-    double sums[P_NSLOTS];
-#pragma unroll
-    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
-    controller_decide(st, sums);
-}
-
-// Multi-GPU: fold -> st->sums (ncclAllReduce, fp64 sum, in place) -> decide.
-__global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const double *__restrict__ part,
-                                                       MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) {
-        if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0; // keep the collective's input finite
-        return;
-    }
-    __shared__ double s_task[kMaxTasks];
-    __shared__ double s_out[P_NSLOTS];
-    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
-    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
-    __syncthreads();
-    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
-}
-__global__ void k_controller_decide(MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || threadIdx.x != 0) return;
-    double sums[P_NSLOTS];
-    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
-    controller_decide(st, sums);
-}
-
-// Accepted step: s = x - xp, y = g - gp into slot `end`, and the Gram rows of {s_new, y_new, g}
-// against the whole basis as block partials rows[(r*13 + b)*stride + blockIdx.x].
+// Runs right after every evaluation of the minimizer, BEFORE the line-search decision (so that decision and
+// direction coefficients are one launch, k_decide): s = x - xp, y = g - gp into slot `end` -- the slot the step
+// would occupy if accepted; a rejected trial just leaves values there that the next trial overwrites, nothing reads
+// that slot in between (d is already formed, the Gram matrix only changes on acceptance) -- and the Gram rows of
+// {s_new, y_new, g} against the whole basis as block partials rows[(r*13 + b)*stride + blockIdx.x].  The last column
+// group also takes the two line-search reductions that are not Gram entries: g.d (row MMX_ROW_GD) and x.x
+// (MMX_ROW_XX).  In PH_INIT (first evaluation) nothing is stored and s = y = 0.
 // 2-D grid: blockIdx.y picks a group of <= 4 basis columns (12 fp64 accumulators per thread instead of
 // 39: full occupancy); every group re-reads x, xp, g, gp (L2/MALL resident), only the last group
 // stores the new pair.  xp <- x and gp <- g are done afterwards by the next trial move (no intra-kernel race).
 constexpr int kHistGroups = 4;
 __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restrict__ x, const float4 *__restrict__ xp,
                                                  const float4 *__restrict__ g, const float4 *__restrict__ gp,
-                                                 float4 *__restrict__ S, float4 *__restrict__ Y,
-                                                 double *__restrict__ rows, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || !st->accepted) return;
+                                                 const float4 *__restrict__ d, float4 *__restrict__ S,
+                                                 float4 *__restrict__ Y, double *__restrict__ rows,
+                                                 const MinState *__restrict__ st) {
+    const int phase = st->phase;
+    if (phase != PH_INIT && phase != PH_LINESEARCH) return;
     __shared__ double s_w[MMX_NROWS * 4 * 4];
     const int slot = st->end;
-    const bool store = st->store_hist != 0;
+    const bool store = phase == PH_LINESEARCH;
+    const bool last = blockIdx.y == kHistGroups - 1;
+    double e_gd = 0.0, e_xx = 0.0;
     const int cg = blockIdx.y, col0 = cg * 4, ncol = min(4, MMX_NBASIS - col0);
     const float4 *colp[4];
     int colkind[4]; // 0: stored vector, 1: s_new, 2: y_new, 3: g
@@ -268,9 +244,14 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
             sn = make_float4(0.f, 0.f, 0.f, 0.f);
             yn = sn;
         }
-        if (store && cg == kHistGroups - 1) {
-            S[(size_t)slot * n4 + i] = sn;
-            Y[(size_t)slot * n4 + i] = yn;
+        if (last) {
+            const float4 D = d[i];
+            e_gd += ((double)G.x * D.x + (double)G.y * D.y) + ((double)G.z * D.z + (double)G.w * D.w);
+            e_xx += ((double)X.x * X.x + (double)X.y * X.y) + ((double)X.z * X.z + (double)X.w * X.w);
+            if (store) {
+                S[(size_t)slot * n4 + i] = sn;
+                Y[(size_t)slot * n4 + i] = yn;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -300,6 +281,19 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
         if (k < ncol) {
             const double *q = s_w + threadIdx.x * 4;
             rows[(size_t)(r * MMX_NBASIS + col0 + k) * kPartStride + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    }
+    if (last) { // block-uniform
+        __syncthreads();
+        const double s1 = wave_sum(e_gd), s2 = wave_sum(e_xx);
+        if (lane == 0) {
+            s_w[wave] = s1;
+            s_w[4 + wave] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const double *q = s_w + 4 * threadIdx.x;
+            rows[(size_t)(MMX_ROW_GD + threadIdx.x) * kPartStride + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
         }
     }
 }
@@ -368,32 +362,104 @@ __device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const dou
 }
 
 
-__global__ __launch_bounds__(1024) void k_direction_coef(int nblk, const double *__restrict__ rows,
-                                                         MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || !st->accepted) return;
-    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
-    static_assert(NQ <= 48, "rows_sum covers 3 rows per wave");
-    __shared__ double s_rows[NQ];
-    rows_sum<NQ>(rows, nblk, s_rows); // nblk <= 256 (enqueue_accept)
-    if (threadIdx.x != 0) return;
-    coef_decide(st, s_rows);
+// Dots of the line search as k_history produced them (g.g is the Gram entry <g,g>).
+__device__ __forceinline__ void dots_from_rows(double *sums, const double *rowsum) {
+    sums[P_GD] = rowsum[MMX_ROW_GD];
+    sums[P_GG] = rowsum[2 * MMX_NBASIS + 2 * MMX_M];
+    sums[P_XX] = rowsum[MMX_ROW_XX];
 }
 
-// Multi-GPU: fold -> st->rowsum (ncclAllReduce) -> decide.
-__global__ __launch_bounds__(1024) void k_reduce_rows(int nblk, const double *__restrict__ rows,
-                                                      MinState *__restrict__ st) {
-    constexpr int NQ = MMX_NROWS * MMX_NBASIS;
-    if (st->phase == PH_DONE || !st->accepted) {
-        if (threadIdx.x <= NQ) st->rowsum[threadIdx.x] = 0.0;
+__device__ __forceinline__ void slot_counts(const CtlArgs &A, int *s_n) {
+    if (threadIdx.x < P_NSLOTS) s_n[threadIdx.x] = A.nblk[threadIdx.x];
+    __syncthreads();
+}
+
+// Plain evaluation (mmx_compute, MD reports), single GPU: fold the energy partials.
+__global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
+                                                     MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    slot_counts(A, s_n);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    if (threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+#pragma unroll
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
+    controller_decide(st, sums);
+}
+
+// Minimizer, single GPU: energies + k_history rows folded together, line-search decision, and on acceptance the
+// direction coefficients -- one launch per evaluation.
+__global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
+                                                 const double *__restrict__ rows, MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) return;
+    static_assert(MMX_NROWSUM <= 48, "rows_load covers 3 rows per wave");
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ double s_rows[MMX_NROWSUM];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    double acc[3];
+    rows_load<MMX_NROWSUM>(rows, nblk_rows, acc); // nblk_rows <= 256 (enqueue_history)
+    slot_counts(A, s_n);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    rows_finish<MMX_NROWSUM>(acc, s_rows);
+    if (threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+#pragma unroll
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
+    dots_from_rows(sums, s_rows);
+    controller_decide(st, sums);
+    if (st->accepted) coef_decide(st, s_rows);
+}
+
+// Multi-GPU: fold -> st->sums (+ st->rowsum) -> ncclAllReduce (fp64 sum, in place) -> decide on every rank.
+__global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const double *__restrict__ part,
+                                                       MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) {
+        if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0; // keep the collective's input finite
         return;
     }
-    __shared__ double s_rows[NQ];
-    rows_sum<NQ>(rows, nblk, s_rows);
-    if (threadIdx.x < NQ) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    slot_counts(A, s_n);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
 }
-__global__ void k_direction_coef_decide(MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || !st->accepted || threadIdx.x != 0) return;
-    coef_decide(st, st->rowsum);
+__global__ void k_controller_decide(MinState *__restrict__ st) {
+    if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
+    controller_decide(st, sums);
+}
+__global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
+                                                     const double *__restrict__ rows, MinState *__restrict__ st) {
+    if (st->phase == PH_DONE) {
+        if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0;
+        if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
+        return;
+    }
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ double s_rows[MMX_NROWSUM];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    double acc[3];
+    rows_load<MMX_NROWSUM>(rows, nblk_rows, acc);
+    slot_counts(A, s_n);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    rows_finish<MMX_NROWSUM>(acc, s_rows);
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
+    if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+}
+__global__ void k_decide_reduced(MinState *__restrict__ st) {
+    if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    double sums[P_NSLOTS];
+    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
+    dots_from_rows(sums, st->rowsum);
+    controller_decide(st, sums);
+    if (st->accepted) coef_decide(st, st->rowsum);
 }
 
 // d = sum_a coef[a] * B_a (with xp <- x, gp <- g) is formed per bead by the next trial move: k_pack<.., DIR> in

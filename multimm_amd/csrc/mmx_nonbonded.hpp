@@ -215,9 +215,9 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
             const float ev = a.eev + s_red[0][3][lane] + s_red[1][3][lane];
             const float eg = a.eg + s_red[0][4][lane] + s_red[1][4][lane];
             if (act) {
-                g[3 * bead] = -fx;
-                g[3 * bead + 1] = -fy;
-                g[3 * bead + 2] = -fz;
+                g[3 * bead] -= fx; // the bonded terms wrote the gradient first
+                g[3 * bead + 1] -= fy;
+                g[3 * bead + 2] -= fz;
             }
             const float sev = wave_sum(act ? ev : 0.f), seg = wave_sum(act ? eg : 0.f);
             acc_ev += 0.5 * (double)sev;
@@ -598,9 +598,11 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
                 }
             }
             if (GAUSS && !FORMS && !NOENERGY) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
-            g[3 * (bead - P.own_lo)] = -ofx;
-            g[3 * (bead - P.own_lo) + 1] = -ofy;
-            g[3 * (bead - P.own_lo) + 2] = -ofz;
+            float *gb = g + 3 * (bead - P.own_lo); // the bonded terms wrote the gradient first
+            const float g0 = gb[0], g1 = gb[1], g2 = gb[2];
+            gb[0] = g0 - ofx;
+            gb[1] = g1 - ofy;
+            gb[2] = g2 - ofz;
         }
         const float sev = wave_sum(tev), seg = wave_sum(teg);
         acc_ev += 0.5 * (double)sev;
@@ -771,9 +773,9 @@ __global__ __launch_bounds__(256) void k_nb_allpairs_fold(int n, int nslices, co
             e1 += e.x;
             e2 += e.y;
         }
-        g[3 * i] = -fx;
-        g[3 * i + 1] = -fy;
-        g[3 * i + 2] = -fz;
+        g[3 * i] -= fx; // the bonded terms wrote the gradient first
+        g[3 * i + 1] -= fy;
+        g[3 * i + 2] -= fz;
         ev += 0.5 * (double)e1;
         eg += 0.5 * (double)e2;
     }
