@@ -183,11 +183,15 @@ def main():
                     except Exception:
                         pass
         kern = {k: v for k, v in d["kernel_us_mean"].items() if v}
-        # default: backbone + loops + confinement run as ONE kernel booked under "confine" (sum of the three
-        # kernels' algorithmic bytes); --separate-bonded times them individually
-        alg_bytes = {"cell_build": 56.0 * n, "backbone": 25.0 * n, "loops": 64.0 * system.n_loops,
-                     "confine": 25.0 * n if args.separate_bonded else 50.0 * n + 64.0 * system.n_loops,
-                     "lbfgs": 384.0 * n}
+        # default: backbone + loops + confinement are ONE pass (38 B/bead + 64 B/loop) that rides in the launch of the
+        # cell scan, i.e. inside the "cell_build" slot, which also forms the L-BFGS direction (168 B/bead) in its pack;
+        # --serial-bonded books the pass under "confine", --separate-bonded times the three kernels individually.
+        # "lbfgs" = k_history: 228 B/bead.
+        fused_bytes = 38.0 * n + 64.0 * system.n_loops
+        in_scan = not (args.serial_bonded or args.separate_bonded) and args.cutoff > 0
+        alg_bytes = {"cell_build": (56.0 + 168.0) * n + (fused_bytes if in_scan else 0.0), "backbone": 25.0 * n,
+                     "loops": 64.0 * system.n_loops, "confine": 25.0 * n if args.separate_bonded else fused_bytes,
+                     "lbfgs": 228.0 * n}
         kernel_gbs = {k: alg_bytes[k] / (kern[k] * 1e-6) / 1e9 for k in alg_bytes if k in kern}
         ms_per_step = dt * 1e3 / max(iters, 1)
         out = {
@@ -216,7 +220,8 @@ def main():
             "evals_per_s": st.evaluations * (1 if dd else world) / dt,
             "status": st.status, "e_initial": st.e_initial, "e_final": st.e_final, "rms_force": st.rms_force,
             "kernel_us_mean": kern,
-            "bonded_kernels": "separate" if args.separate_bonded else "fused into the confine slot",
+            "bonded_kernels": ("separate" if args.separate_bonded else "one pass, confine slot" if not in_scan
+                               else "one pass inside the cell-scan launch (cell_build slot)"),
             "kernel_algorithmic_GBps": kernel_gbs,
             "roofline": roofline,
         }
