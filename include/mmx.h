@@ -50,13 +50,13 @@ enum {
 
 /* Kernel slots of mmx_stats.kernel_* and mmx_time_kernel(). */
 enum {
-    MMX_K_CELL_BUILD = 0, /* K1: bbox + cell hash + count + scan + fill + in-cell order */
+    MMX_K_CELL_BUILD = 0, /* K1: pack (+ trial move, direction) + cell hash + count + scan (+ bonded pass) + fill + order */
     MMX_K_NONBONDED = 1,  /* K2: cell-list pair kernel (or K2x all-pairs when cutoff <= 0) */
     MMX_K_BACKBONE = 2,   /* K3: bonds + angles */
     MMX_K_LOOPS = 3,      /* K4: loop restraints */
     MMX_K_CONFINE = 4,    /* K5: container + lamina + central */
-    MMX_K_LBFGS = 5,      /* K6: all L-BFGS vector kernels of one accepted iteration */
-    MMX_K_REDUCE = 6,     /* energy/dot reductions + line-search controller */
+    MMX_K_LBFGS = 5,      /* K6: history pass of an evaluation ((s,y) candidate, Gram rows, g.d, x.x) */
+    MMX_K_REDUCE = 6,     /* fold of the partials + line-search controller (+ direction coefficients) */
     MMX_K_CHB = 7,        /* chromosomal blocks: all pairs inside each chromosome */
     MMX_N_KERNELS = 8
 };
@@ -185,8 +185,10 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "profile"           k>0: HIP-event time every k-th launch of each kernel slot       0
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0
- * "fused_bonded"      1: backbone + loops + confinement in one kernel (booked in the "confine"
- *                     timing slot); 0: the three kernels separately (per-kernel timing)       1
+ * "fused_bonded"      1: backbone + loops + confinement in one pass; 0: the three kernels
+ *                     separately (per-kernel timing)                                  1
+ * "overlap_bonded"    1: that one pass rides in the launch of the cell scan (cell-list mode; booked
+ *                     in the cell-build slot); 0: its own launch ("confine" slot)     1
  * "order_fallbacks"   (get only) cells of the last call that were too large for the in-LDS sort and
  *                     kept arrival order: 0 means the summation order was bitwise reproducible
  */
