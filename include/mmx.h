@@ -215,20 +215,27 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
  *   MMX_INT_LANGEVIN  mm.LangevinIntegrator(T, friction, dt)   (the default, config.py:258-266)
  *   MMX_INT_VERLET    mm.VerletIntegrator(dt)
  *   MMX_INT_BROWNIAN  mm.BrownianIntegrator(T, friction, dt)
- * (variable-step and aMD integrators are not provided: MMX_ERR_BAD_ARG).
+ *   MMX_INT_AMD       mm.amd.AMDIntegrator(dt, alpha, E), model.py:794-800: accelerated MD, a leap-frog step
+ *                     on the boosted force f' = f (alpha / (alpha + E - U))^2 while the potential energy U of the
+ *                     current positions is below E, f' = f otherwise; alpha and E from mmx_md_set_amd
+ *                     (temperature and friction of mmx_md_configure are ignored)
+ * (the variable-step integrators -- which the reference itself cannot construct, model.py:776,791 read a missing
+ * attribute -- are not provided: MMX_ERR_BAD_ARG).
  * Units: ps, K, 1/ps, amu (ff.xml:5: 16427.889 for every bead); velocities nm/ps.  Noise comes from
  * Philox4x32-10 keyed by `seed` and indexed by (bead, step): independent of the launch geometry and of the
  * decomposition over GPUs (it is not OpenMM's generator: trajectories agree in distribution only). */
 #define MMX_INT_LANGEVIN 0
 #define MMX_INT_VERLET 1
 #define MMX_INT_BROWNIAN 2
+#define MMX_INT_AMD 3
 
 typedef struct {
     int64_t step_count;  /* steps integrated since mmx_md_configure (State.getStepCount(), model.py:939) */
     int32_t n_steps;     /* steps of this call */
     int32_t integrator;
     double potential;    /* kJ/mol at the final positions (State.getPotentialEnergy(), model.py:943) */
-    double kinetic;      /* kJ/mol; leap-frog velocities shifted by dt/2 as OpenMM reports them (model.py:944) */
+    double kinetic;      /* kJ/mol; leap-frog velocities shifted by dt/2 as OpenMM reports them (model.py:944);
+                            brownian and aMD (a CustomIntegrator: plain m v^2 / 2): unshifted */
     double temperature;  /* 2 K / (3 N kB) in kelvin (the fallback formula of model.py:966-970) */
     double seconds;      /* wall time of the call */
     double energy_terms[MMX_N_TERMS];
@@ -236,6 +243,9 @@ typedef struct {
 
 int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temperature_K, double friction_per_ps,
                      double mass_amu, uint64_t seed);
+/* Boost parameters of MMX_INT_AMD in kJ/mol: SIM_AMD_ALPHA, SIM_AMD_E (config.py:255-256: 100, 1000), the
+ * alpha and E of mm.amd.AMDIntegrator(dt, alpha, E), model.py:796-800.  alpha > 0. */
+int mmx_md_set_amd(mmx_handle h, double alpha_kj_per_mol, double e_kj_per_mol);
 /* context.setVelocitiesToTemperature(T, seed), model.py:878: v = sqrt(kB T / m) N(0,1) per component. */
 int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uint64_t seed);
 /* [N,3] nm/ps, whole system (multi-GPU: the owned rows are used / filled, other rows are left untouched). */

@@ -73,10 +73,12 @@ class SimulationConfig:
     SIM_RUN_MD: bool = False
     SIM_N_STEPS: int = 10000           # config.py:253
     SIM_SAMPLING_STEP: int = 100       # config.py:257
-    SIM_INTEGRATOR_TYPE: str = "langevin"   # config.py:258; MI355X provides langevin / verlet / brownian
+    SIM_INTEGRATOR_TYPE: str = "langevin"   # config.py:258; MI355X provides langevin / verlet / brownian / amd
     SIM_INTEGRATOR_STEP: float = 0.001      # ps  ("1 femtosecond", config.py:259)
     SIM_FRICTION_COEFF: float = 0.5         # 1/ps (config.py:260-262)
     SIM_TEMPERATURE: float = 310.0          # K   (config.py:266)
+    SIM_AMD_ALPHA: float = 100.0            # kJ/mol (config.py:255)
+    SIM_AMD_E: float = 1000.0               # kJ/mol (config.py:256)
     TRJ_FRAMES: int = 2000                  # config.py:267
     MIN_TOLERANCE: float = 10.0        # OpenMM minimizeEnergy() default, kJ/mol/nm
     MIN_MAX_ITERATIONS: int = 0        # 0 = until converged
@@ -148,7 +150,8 @@ def load_config(path_or_dict) -> SimulationConfig:
                 setattr(cfg, key, int(float(sval)) if sval is not None else getattr(cfg, key))
             elif key in ("LOC_START", "LOC_END", "N_ENSEMBLE"):
                 setattr(cfg, key, int(float(sval)) if sval is not None else None)
-            elif key in ("MIN_TOLERANCE", "SIM_INTEGRATOR_STEP", "SIM_FRICTION_COEFF", "SIM_TEMPERATURE"):
+            elif key in ("MIN_TOLERANCE", "SIM_INTEGRATOR_STEP", "SIM_FRICTION_COEFF", "SIM_TEMPERATURE",
+                         "SIM_AMD_ALPHA", "SIM_AMD_E"):
                 setattr(cfg, key, parse_quantity(val))
             else:
                 setattr(cfg, key, sval if sval is None else str(sval))

@@ -179,6 +179,7 @@ struct mmx_handle_s {
     bool md_configured = false, md_forces_valid = false;
     int md_kind = 0;
     double md_dt = 0.0, md_temp = 0.0, md_friction = 0.0, md_mass = 1.0;
+    double amd_alpha = 100.0, amd_e = 1000.0; // config.py:255-256
     uint64_t md_seed = 0, md_step = 0;
     MdParams md{};
     int forms[MMX_N_SELECTORS]{}; // functional form per term selector (0 = default)
@@ -505,14 +506,15 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     do {                                                                                                    \
         if (fuse_count)                                                                                     \
             hipLaunchKernelGGL((k_md_pack<K, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, \
-                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M,                      \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial,      \
                                h->grid + (h->build_idx & 1), h->cell_of, h->rank_in_cell, h->count);        \
         else                                                                                                \
             hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,   \
-                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M);                     \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial);     \
     } while (0)
         if (h->md_kind == MD_LANGEVIN) MDP(MD_LANGEVIN);
         else if (h->md_kind == MD_VERLET) MDP(MD_VERLET);
+        else if (h->md_kind == MD_AMD) MDP(MD_AMD);
         else MDP(MD_BROWNIAN);
 #undef MDP
     } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
@@ -1444,7 +1446,7 @@ static void md_refresh(mmx_handle_s *h) {
         M.vscale = (float)a;
         M.fscale = (float)((gam > 0.0 ? (1.0 - a) / gam : dt) / m);
         M.noise = (float)std::sqrt(kT * (1.0 - a * a) / m);
-    } else if (h->md_kind == MD_VERLET) {
+    } else if (h->md_kind == MD_VERLET || h->md_kind == MD_AMD) {
         M.vscale = 1.f;
         M.fscale = (float)(dt / m);
         M.noise = 0.f;
@@ -1453,13 +1455,15 @@ static void md_refresh(mmx_handle_s *h) {
         M.fscale = (float)(dt / (gam * m));
         M.noise = (float)std::sqrt(2.0 * kT * dt / (gam * m));
     }
+    M.amd_alpha = h->amd_alpha;
+    M.amd_e = h->amd_e;
 }
 
 int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temperature_K, double friction_per_ps,
                      double mass_amu, uint64_t seed) try {
     if (!h) return MMX_ERR_BAD_ARG;
-    if (integrator < MMX_INT_LANGEVIN || integrator > MMX_INT_BROWNIAN)
-        return fail(h, MMX_ERR_BAD_ARG, "integrator must be MMX_INT_LANGEVIN, MMX_INT_VERLET or MMX_INT_BROWNIAN");
+    if (integrator < MMX_INT_LANGEVIN || integrator > MMX_INT_AMD)
+        return fail(h, MMX_ERR_BAD_ARG, "integrator must be MMX_INT_LANGEVIN, MMX_INT_VERLET, MMX_INT_BROWNIAN or MMX_INT_AMD");
     if (!(dt_ps > 0.0) || !(mass_amu > 0.0) || !(temperature_K >= 0.0) || !(friction_per_ps >= 0.0) ||
         (integrator == MMX_INT_BROWNIAN && !(friction_per_ps > 0.0)))
         return fail(h, MMX_ERR_BAD_ARG, "bad integrator parameters");
@@ -1478,6 +1482,16 @@ int mmx_md_configure(mmx_handle h, int32_t integrator, double dt_ps, double temp
     h->md_step = 0;
     h->md_configured = true;
     h->md_forces_valid = false;
+    md_refresh(h);
+    return MMX_OK;
+} MMX_CATCH(h)
+
+int mmx_md_set_amd(mmx_handle h, double alpha_kj_per_mol, double e_kj_per_mol) try {
+    if (!h) return MMX_ERR_BAD_ARG;
+    if (!(alpha_kj_per_mol > 0.0) || !(e_kj_per_mol - e_kj_per_mol == 0.0))
+        return fail(h, MMX_ERR_BAD_ARG, "aMD needs alpha > 0 and a finite E");
+    h->amd_alpha = alpha_kj_per_mol;
+    h->amd_e = e_kj_per_mol;
     md_refresh(h);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -1530,7 +1544,8 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     const int poll_every = 8 * std::max(1, h->poll_interval);
     for (int s = 0; s < n_steps; ++s) {
         // pair energies are only needed where they are read: at the last step (report) and at the polls (NaN check)
-        const bool report = s + 1 == n_steps || (s + 1) % poll_every == 0;
+        // aMD reads the potential energy of the current positions at every step
+        const bool report = h->md_kind == MD_AMD || s + 1 == n_steps || (s + 1) % poll_every == 0;
         h->nb_skip_energy = !report;
         enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE);
         h->nb_skip_energy = false;
@@ -1546,7 +1561,7 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     }
     // kinetic energy with the half-step shift OpenMM applies to leap-frog velocities (none for brownian)
     const int gk = std::min((h->n_own + 255) / 256, 1024);
-    const double shift = h->md_kind == MD_BROWNIAN ? 0.0 : 0.5 * h->md_dt;
+    const double shift = (h->md_kind == MD_BROWNIAN || h->md_kind == MD_AMD) ? 0.0 : 0.5 * h->md_dt;
     hipLaunchKernelGGL(k_md_kinetic, dim3(gk), dim3(256), 0, h->stream, h->n_own, h->v, h->g, (float)(shift / h->md_mass),
                        0.5 * h->md_mass, h->ke_part);
     hipLaunchKernelGGL(k_md_kinetic_fold, dim3(1), dim3(256), 0, h->stream, gk, h->ke_part, h->ke_out);

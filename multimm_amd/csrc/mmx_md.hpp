@@ -14,7 +14,7 @@
 
 namespace mmx {
 
-enum MdKind { MD_LANGEVIN = 0, MD_VERLET = 1, MD_BROWNIAN = 2 };
+enum MdKind { MD_LANGEVIN = 0, MD_VERLET = 1, MD_BROWNIAN = 2, MD_AMD = 3 };
 
 struct MdParams {
     float dt;       // ps
@@ -24,6 +24,7 @@ struct MdParams {
     float inv_dt;
     uint32_t key0, key1;       // seed
     uint32_t step_lo, step_hi; // step index of this launch
+    double amd_alpha, amd_e;   // aMD boost: f' = f (alpha / (alpha + E - U))^2 while U < E (kJ/mol)
 };
 
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
                                                  float *__restrict__ v, const float *__restrict__ g,
                                                  const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
                                                  float *__restrict__ bbox_part, const MdParams M,
+                                                 const double *__restrict__ epot, // aMD: U of the current positions
                                                  const GridParams *__restrict__ grid = nullptr,
                                                  int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
                                                  int *__restrict__ count = nullptr) {
@@ -72,10 +74,18 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n_own;
     float p[3] = {0.f, 0.f, 0.f};
+    float boost = 1.f;
+    if (KIND == MD_AMD) { // mm.amd.AMDIntegrator: modify = step(E - energy); (alpha / (alpha + E - energy))^2
+        const double u = *epot;
+        if (M.amd_e - u >= 0.0) {
+            const double r = M.amd_alpha / (M.amd_alpha + M.amd_e - u);
+            boost = (float)(r * r);
+        }
+    }
     if (act) {
         const int bead = own_lo + i;
         float z[3] = {0.f, 0.f, 0.f};
-        if (KIND != MD_VERLET) normal3((uint32_t)bead, M.step_lo, M.step_hi, 0u, M.key0, M.key1, z);
+        if (KIND == MD_LANGEVIN || KIND == MD_BROWNIAN) normal3((uint32_t)bead, M.step_lo, M.step_hi, 0u, M.key0, M.key1, z);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float f = -g[3 * i + k];
@@ -85,6 +95,9 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
                 dx = vel * M.dt;
             } else if (KIND == MD_VERLET) {
                 vel = fmaf(M.fscale, f, vel);
+                dx = vel * M.dt;
+            } else if (KIND == MD_AMD) {
+                vel = fmaf(M.fscale * boost, f, vel);
                 dx = vel * M.dt;
             } else {
                 dx = fmaf(M.fscale, f, M.noise * z[k]);

@@ -60,7 +60,7 @@ class MMXMdStats(C.Structure):
                 ("seconds", C.c_double), ("energy_terms", C.c_double * N_TERMS)]
 
 
-INTEGRATORS = {"langevin": 0, "verlet": 1, "brownian": 2}  # MMX_INT_*; model.py:768-808
+INTEGRATORS = {"langevin": 0, "verlet": 1, "brownian": 2, "amd": 3}  # MMX_INT_*; model.py:768-808
 BEAD_MASS_AMU = 16427.889                                   # forcefields/ff.xml:5
 
 _lib: Optional[C.CDLL] = None
@@ -98,6 +98,7 @@ SIGNATURES = {
     "mmx_compute": (C.c_int, [_P, _P, _P]),
     "mmx_minimize": (C.c_int, [_P, C.c_double, C.c_int32, C.POINTER(MMXStats)]),
     "mmx_md_configure": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64]),
+    "mmx_md_set_amd": (C.c_int, [_P, C.c_double, C.c_double]),
     "mmx_md_set_velocities_to_temperature": (C.c_int, [_P, C.c_double, C.c_uint64]),
     "mmx_set_velocities": (C.c_int, [_P, _P]),
     "mmx_get_velocities": (C.c_int, [_P, _P]),
@@ -295,12 +296,17 @@ class Engine:
 
     # -- molecular dynamics (model.py:768-808, 878, 907-995) -------------------------------------------
     def md_configure(self, integrator: str = "langevin", dt_ps: float = 0.001, temperature_K: float = 310.0,
-                     friction_per_ps: float = 0.5, mass_amu: float = BEAD_MASS_AMU, seed: int = 0):
+                     friction_per_ps: float = 0.5, mass_amu: float = BEAD_MASS_AMU, seed: int = 0,
+                     amd_alpha: float = 100.0, amd_e: float = 1000.0):
+        """``integrator`` "amd" = mm.amd.AMDIntegrator(dt, amd_alpha, amd_e) (model.py:794-800; kJ/mol, defaults of
+        config.py:255-256); temperature and friction are ignored by it and by "verlet"."""
         if integrator not in INTEGRATORS:
             raise MMXError(-1, f"integrator {integrator!r} is not provided by the MI355X engine "
                                f"(available: {', '.join(INTEGRATORS)})")
         self._chk(self._lib.mmx_md_configure(self._h, INTEGRATORS[integrator], float(dt_ps), float(temperature_K),
                                              float(friction_per_ps), float(mass_amu), int(seed)))
+        if integrator == "amd":
+            self._chk(self._lib.mmx_md_set_amd(self._h, float(amd_alpha), float(amd_e)))
 
     def set_velocities_to_temperature(self, temperature_K: float, seed: int = 0):
         self._chk(self._lib.mmx_md_set_velocities_to_temperature(self._h, float(temperature_K), int(seed)))

@@ -150,7 +150,8 @@ class MultiMM:
         kind = str(a.SIM_INTEGRATOR_TYPE).lower()
         eng = self.engine
         eng.md_configure(kind, dt_ps=float(a.SIM_INTEGRATOR_STEP), temperature_K=float(a.SIM_TEMPERATURE),
-                         friction_per_ps=float(a.SIM_FRICTION_COEFF), seed=int(a.SHUFFLING_SEED))
+                         friction_per_ps=float(a.SIM_FRICTION_COEFF), seed=int(a.SHUFFLING_SEED),
+                         amd_alpha=float(a.SIM_AMD_ALPHA), amd_e=float(a.SIM_AMD_E))
         # context.setVelocitiesToTemperature(SIM_TEMPERATURE, SHUFFLING_SEED), model.py:878 (the minimizer
         # leaves velocities alone, so setting them here is equivalent)
         eng.set_velocities_to_temperature(float(a.SIM_TEMPERATURE), int(a.SHUFFLING_SEED))
@@ -177,7 +178,8 @@ class MultiMM:
                 self.md_history["total"].append(st.potential + st.kinetic)
                 # model.py:959-972: integrator.getTemperature() (the bath set point) when the integrator has
                 # one, else 2K / (3 N kB)
-                self.md_history["temperature"].append(float(a.SIM_TEMPERATURE) if kind != "verlet" else kinetic_T)
+                self.md_history["temperature"].append(kinetic_T if kind in ("verlet", "amd")
+                                                      else float(a.SIM_TEMPERATURE))
                 self.state_positions = eng.get_positions().astype(np.float64)
                 cif.write_structure(os.path.join(a.OUT_PATH, "md_frames", f"frame_{i + 1}.cif"),
                                     self.state_positions, self.chr_ends)

@@ -763,8 +763,14 @@ typedef struct {
 /* kind: 0 langevin, 1 verlet, 2 brownian.  Advances (x, v) by n_steps starting at step index step0 and
  * reports the energies at the final point the way OpenMM does (kinetic energy of velocities shifted by
  * half a step for the leap-frog integrators, unshifted for brownian).  Returns 0 / -1. */
-int orc_md_step(const orc_system *s, int kind, double dt, double temperature, double friction, double mass,
-                uint64_t seed, int64_t step0, int32_t n_steps, double *x, double *v, orc_md_stats *st) {
+/* kind 3 = mm.amd.AMDIntegrator(dt, alpha, E) (model.py:794-800; OpenMM app amd.py [upstream]): a CustomIntegrator
+ *   v <- v + dt f'/m,  f' = f ((1 - modify) + modify (alpha / (alpha + E - energy))^2),  modify = step(E - energy)
+ *   x <- x + dt v
+ * with `energy` the potential energy of the current positions; its kinetic energy is the CustomIntegrator default
+ * m v^2 / 2 (no half-step shift). */
+static int md_step_impl(const orc_system *s, int kind, double dt, double temperature, double friction, double mass,
+                        double amd_alpha, double amd_e, uint64_t seed, int64_t step0, int32_t n_steps, double *x,
+                        double *v, orc_md_stats *st) {
     const int n = s->n;
     double *F = (double *)malloc(sizeof(double) * 3 * (size_t)n);
     if (!F) return -1;
@@ -775,7 +781,7 @@ int orc_md_step(const orc_system *s, int kind, double dt, double temperature, do
     if (kind == 0) {
         fscale = (friction > 0.0 ? (1.0 - a) / friction : dt) / mass;
         noise = sqrt(kT * (1.0 - a * a) / mass);
-    } else if (kind == 1) {
+    } else if (kind == 1 || kind == 3) {
         fscale = dt / mass;
         noise = 0.0;
     } else {
@@ -785,9 +791,18 @@ int orc_md_step(const orc_system *s, int kind, double dt, double temperature, do
     if (orc_eval(s, x, F, et) != 0) { free(F); return -1; }
     for (int32_t k = 0; k < n_steps; ++k) {
         const uint64_t step = (uint64_t)(step0 + k);
+        double boost = 1.0;
+        if (kind == 3) {
+            double u = 0.0;
+            for (int t = 0; t < ORC_N_TERMS; ++t) u += et[t];
+            if (amd_e - u >= 0.0) {
+                const double r = amd_alpha / (amd_alpha + amd_e - u);
+                boost = r * r;
+            }
+        }
         for (int i = 0; i < n; ++i) {
             double z[3] = {0.0, 0.0, 0.0};
-            if (kind != 1) orc_normal3((uint32_t)i, step, 0, seed, z);
+            if (kind == 0 || kind == 2) orc_normal3((uint32_t)i, step, 0, seed, z);
             for (int q = 0; q < 3; ++q) {
                 const int64_t c = 3 * (int64_t)i + q;
                 if (kind == 0) {
@@ -795,6 +810,9 @@ int orc_md_step(const orc_system *s, int kind, double dt, double temperature, do
                     x[c] += v[c] * dt;
                 } else if (kind == 1) {
                     v[c] += fscale * F[c];
+                    x[c] += v[c] * dt;
+                } else if (kind == 3) {
+                    v[c] += fscale * boost * F[c];
                     x[c] += v[c] * dt;
                 } else {
                     const double dx = fscale * F[c] + noise * z[q];
@@ -806,7 +824,7 @@ int orc_md_step(const orc_system *s, int kind, double dt, double temperature, do
         if (orc_eval(s, x, F, et) != 0) { free(F); return -1; }
     }
     if (st) {
-        const double shift = kind == 2 ? 0.0 : 0.5 * dt;
+        const double shift = (kind == 2 || kind == 3) ? 0.0 : 0.5 * dt;
         double ke = 0.0, pot = 0.0;
         for (int64_t c = 0; c < 3 * (int64_t)n; ++c) {
             const double w = v[c] + shift * F[c] / mass;
@@ -824,4 +842,15 @@ int orc_md_step(const orc_system *s, int kind, double dt, double temperature, do
     }
     free(F);
     return 0;
+}
+
+int orc_md_step(const orc_system *s, int kind, double dt, double temperature, double friction, double mass,
+                uint64_t seed, int64_t step0, int32_t n_steps, double *x, double *v, orc_md_stats *st) {
+    if (kind < 0 || kind > 2) return -1;
+    return md_step_impl(s, kind, dt, temperature, friction, mass, 0.0, 0.0, seed, step0, n_steps, x, v, st);
+}
+
+int orc_md_step_amd(const orc_system *s, double dt, double mass, double amd_alpha, double amd_e, int64_t step0,
+                    int32_t n_steps, double *x, double *v, orc_md_stats *st) {
+    return md_step_impl(s, 3, dt, 0.0, 0.0, mass, amd_alpha, amd_e, 0, step0, n_steps, x, v, st);
 }

@@ -51,7 +51,7 @@ class OrcMdStats(C.Structure):
                 ("temperature", C.c_double), ("eterms", C.c_double * N_TERMS)]
 
 
-MD_KINDS = {"langevin": 0, "verlet": 1, "brownian": 2}
+MD_KINDS = {"langevin": 0, "verlet": 1, "brownian": 2, "amd": 3}
 
 # Functional forms by ini key, default first (config.py:269-312; branches of model.py:173-215, 229-292, 305-382,
 # 395-449, 479-544, 557-615, 648-703).  The index is what orc_system.*_form holds.
@@ -93,6 +93,9 @@ def lib() -> C.CDLL:
         _lib.orc_md_step.restype = C.c_int
         _lib.orc_md_step.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_uint64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(OrcMdStats)]
+        _lib.orc_md_step_amd.restype = C.c_int
+        _lib.orc_md_step_amd.argtypes = [C.POINTER(OrcSystem), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(OrcMdStats)]
         assert _lib.orc_sizeof_system() == C.sizeof(OrcSystem), "OrcSystem layout mismatch"
     return _lib
 
@@ -211,11 +214,18 @@ class Oracle:
 
 
     def md_step(self, x, v, n_steps, kind="langevin", dt=0.001, temperature=310.0, friction=0.5,
-                mass=16427.889, seed=0, step0=0):
-        """Advances copies of (x, v) by n_steps of the named integrator; returns (x, v, OrcMdStats)."""
+                mass=16427.889, seed=0, step0=0, amd_alpha=100.0, amd_e=1000.0):
+        """Advances copies of (x, v) by n_steps of the named integrator; returns (x, v, OrcMdStats).
+        kind "amd": mm.amd.AMDIntegrator(dt, amd_alpha, amd_e) (model.py:794-800; config.py:255-256 defaults)."""
         x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.s.n_beads, 3)).copy()
         v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(self.s.n_beads, 3)).copy()
         st = OrcMdStats()
+        if kind == "amd":
+            rc = lib().orc_md_step_amd(C.byref(self.o), float(dt), float(mass), float(amd_alpha), float(amd_e),
+                                       int(step0), int(n_steps), x.ctypes.data, v.ctypes.data, C.byref(st))
+            if rc != 0:
+                raise MemoryError("oracle allocation failed")
+            return x, v, st
         rc = lib().orc_md_step(C.byref(self.o), MD_KINDS[kind], float(dt), float(temperature), float(friction),
                                float(mass), int(seed), int(step0), int(n_steps), x.ctypes.data, v.ctypes.data,
                                C.byref(st))

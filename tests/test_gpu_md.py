@@ -74,6 +74,44 @@ def test_short_trajectory_matches_restatement(kind, dt, friction):
     assert abs(st.temperature - sr.temperature) <= 1e-4 * sr.temperature + 1e-6
 
 
+@pytest.mark.parametrize("regime", ["boosted", "above_threshold"])
+def test_amd_trajectory_matches_restatement(regime):
+    """SIM_INTEGRATOR_TYPE = amd (model.py:794-800): the boost factor is recomputed from the potential energy of the
+    current positions at every step, on the device.  "boosted": E above U for the whole run; "above_threshold": E
+    below U, where aMD must reproduce the Verlet trajectory of the same engine bit for bit."""
+    from oracle.oracle import Oracle, md_velocities
+    s = _relaxed()
+    n_steps, dt = 60, 0.01
+    v0 = md_velocities(s.n_beads, 310.0, BEAD_MASS_AMU, 3).astype(np.float32)
+    with engine_for(s) as eng:
+        et, _ = eng.compute()
+        u0 = float(np.sum(et))
+        alpha, e = (2000.0, u0 + 3000.0) if regime == "boosted" else (100.0, u0 - 1e9)
+        eng.md_configure("amd", dt_ps=dt, amd_alpha=alpha, amd_e=e)
+        eng.set_velocities(v0)
+        x0 = eng.get_positions().astype(np.float64)
+        st = eng.md_step(n_steps)
+        x, v = eng.get_positions().astype(np.float64), eng.get_velocities().astype(np.float64)
+        if regime == "above_threshold":
+            eng.set_positions(x0)
+            eng.md_configure("verlet", dt_ps=dt)
+            eng.set_velocities(v0)
+            eng.md_step(n_steps)
+            assert np.array_equal(eng.get_positions().astype(np.float64), x)
+            assert np.array_equal(eng.get_velocities().astype(np.float64), v)
+    xr, vr, sr = Oracle(s).md_step(x0, v0.astype(np.float64), n_steps, kind="amd", dt=dt, mass=BEAD_MASS_AMU,
+                                   amd_alpha=alpha, amd_e=e)
+    if regime == "boosted":   # the two trajectories must differ from plain Verlet, i.e. the boost was applied
+        xv, _, _ = Oracle(s).md_step(x0, v0.astype(np.float64), n_steps, kind="verlet", dt=dt, mass=BEAD_MASS_AMU)
+        assert np.abs(xv - xr).max() > 100 * 2e-6
+    travelled = np.abs(xr - x0).max()
+    assert np.abs(x - xr).max() <= 2e-6 + 1e-3 * travelled
+    assert np.abs(v - vr).max() <= 1e-3 * max(SIGMA_V, np.abs(vr).max())
+    scale_e = np.abs(np.array(sr.eterms[:])).sum()
+    assert abs(st.potential - sr.potential) <= 2e-5 * scale_e + 1e-3
+    assert abs(st.kinetic - sr.kinetic) <= 1e-4 * sr.kinetic + 1e-6   # unshifted m v^2 / 2 on both sides
+
+
 def test_md_with_exact_all_pairs_forces():
     """NB_CUTOFF <= 0 (the reference's NoCutoff semantics): MD on the all-pairs kernel, against the restatement."""
     from oracle.oracle import Oracle, md_velocities
@@ -141,6 +179,8 @@ def test_md_errors():
             eng.md_step(1)  # not configured
         with pytest.raises(MMXError):
             eng.md_configure("variable_langevin")
+        with pytest.raises(MMXError):
+            eng.md_configure("amd", amd_alpha=0.0)
         with pytest.raises(MMXError):
             eng.md_configure("brownian", friction_per_ps=0.0)
         with pytest.raises(MMXError):

@@ -103,8 +103,11 @@ def test_md_config_keys_and_presets():
                      "SIM_INTEGRATOR_TYPE": "brownian"})
     assert c.SIM_RUN_MD and abs(c.SIM_INTEGRATOR_STEP - 0.002) < 1e-15 and c.SIM_TEMPERATURE == 300.0
     assert (c.SIM_N_STEPS, c.TRJ_FRAMES, c.SIM_FRICTION_COEFF, c.SIM_INTEGRATOR_TYPE) == (500, 50, 0.1, "brownian")
+    e = load_config({"SIM_INTEGRATOR_TYPE": "amd", "SIM_AMD_ALPHA": "250", "SIM_AMD_E": "5e3"})
+    assert (e.SIM_INTEGRATOR_TYPE, e.SIM_AMD_ALPHA, e.SIM_AMD_E) == ("amd", 250.0, 5000.0)
     d = load_config({"MODELLING_LEVEL": "gw"})
     assert not d.SIM_RUN_MD
+    assert (d.SIM_AMD_ALPHA, d.SIM_AMD_E) == (100.0, 1000.0)   # config.py:255-256
     assert (d.SIM_N_STEPS, d.SIM_SAMPLING_STEP, d.SIM_INTEGRATOR_TYPE, d.SIM_INTEGRATOR_STEP, d.SIM_FRICTION_COEFF,
             d.SIM_TEMPERATURE, d.TRJ_FRAMES) == (10000, 100, "langevin", 0.001, 0.5, 310.0, 2000)
 

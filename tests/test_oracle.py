@@ -223,6 +223,35 @@ def test_md_integrators_basic_properties():
     assert sb1.potential < sb0.potential
 
 
+def test_amd_integrator_known_answers():
+    """mm.amd.AMDIntegrator(dt, alpha, E), model.py:794-800: f' = f (alpha/(alpha+E-U))^2 while U <= E, f otherwise.
+    E far below U: exactly the Verlet trajectory.  E above U: the first step is the Verlet step with the force scaled by
+    the hand-computed boost; the kinetic energy carries no half-step shift (CustomIntegrator default m v^2 / 2)."""
+    from oracle.oracle import Oracle, md_velocities
+    s = synthetic_system("region_5k", n_beads=300, jitter=0.01, seed=1)
+    orc = Oracle(s, as_float32_inputs=False)   # eval() and md_step() must see the very same positions
+    x0, _ = orc.minimize(tolerance=0.0, max_iters=200)
+    v0 = md_velocities(s.n_beads, 310.0, 16427.889, 2)
+    kw = dict(dt=0.005, mass=16427.889)
+    et, F = orc.eval(x0)
+    u0 = float(np.sum(et))
+    xv, vv, _ = orc.md_step(x0, v0, 40, kind="verlet", **kw)
+    xa, va, _ = orc.md_step(x0, v0, 40, kind="amd", amd_alpha=100.0, amd_e=u0 - 1e9, **kw)
+    assert np.array_equal(xa, xv) and np.array_equal(va, vv)
+    alpha, e = 250.0, u0 + 500.0
+    boost = (alpha / (alpha + e - u0)) ** 2
+    assert boost == pytest.approx((250.0 / 750.0) ** 2)
+    x1, v1, st1 = orc.md_step(x0, v0, 1, kind="amd", amd_alpha=alpha, amd_e=e, **kw)
+    v_ref = v0 + kw["dt"] * boost * F / kw["mass"]
+    assert np.allclose(v1, v_ref, rtol=0, atol=1e-15) and np.allclose(x1, x0 + kw["dt"] * v_ref, rtol=0, atol=1e-15)
+    assert st1.kinetic == pytest.approx(0.5 * kw["mass"] * np.sum(v1 * v1), rel=1e-12)
+    # the boost flattens the landscape: with E above U the boosted run gains less kinetic energy from the same
+    # forces than the plain one over the first steps
+    _, _, sb = orc.md_step(x0, 0 * v0, 5, kind="amd", amd_alpha=alpha, amd_e=e, **kw)
+    _, _, sp = orc.md_step(x0, 0 * v0, 5, kind="amd", amd_alpha=alpha, amd_e=u0 - 1e9, **kw)
+    assert sb.kinetic < sp.kinetic
+
+
 # ---- alternative functional forms (SURVEY 8 f4; config.py:269-312) ------------------------------------
 def test_kat_alternative_pair_forms(oracle_lib):
     """Hand-derivable values of the non-default pair forms (model.py:205-209, 262-288, 340-377)."""
