@@ -429,6 +429,11 @@ def test_ensemble_loop_like_the_reference(tmp_path):
     # rank 1 of 2 takes replica 1 only
     res1 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens2")), rank=1, world=2, archive=False, device=0)
     assert [i for i, _, _ in res1] == [1]
+    # three replicas in flight on the one GPU (own handle, stream and host thread each): same results, same order
+    res3 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens3")), concurrent=3)
+    assert [i for i, _, _ in res3] == [0, 1, 2]
+    for (_, _, a), (_, _, b) in zip(res, res3):
+        assert (a.iterations, a.evaluations, a.e_initial, a.e_final) == (b.iterations, b.evaluations, b.e_initial, b.e_final)
 
 
 def test_extreme_compartment_radius_falls_back_to_unscaled_kernel():
