@@ -6,7 +6,8 @@ run.py:423-445).  The replicas are independent, so with several GPUs replica i g
 process per GPU, no data-path collective: what ``bench.py --gpus N`` times).  Small systems leave most of a GPU
 idle (one replica of 5 000 beads is bound by launch latency), so a rank may also keep ``concurrent`` replicas in
 flight on its GPU, each with its own engine handle, stream and host thread: measured 2x aggregate iterations/s with
-two, 3x with six replicas of 5 000 beads on one MI355X (``scripts/concurrent_replicas.py``).
+two and 2.9x with three replicas of 5 000 beads on one MI355X, +39 % with three of 200 000 beads; beyond three the
+streams share hardware queues and the per-replica rate halves (``scripts/concurrent_replicas.py``).
 """
 from __future__ import annotations
 
