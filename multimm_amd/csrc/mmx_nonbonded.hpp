@@ -583,20 +583,24 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
             tev += ee[s];
             teg += eg[s];
         }
-        tev *= escale; // LEAN, p = 6: the loop summed (sigma-free) u^6
         const int bead = ow >> 3; // -1 for padding slots and for lanes >= 8
         const bool own = bead >= 0;
-        if (own) {
-            // the self pair (r = 0, zero force) was swept with everything else: remove its energy
-            if (EV && !FORMS && !NOENERGY) {
-                const float u = __builtin_amdgcn_rcpf(fmaf(1e-20f, __builtin_amdgcn_rsqf(1e-20f), P.ev_rs));
-                if (PMODE == 6) {
-                    const float u2 = u * u;
-                    tev -= (u2 * u2) * (u2 * ev_c);
-                } else {
-                    tev -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
-                }
+        // The self pair (r = 0, zero force) was swept with everything else: remove its energy (6400 kJ/mol per bead
+        // with the default parameters, against a few kJ/mol of genuine pair energy).  The value subtracted is formed
+        // by the very operations the loop used -- same scaled constants, same order, before the common factor is
+        // applied -- so that nothing systematic is left of it (a value that is merely equal in exact arithmetic
+        // leaves ~1e-7 * 6400 kJ/mol per bead behind, all of one sign).
+        if (own && EV && !FORMS && !NOENERGY) {
+            const float us = __builtin_amdgcn_rcpf(fmaf(tiny, __builtin_amdgcn_rsqf(tiny), LEAN ? rs_s : P.ev_rs));
+            if (PMODE == 6) {
+                const float u2 = us * us;
+                tev -= LEAN ? (u2 * u2) * u2 : (u2 * u2) * (u2 * ev_c);
+            } else {
+                tev -= P.ev_eps * ev_pow<PMODE>((LEAN ? sigma_s : P.ev_sigma) * us, P.ev_power);
             }
+        }
+        tev *= escale; // LEAN, p = 6: the loop summed (sigma-free) u^6
+        if (own) {
             if (GAUSS && !FORMS && !NOENERGY) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
             float *gb = g + 3 * (bead - P.own_lo); // the bonded terms wrote the gradient first
             const float g0 = gb[0], g1 = gb[1], g2 = gb[2];
@@ -604,8 +608,10 @@ __global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFPa
             gb[1] = g1 - ofy;
             gb[2] = g2 - ofz;
         }
-        const float sev = wave_sum(tev), seg = wave_sum(teg);
-        acc_ev += 0.5 * (double)sev;
+        // fp64 across the lanes: up to eight of them still carry a self-pair energy that the owners' lanes cancel
+        const double sev = NOENERGY ? 0.0 : wave_sum((double)tev);
+        const float seg = wave_sum(teg);
+        acc_ev += 0.5 * sev;
         acc_g += 0.5 * (double)seg;
     }
     if (lane == 0) {

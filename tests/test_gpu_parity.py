@@ -460,3 +460,41 @@ def test_zero_strength_terms_are_left_out():
     with engine_for(s1) as eng:
         with pytest.raises(MMXError):
             eng.set_excluded_volume(100.0, 0.1, 0.05, 0.0, 0.6)   # power must be positive
+
+
+@pytest.mark.parametrize("which", ["bonded_only", "pairs_only", "separate_bonded", "serial_bonded", "with_chb"])
+def test_minimize_under_every_launch_shape(which):
+    """The bonded pass is the first writer of the gradient and normally rides in the cell scan's launch; the pair
+    kernels add to it.  Every other shape of an evaluation must minimize to the same quality: no pair term at all
+    (the bonded pass writes the whole gradient), no bonded term (it writes zeros), the three bonded kernels launched
+    separately after a memset, the fused pass as its own launch, chromosomal blocks in between.  Checked: the energy
+    the minimizer reports is the oracle's energy at the returned positions, and the same number of iterations from the
+    same start lands within 1e-3 of the decrease of the default shape."""
+    from oracle.oracle import Oracle
+    ff = {}
+    opts = {}
+    if which == "bonded_only":
+        ff = dict(EV_USE_EXCLUDED_VOLUME=False, COB_USE_COMPARTMENT_BLOCKS=False)
+    elif which == "pairs_only":
+        ff = dict(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+                  SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
+    elif which == "separate_bonded":
+        opts = {"fused_bonded": 0}
+    elif which == "serial_bonded":
+        opts = {"overlap_bonded": 0}
+    elif which == "with_chb":
+        ff = dict(CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.05)
+    s = synthetic_system("gw_200k", n_beads=3000, jitter=0.02, seed=6, **ff)
+    with engine_for(s) as eng:
+        st0 = eng.minimize(tolerance=0.0, max_iters=80)
+    with engine_for(s) as eng:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        st = eng.minimize(tolerance=0.0, max_iters=80)
+        x = eng.get_positions()
+        et, _ = eng.compute()
+    assert st.iterations == 80 and st.e_final < st.e_initial
+    scale = np.abs(et).sum()
+    assert abs(Oracle(s).energy(x) - st.e_final) <= E_RTOL * scale + E_ATOL
+    assert abs(et.sum() - st.e_final) <= E_RTOL * scale + E_ATOL
+    assert abs(st.e_final - st0.e_final) <= 1e-3 * abs(st0.e_initial - st0.e_final)
