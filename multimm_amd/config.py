@@ -69,6 +69,14 @@ class SimulationConfig:
     LOC_START: Optional[int] = None
     LOC_END: Optional[int] = None
     SHUFFLING_SEED: int = 0
+    SHUFFLE_CHROMS: bool = False            # config.py:185 (parsers: chromosome order shuffled with SHUFFLING_SEED)
+    DOWNSAMPLING_PROB: float = 1.0          # config.py:157: probability of keeping a loop
+    COMPARTMENT_FLIP_PROB: float = 0.0      # config.py:146-149
+    COMPARTMENT_NOISE_STD: float = 0.0      # config.py:150-153
+    GENE_TSV: Optional[str] = None          # config.py:168-171 (the reference ships a default table; none travels here)
+    GENE_NAME: Optional[str] = None         # config.py:172
+    GENE_ID: Optional[str] = None           # config.py:173
+    GENE_WINDOW: int = 100000               # config.py:174
     N_ENSEMBLE: Optional[int] = None
     SIM_RUN_MD: bool = False
     SIM_N_STEPS: int = 10000           # config.py:253
@@ -96,6 +104,7 @@ class SimulationConfig:
             ff.SC_USE_SPHERICAL_CONTAINER = ff.CHB_USE_CHROMOSOMAL_BLOCKS = False
             ff.SCB_USE_SUBCOMPARTMENT_BLOCKS = ff.COB_USE_COMPARTMENT_BLOCKS = False
             ff.IBL_USE_B_LAMINA_INTERACTION = ff.CF_USE_CENTRAL_FORCE = False
+            self.SHUFFLE_CHROMS = False  # run.py:152
             self.SIM_RUN_MD = True
         elif level in ("region", "loc", "chromosome", "chrom"):
             self.N_BEADS = 5000 if level in ("region", "loc") else 20000
@@ -146,12 +155,13 @@ def load_config(path_or_dict) -> SimulationConfig:
             if isinstance(cur, bool):
                 setattr(cfg, key, parse_bool(val))
             elif key in ("N_BEADS", "SHUFFLING_SEED", "MIN_MAX_ITERATIONS", "DEVICE", "SIM_N_STEPS",
-                         "SIM_SAMPLING_STEP", "TRJ_FRAMES"):
+                         "SIM_SAMPLING_STEP", "TRJ_FRAMES", "GENE_WINDOW"):
                 setattr(cfg, key, int(float(sval)) if sval is not None else getattr(cfg, key))
             elif key in ("LOC_START", "LOC_END", "N_ENSEMBLE"):
                 setattr(cfg, key, int(float(sval)) if sval is not None else None)
             elif key in ("MIN_TOLERANCE", "SIM_INTEGRATOR_STEP", "SIM_FRICTION_COEFF", "SIM_TEMPERATURE",
-                         "SIM_AMD_ALPHA", "SIM_AMD_E"):
+                         "SIM_AMD_ALPHA", "SIM_AMD_E", "DOWNSAMPLING_PROB", "COMPARTMENT_FLIP_PROB",
+                         "COMPARTMENT_NOISE_STD"):
                 setattr(cfg, key, parse_quantity(val))
             else:
                 setattr(cfg, key, sval if sval is None else str(sval))

@@ -44,6 +44,27 @@ def _chrom_layout(chrom, rng, shuffle, n_chroms):
     return chrom_idxs, ends
 
 
+def get_gene_region(gene_tsv, gene_id=None, gene_name=None, window_size=200000):
+    """-> (chrom, [start - window, end + window] clipped at 0, [start, end]) of the first row of the gene table whose
+    ``gene_id`` (preferred) or ``gene_name`` matches (utils.py:688-710; columns gene_id, gene_name, chromosome, start,
+    end, tab separated with a header line)."""
+    import csv
+    with open(gene_tsv, newline="") as fh:
+        rows = list(csv.DictReader(fh, delimiter="\t"))
+    if gene_id is not None:
+        key, val = "gene_id", gene_id
+    elif gene_name is not None:
+        key, val = "gene_name", gene_name
+    else:
+        raise ValueError("Either 'gene_id' or 'gene_name' must be provided.")
+    hit = next((r for r in rows if r.get(key) == val), None)
+    if hit is None:
+        what = "Gene ID" if key == "gene_id" else "Gene name"
+        raise ValueError(f"{what} '{val}' not found in the provided TSV file.")
+    start, end = int(float(hit["start"])), int(float(hit["end"]))
+    return hit["chromosome"], [max(0, int(start - window_size)), int(end + window_size)], [start, end]
+
+
 def _save_meta(path, **arrays):
     """metadata/<name>.npy under the run directory, what plots.py:456-458 and viz_chroms read back."""
     if path is None:

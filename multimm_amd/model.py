@@ -41,14 +41,30 @@ class MultiMM:
         if ms is None and str(self.args.LOOPS_PATH or "").lower().endswith(".bedpe"):
             # the reference's own inputs (model.py:105-132): compartments first, then loops, whose chr_ends
             # overwrite the ones of import_bed
-            from .ingest import import_bed, import_mns_from_bedpe
-            chrom = self.args.CHROM or None
-            coords = (self.args.LOC_START, self.args.LOC_END) if chrom else None
-            if self.args.COMPARTMENT_PATH and str(self.args.COMPARTMENT_PATH).lower().endswith(".bed"):
-                Cs, chr_ends, _ = import_bed(self.args.COMPARTMENT_PATH, n, coords=coords, chrom=chrom,
-                                             seed=int(self.args.SHUFFLING_SEED), path=self.args.OUT_PATH)
-            ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(self.args.LOOPS_PATH, n, coords=coords, chrom=chrom,
-                                                             seed=int(self.args.SHUFFLING_SEED), path=self.args.OUT_PATH)
+            from .ingest import CHROM_SIZES, get_gene_region, import_bed, import_mns_from_bedpe
+            a = self.args
+            chrom = a.CHROM or None
+            coords = [a.LOC_START, a.LOC_END] if (a.LOC_START is not None and a.LOC_END is not None) else None
+            if chrom is not None and coords is None and chrom in CHROM_SIZES:
+                coords = [0, CHROM_SIZES[chrom]]                       # whole chromosome, model.py:61-63
+            if a.GENE_TSV and str(a.MODELLING_LEVEL).lower() == "gene":  # model.py:65-98
+                gid = None if str(a.GENE_ID or "").lower() in ("", "none") else a.GENE_ID
+                gname = None if str(a.GENE_NAME or "").lower() in ("", "none") else a.GENE_NAME
+                if gid is None and gname is None:
+                    raise ValueError("You did not provide gene name or ID.")
+                chrom, coords, gene = get_gene_region(a.GENE_TSV, gene_id=gid, gene_name=None if gid else gname,
+                                                      window_size=int(a.GENE_WINDOW))
+                span = coords[1] - coords[0]
+                self.gene_start, self.gene_end = ((gene[0] - coords[0]) * n) // span, ((gene[1] - coords[0]) * n) // span
+                logger.info("We model the region %d-%d of chrom %s of the gene %s.", coords[0], coords[1], chrom,
+                            gid or gname)
+            common = dict(coords=coords, chrom=chrom, shuffle=bool(a.SHUFFLE_CHROMS), seed=int(a.SHUFFLING_SEED),
+                          path=a.OUT_PATH)
+            if a.COMPARTMENT_PATH and str(a.COMPARTMENT_PATH).lower().endswith(".bed"):
+                Cs, chr_ends, _ = import_bed(a.COMPARTMENT_PATH, n, flip_prob=float(a.COMPARTMENT_FLIP_PROB),
+                                             noise_strength=float(a.COMPARTMENT_NOISE_STD), **common)
+            ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(a.LOOPS_PATH, n, down_prob=float(a.DOWNSAMPLING_PROB),
+                                                             **common)
         if ms is None:
             # no CHROM = genome-wide layout (22 chromosome intervals), as the parsers produce for chrom=None
             preset = "gw_200k" if (str(self.args.MODELLING_LEVEL).lower() in ("gw", "genome") or not self.args.CHROM) \

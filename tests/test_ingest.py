@@ -117,3 +117,56 @@ def test_metadata_npy_files_like_the_reference(tmp_path):
     assert np.array_equal(np.load(meta / "chrom_lengths.npy"), ends) and np.array_equal(np.load(meta / "chrom_idxs.npy"), idxs)
     assert np.array_equal(np.load(meta / "ms.npy"), ms) and np.array_equal(np.load(meta / "ns.npy"), ns)
     assert np.allclose(np.load(meta / "ds.npy"), ds)
+
+
+def test_gene_region_lookup_and_gene_level_run(tmp_path):
+    """utils.py:688-710 + model.py:65-98: MODELLING_LEVEL = gene takes chromosome and region from the gene table
+    (gene id preferred over gene name), widened by GENE_WINDOW on both sides and clipped at 0; the gene's own bead
+    range is kept as gene_start / gene_end."""
+    from multimm_amd.config import load_config
+    from multimm_amd.ingest import get_gene_region
+    from multimm_amd.model import MultiMM
+    tsv = tmp_path / "genes.tsv"
+    tsv.write_text("gene_id\tgene_name\tchromosome\tstart\tend\n"
+                   "ENSG01\tAAA\tchr2\t50000\t80000\n"
+                   "ENSG02\tBBB\tchr1\t20000\t30000\n")
+    assert get_gene_region(str(tsv), gene_id="ENSG02", window_size=5000) == ("chr1", [15000, 35000], [20000, 30000])
+    assert get_gene_region(str(tsv), gene_name="AAA", window_size=100000) == ("chr2", [0, 180000], [50000, 80000])
+    with pytest.raises(ValueError, match="Gene ID 'nope' not found"):
+        get_gene_region(str(tsv), gene_id="nope")
+    with pytest.raises(ValueError, match="Either"):
+        get_gene_region(str(tsv))
+    f = _write(tmp_path / "l.bedpe", [("chr1", 15000 + 100 * i, 15010 + 100 * i, "chr1", 15900 + 100 * i, 15910 + 100 * i,
+                                         float(i + 1)) for i in range(1, 100)])
+    cfg = load_config(dict(PLATFORM="MI355X", MODELLING_LEVEL="gene", GENE_TSV=str(tsv), GENE_ID="ENSG02",
+                           GENE_WINDOW="5000", LOOPS_PATH=f, OUT_PATH=str(tmp_path / "o"), SHUFFLE_CHROMS="true"))
+    assert cfg.N_BEADS == 1000 and cfg.SHUFFLE_CHROMS is False and cfg.GENE_WINDOW == 5000   # gene preset, run.py:137-154
+    m = MultiMM(cfg)
+    assert (m.gene_start, m.gene_end) == ((20000 - 15000) * 1000 // 20000, (30000 - 15000) * 1000 // 20000)
+    ms, ns, _, ends, _ = import_mns_from_bedpe(f, 1000, coords=[15000, 35000], chrom="chr1")
+    assert np.array_equal(m.ms, ms) and np.array_equal(m.ns, ns) and list(m.chr_ends) == list(ends)
+    with pytest.raises(ValueError, match="gene name or ID"):
+        MultiMM(load_config(dict(PLATFORM="MI355X", MODELLING_LEVEL="gene", GENE_TSV=str(tsv), LOOPS_PATH=f,
+                                 OUT_PATH=str(tmp_path / "o2"))))
+
+
+def test_ingest_options_come_from_the_config(tmp_path):
+    """model.py:105-132: SHUFFLE_CHROMS, DOWNSAMPLING_PROB, COMPARTMENT_FLIP_PROB and COMPARTMENT_NOISE_STD reach the
+    parsers with SHUFFLING_SEED; CHROM without LOC_START/LOC_END means the whole chromosome (model.py:61-63)."""
+    from multimm_amd.config import load_config
+    from multimm_amd.ingest import CHROM_SIZES
+    from multimm_amd.model import MultiMM
+    f = _write(tmp_path / "l.bedpe", [("chr1", 500000 * i, 500000 * i + 10, "chr1", 500000 * i + 5000000,
+                                         500000 * i + 5000010, float(i + 1)) for i in range(1, 400)])
+    b = _write(tmp_path / "c.bed", [("chr1", 0, 100000000, "A1"), ("chr1", 100000000, CHROM_SIZES["chr1"], "B1")])
+    base = dict(PLATFORM="MI355X", N_BEADS=2000, CHROM="chr1", LOOPS_PATH=f, COMPARTMENT_PATH=b, SHUFFLING_SEED=3)
+    m0 = MultiMM(load_config(dict(base, OUT_PATH=str(tmp_path / "a"))))
+    ms, ns, _, _, _ = import_mns_from_bedpe(f, 2000, coords=[0, CHROM_SIZES["chr1"]], chrom="chr1", seed=3)
+    assert len(ms) > 100 and np.array_equal(m0.ms, ms) and np.array_equal(m0.ns, ns)   # whole chromosome
+    m1 = MultiMM(load_config(dict(base, OUT_PATH=str(tmp_path / "b"), DOWNSAMPLING_PROB="0.5",
+                                  COMPARTMENT_FLIP_PROB="0.25", COMPARTMENT_NOISE_STD="0.1")))
+    ms1, _, _, _, _ = import_mns_from_bedpe(f, 2000, coords=[0, CHROM_SIZES["chr1"]], chrom="chr1", seed=3, down_prob=0.5)
+    cs1, _, _ = import_bed(b, 2000, coords=[0, CHROM_SIZES["chr1"]], chrom="chr1", seed=3, flip_prob=0.25,
+                           noise_strength=0.1)
+    assert 0 < len(m1.ms) < len(m0.ms) and np.array_equal(m1.ms, ms1)
+    assert np.array_equal(m1.Cs, cs1) and not np.array_equal(m1.Cs, m0.Cs)
