@@ -78,6 +78,7 @@ class SimulationConfig:
     GENE_ID: Optional[str] = None           # config.py:173
     GENE_WINDOW: int = 100000               # config.py:174
     N_ENSEMBLE: Optional[int] = None
+    GENERATE_ENSEMBLE: bool = False    # config.py:142-145: run N_ENSEMBLE replicas instead of one (run.py:471)
     SIM_RUN_MD: bool = False
     SIM_N_STEPS: int = 10000           # config.py:253
     SIM_SAMPLING_STEP: int = 100       # config.py:257

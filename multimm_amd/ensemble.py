@@ -64,3 +64,19 @@ def run_ensemble(args: SimulationConfig | str | dict, n_ensemble: Optional[int] 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=int(concurrent)) as pool:
         return list(pool.map(one, mine))
+
+
+def run(args: SimulationConfig | str | dict, rank: int = 0, world: int = 1, concurrent: int = 1, **model_inputs):
+    """The dispatch of ``run.py:469-491``: ``GENERATE_ENSEMBLE`` -> the replica loop (``run_ensemble``), else one
+    ``MultiMM(args).run()``; returns what the branch taken returns."""
+    cfg = args if isinstance(args, SimulationConfig) else load_config(args)
+    if cfg.GENERATE_ENSEMBLE:
+        if not cfg.N_ENSEMBLE:
+            raise ValueError("GENERATE_ENSEMBLE needs N_ENSEMBLE")
+        return run_ensemble(cfg, rank=rank, world=world, concurrent=concurrent, **model_inputs)
+    md = MultiMM(cfg, **model_inputs)
+    try:
+        return md.run()
+    finally:
+        if md.engine is not None:
+            md.engine.close()

@@ -437,6 +437,12 @@ def test_ensemble_loop_like_the_reference(tmp_path):
     # rank 1 of 2 takes replica 1 only
     res1 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens2")), rank=1, world=2, archive=False, device=0)
     assert [i for i, _, _ in res1] == [1]
+    # run.py:469-491: GENERATE_ENSEMBLE switches between the loop and a single run
+    from multimm_amd.ensemble import run
+    res4 = run(dict(cfg, OUT_PATH=str(tmp_path / "ens4"), GENERATE_ENSEMBLE=True, N_ENSEMBLE=2))
+    assert [i for i, _, _ in res4] == [0, 1] and res4[1][2].e_final == res[1][2].e_final
+    single = run(dict(cfg, OUT_PATH=str(tmp_path / "one")))
+    assert single.e_final == res[0][2].e_final and os.path.exists(tmp_path / "one" / "model" / "MultiMM_minimized.cif")
     # three replicas in flight on the one GPU (own handle, stream and host thread each): same results, same order
     res3 = run_ensemble(dict(cfg, OUT_PATH=str(tmp_path / "ens3")), concurrent=3)
     assert [i for i, _, _ in res3] == [0, 1, 2]

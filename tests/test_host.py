@@ -103,6 +103,8 @@ def test_md_config_keys_and_presets():
                      "SIM_INTEGRATOR_TYPE": "brownian"})
     assert c.SIM_RUN_MD and abs(c.SIM_INTEGRATOR_STEP - 0.002) < 1e-15 and c.SIM_TEMPERATURE == 300.0
     assert (c.SIM_N_STEPS, c.TRJ_FRAMES, c.SIM_FRICTION_COEFF, c.SIM_INTEGRATOR_TYPE) == (500, 50, 0.1, "brownian")
+    g = load_config({"GENERATE_ENSEMBLE": "True", "N_ENSEMBLE": "4"})
+    assert g.GENERATE_ENSEMBLE is True and g.N_ENSEMBLE == 4 and not load_config({}).GENERATE_ENSEMBLE
     e = load_config({"SIM_INTEGRATOR_TYPE": "amd", "SIM_AMD_ALPHA": "250", "SIM_AMD_E": "5e3"})
     assert (e.SIM_INTEGRATOR_TYPE, e.SIM_AMD_ALPHA, e.SIM_AMD_E) == ("amd", 250.0, 5000.0)
     d = load_config({"MODELLING_LEVEL": "gw"})
