@@ -101,14 +101,8 @@ class MultiMM:
         n = int(self.args.N_BEADS)
         init_cif = os.path.join(self.args.OUT_PATH, "metadata", "MultiMM_init.cif")
         if self.args.BUILD_INITIAL_STRUCTURE or not self.args.INITIAL_STRUCTURE_PATH:
-            kind = str(self.args.INITIAL_STRUCTURE_TYPE).lower()
-            if kind == "hilbert":
-                pts_angstrom = hilbert_points(n).astype(np.float64)
-            elif kind == "circle":
-                th = 2.0 * np.pi * np.arange(n) / n
-                pts_angstrom = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), 50.0 * (np.arange(n) + 1) / n], axis=1)
-            else:
-                raise NotImplementedError(f"INITIAL_STRUCTURE_TYPE={kind!r}: only hilbert and circle are on this path")
+            from .initial_structure import compute_init_struct
+            pts_angstrom = compute_init_struct(n, self.args.INITIAL_STRUCTURE_TYPE, seed=int(self.args.SHUFFLING_SEED))
             cif.write_structure(init_cif, pts_angstrom * 0.1, self.chr_ends)
             positions = cif.read_positions(init_cif)      # %.3f Angstrom round trip, as the reference does
         else:

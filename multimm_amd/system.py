@@ -273,8 +273,8 @@ def synthetic_system(name: str = "gw_200k", seed: int = 0, n_beads: Optional[int
     """Synthetic Hilbert-curve-initialised bead system for one of BASELINE.json's configurations.
 
     ``n_beads`` rescales a preset (loops scale with N); ``jitter`` adds N(0, jitter nm) noise with
-    seed 1234 to break lattice degeneracy; ``start='circle'`` uses ``polymer_circle(N, 50, 5)``
-    (initial_structure_tools.py:169-182, 268-269) as config_specific_region.ini does.
+    seed 1234 to break lattice degeneracy; ``start`` is any INITIAL_STRUCTURE_TYPE (``multimm_amd/initial_structure.py``;
+    'circle' = ``polymer_circle(N, 50, 5)`` as config_specific_region.ini uses).
     """
     if name not in _PRESETS:
         raise ValueError(f"unknown preset {name!r}; choose from {sorted(_PRESETS)}")
@@ -282,13 +282,8 @@ def synthetic_system(name: str = "gw_200k", seed: int = 0, n_beads: Optional[int
     n = int(n_beads) if n_beads else n0
     n_loops = max(1, int(round(l0 * n / n0)))
     rng = np.random.default_rng(seed)
-    if start == "hilbert":
-        pos = hilbert_points(n).astype(np.float64) * 0.1   # Angstrom lattice read back as nm
-    elif start == "circle":
-        th = 2.0 * np.pi * np.arange(n) / n
-        pos = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), 50.0 * (np.arange(n) + 1) / n], axis=1) * 0.1
-    else:
-        raise ValueError("start must be 'hilbert' or 'circle'")
+    from .initial_structure import compute_init_struct
+    pos = compute_init_struct(n, start, seed=seed) * 0.1   # the mmCIF's Angstrom read back as nm
     if jitter > 0.0:
         pos = pos + np.random.default_rng(1234).normal(0.0, jitter, size=pos.shape)
     chr_ends = gw_chr_ends(n) if gw else np.array([0, n], dtype=np.int32)

@@ -289,6 +289,23 @@ def test_multimm_run_end_to_end(tmp_path):
     assert 0.05 < np.median(bonds) < 0.2
 
 
+@pytest.mark.parametrize("kind", ["rw", "confined_rw", "knot", "helix", "spiral", "sphere", "circle", "self_avoiding_rw"])
+def test_every_initial_structure_type_minimizes(tmp_path, kind):
+    """INITIAL_STRUCTURE_TYPE (config.py:138-141, model.py:745): every start the reference can build goes through the
+    mmCIF round trip and minimizes on the device; the energy reported is the oracle's at the returned structure."""
+    from oracle.oracle import Oracle
+    from multimm_amd.config import load_config
+    from multimm_amd.model import MultiMM
+    n = 300 if kind == "self_avoiding_rw" else 1200
+    m = MultiMM(load_config(dict(PLATFORM="MI355X", N_BEADS=n, CHROM="chr1", OUT_PATH=str(tmp_path / kind),
+                                 INITIAL_STRUCTURE_TYPE=kind, MIN_MAX_ITERATIONS=150, SHUFFLING_SEED=5)))
+    st = m.run()
+    m.engine.close()
+    assert st.iterations > 0 and st.e_final < st.e_initial and np.all(np.isfinite(m.state_positions))
+    e_ref = Oracle(m.system).energy(m.state_positions)
+    assert abs(e_ref - st.e_final) <= 2e-5 * abs(e_ref) + 1e-2
+
+
 def test_config2_converges_to_openmm_tolerance():
     """BASELINE config 2 (chr1, 50k beads, EV + backbone + loops) minimized until OpenMM's default stop rule holds;
     the oracle confirms energy and stop rule at the returned point."""

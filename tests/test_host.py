@@ -136,3 +136,35 @@ def test_dcd_layout_and_round_trip(tmp_path):
     r = read_dcd(p)
     assert (r["n_frames"], r["n_atoms"], r["first_step"], r["interval"], r["last_step"]) == (3, 7, 5, 5, 20)
     assert abs(r["dt_ps"] - 0.001) < 1e-9 and np.abs(r["frames_nm"] - x).max() < 1e-6
+
+
+def test_initial_structure_types():
+    """INITIAL_STRUCTURE_TYPE (config.py:138-141): the nine generators of initial_structure_tools.py:169-289, 614-640.
+    Hand-checkable values for the curves, defining properties for the random ones."""
+    from multimm_amd.initial_structure import MODES, compute_init_struct
+    assert set(MODES) == {"rw", "confined_rw", "knot", "self_avoiding_rw", "circle", "helix", "spiral", "sphere", "hilbert"}
+    n = 101
+    h = compute_init_struct(n, "helix")
+    assert np.allclose(h[0], [1, 0, 0]) and np.allclose(h[-1], [1, 0, 2 * n]) and np.allclose(h[25], [-1, 0, 50.5], atol=1e-12)
+    sp = compute_init_struct(n, "spiral")
+    assert np.allclose(sp[-1], [1 + 0.05 * 100, 0, n]) and np.allclose(np.hypot(sp[:, 0], sp[:, 1]), 1 + 0.05 * np.arange(n))
+    k = compute_init_struct(n, "knot")
+    assert np.allclose(k[0], [0, -5, 0]) and np.allclose(k[-1], [0, -5, 0], atol=1e-12)   # closed curve
+    assert np.allclose(k[25], [5 * (1 + 0), 5 * (0 + 2), 5.0], atol=1e-12)                # t = pi/2
+    c = compute_init_struct(4, "circle")
+    assert np.allclose(c, [[5, 0, 12.5], [0, 5, 25], [-5, 0, 37.5], [0, -5, 50]], atol=1e-12)
+    assert np.abs(np.diff(compute_init_struct(64, "hilbert"), axis=0)).sum(axis=1).tolist() == [1] * 63   # lattice walk
+    rw = compute_init_struct(500, "rw", seed=3)
+    assert np.allclose(np.linalg.norm(np.diff(rw, axis=0), axis=1), 1.0) and np.all(rw[0] == 0)
+    assert np.array_equal(rw, compute_init_struct(500, "rw", seed=3)) and not np.array_equal(rw, compute_init_struct(500, "rw", seed=4))
+    cw = compute_init_struct(2000, "confined_rw", seed=1)
+    d = np.abs(np.diff(cw, axis=0))
+    assert np.abs(cw).max() == 5.0 and set(np.unique(d)) <= {0.0, 1.0} and (d == 0).any()   # sticks to the walls
+    saw = compute_init_struct(120, "self_avoiding_rw", seed=2)
+    dist = np.linalg.norm(saw[:, None] - saw[None], axis=2) + 10 * np.eye(120)
+    assert np.allclose(np.linalg.norm(np.diff(saw, axis=0), axis=1), 1.0) and dist.min() >= 1.0 - 1e-3 - 1e-12
+    ball = compute_init_struct(20000, "sphere", seed=0)
+    r = np.linalg.norm(ball, axis=1)
+    assert r.max() <= 1.0 and abs(r.mean() - 0.75) < 0.01 and np.abs(ball.mean(axis=0)).max() < 0.02  # uniform in the ball
+    with pytest.raises(ValueError, match="Invalid option for initial structure: 'zigzag'"):
+        compute_init_struct(10, "zigzag")
