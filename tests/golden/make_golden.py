@@ -85,6 +85,13 @@ def main():
             out["md_positions"], out["md_velocities"] = xmd, vmd
             case["md"] = dict(kind="langevin", n_steps=n_md, dt=0.005, temperature=310.0, friction=0.5, mass=16427.889,
                               seed=11, velocity_seed=7, potential=mst.potential, kinetic=mst.kinetic)
+            # mm.amd.AMDIntegrator (model.py:794-800) with the boost active: E above the potential energy of the start
+            amd_alpha, amd_e = 300.0, float(np.floor(et.sum())) + 200.0
+            xa, va, ast = orc.md_step(s.positions, v0, n_md, kind="amd", dt=0.005, mass=16427.889, amd_alpha=amd_alpha,
+                                      amd_e=amd_e)
+            out["amd_positions"], out["amd_velocities"] = xa, va
+            case["amd"] = dict(n_steps=n_md, dt=0.005, mass=16427.889, alpha=amd_alpha, e=amd_e, velocity_seed=7,
+                               potential=ast.potential, kinetic=ast.kinetic)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         meta["cases"][name] = case
         print(f"{name}: n={s.n_beads} E={et.sum():.9g}")

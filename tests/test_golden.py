@@ -65,6 +65,18 @@ def test_oracle_md_reproduces_fixture():
     assert st.potential == pytest.approx(m["potential"], rel=1e-11) and st.kinetic == pytest.approx(m["kinetic"], rel=1e-11)
 
 
+def test_oracle_amd_reproduces_fixture():
+    from oracle.oracle import Oracle, md_velocities
+    s, z, c = load_case("gw_512_cutoff")
+    m = c["amd"]
+    v0 = md_velocities(s.n_beads, 310.0, m["mass"], m["velocity_seed"])
+    x, v, st = Oracle(s).md_step(s.positions, v0, m["n_steps"], kind="amd", dt=m["dt"], mass=m["mass"],
+                                 amd_alpha=m["alpha"], amd_e=m["e"])
+    assert np.abs(x - z["amd_positions"]).max() < 1e-12 and np.abs(v - z["amd_velocities"]).max() < 1e-12
+    assert st.potential == pytest.approx(m["potential"], rel=1e-10) and st.kinetic == pytest.approx(m["kinetic"], rel=1e-10)
+    assert np.abs(z["amd_positions"] - z["md_positions"]).max() > 1e-6   # a different trajectory than the Langevin one
+
+
 def test_closed_forms_and_philox_vectors():
     """Hand-derivable values and the published Random123 vectors: independent of any oracle code."""
     from oracle.oracle import Oracle, philox4x32_10
@@ -132,5 +144,23 @@ def test_gpu_md_against_fixture():
     travelled = np.abs(z["md_positions"] - s.positions).max()
     assert np.abs(x - z["md_positions"]).max() <= 2e-6 + 1e-3 * travelled
     assert np.abs(v - z["md_velocities"]).max() <= 1e-3 * np.abs(z["md_velocities"]).max()
+    assert st.kinetic == pytest.approx(m["kinetic"], rel=1e-4)
+    assert st.potential == pytest.approx(m["potential"], rel=2e-5, abs=1e-2 + 2e-5 * np.abs(z["energy_terms"]).sum())
+
+
+@pytest.mark.gpu
+def test_gpu_amd_against_fixture():
+    from multimm_amd.engine import engine_for
+    from oracle.oracle import md_velocities
+    s, z, c = load_case("gw_512_cutoff")
+    m = c["amd"]
+    with engine_for(s) as eng:
+        eng.md_configure("amd", dt_ps=m["dt"], mass_amu=m["mass"], amd_alpha=m["alpha"], amd_e=m["e"])
+        eng.set_velocities(md_velocities(s.n_beads, 310.0, m["mass"], m["velocity_seed"]).astype(np.float32))
+        st = eng.md_step(m["n_steps"])
+        x, v = eng.get_positions().astype(np.float64), eng.get_velocities().astype(np.float64)
+    travelled = np.abs(z["amd_positions"] - s.positions).max()
+    assert np.abs(x - z["amd_positions"]).max() <= 2e-6 + 1e-3 * travelled
+    assert np.abs(v - z["amd_velocities"]).max() <= 1e-3 * np.abs(z["amd_velocities"]).max()
     assert st.kinetic == pytest.approx(m["kinetic"], rel=1e-4)
     assert st.potential == pytest.approx(m["potential"], rel=2e-5, abs=1e-2 + 2e-5 * np.abs(z["energy_terms"]).sum())
