@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
                     help="N > 1: 'ensemble' = one replica per GPU (config 4, weak scaling, no collective); "
                          "'dd' = ONE system decomposed over the GPUs (config 5, strong scaling, RCCL)")
+    ap.add_argument("--replicas-per-gpu", type=int, default=3,
+                    help="extra leg at N=1 (never part of `value`): aggregate rate of this many replicas sharing the GPU; "
+                         "<= 1 disables")
     ap.add_argument("--serial-bonded", action="store_true",
                     help="bonded terms on the main stream instead of beside the cell build (A/B of the overlap)")
     ap.add_argument("--separate-bonded", action="store_true",
@@ -59,6 +62,44 @@ def parse_args():
                     help="HBM bytes per launch of the pair kernel from a separate rocprofv3 --pmc run "
                          "(profiles/): copied into roofline.traffic")
     return ap.parse_args()
+
+
+def replicas_per_gpu_leg(workload: str, n_beads, cutoff: float, device: int, k: int, iters: int) -> dict | None:
+    """NOT part of `value`: aggregate iterations/s of k independent replicas (seeds 0..k-1) kept in flight on ONE GPU,
+    one engine handle + stream + host thread each -- what `run_ensemble(..., concurrent=k)` uses for BASELINE config 4.
+    Reported beside the headline because a single minimization leaves the GPU idle in its latency-bound launches."""
+    import threading
+    import time
+    try:
+        from multimm_amd import synthetic_system
+        from multimm_amd.engine import engine_for
+        systems = [synthetic_system(workload, seed=i, n_beads=n_beads or None, NB_CUTOFF=cutoff) for i in range(k)]
+        engines = [engine_for(s, device=device) for s in systems]
+        try:
+            for e in engines:
+                e.minimize(tolerance=0.0, max_iters=10)
+            done = [0] * k
+            gate = threading.Barrier(k + 1)
+
+            def work(i):
+                gate.wait()
+                done[i] = engines[i].minimize(tolerance=0.0, max_iters=iters).iterations
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+            for t in th:
+                t.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+        finally:
+            for e in engines:
+                e.close()
+        return {"replicas": k, "iterations_each": iters, "value": sum(done) / dt, "unit": "iters/s (aggregate)",
+                "note": "independent replicas sharing one GPU, after 10 warm-up iterations each; not the headline"}
+    except Exception as exc:  # never let the extra leg break the bench line
+        return {"error": repr(exc)}
 
 
 def cpu_baseline(system, budget_s: float) -> dict | None:
@@ -226,8 +267,12 @@ def main():
             "roofline": roofline,
         }
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
-        print(json.dumps(out))
     eng.close()
+    if rank == 0:
+        if n_gpus == 1 and args.replicas_per_gpu > 1:
+            out["replicas_per_gpu"] = replicas_per_gpu_leg(args.workload, args.n_beads, args.cutoff, local_rank,
+                                                           args.replicas_per_gpu, args.steps)
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
