@@ -13,7 +13,9 @@ ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collect
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
 pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
 "cpu_baseline" = the in-repo fp64 oracle (OpenMM is not installed; kind "port") timed on the host cores
-on a bounded sample of the same workload.
+on a bounded sample of the same workload.  At N = 1 a third object, "replicas_per_gpu", reports -- outside the timed
+region and never as part of `value` -- the aggregate rate of three independent replicas sharing the GPU
+(`run_ensemble(..., concurrent=3)`): a single minimization leaves the GPU idle in its latency-bound launches.
 """
 from __future__ import annotations
 
