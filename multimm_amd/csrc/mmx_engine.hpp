@@ -1,0 +1,579 @@
+// mmx_engine.hpp -- what the C ABI calls into: derived parameters, kernel selection, and the launch sequences of one
+// evaluation (pack -> [cell scan + bonded pass] -> fill -> order -> pair kernel -> history -> decide), collectives of a
+// decomposed run, profiling events.  Host code of libmmx.so; included by mmx_api.hip only.
+#pragma once
+#include "mmx_handle.hpp"
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+            return MMX_ERR_HIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+int fail(mmx_handle h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+template <class T>
+hipError_t dalloc(T **p, size_t count) {
+    hipError_t e = hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    return e;
+}
+
+bool all_pairs(const mmx_handle_s *h) {
+    return (h->P.use_ev && h->ev_cut <= 0.f) || (h->P.use_gauss && h->g_cut <= 0.f);
+}
+bool has_nb(const mmx_handle_s *h) { return h->P.use_ev || h->P.use_gauss; }
+
+float hmin_of(const mmx_handle_s *h) {
+    float rc = 0.f;
+    if (h->P.use_ev) rc = std::max(rc, h->ev_cut);
+    if (h->P.use_gauss) rc = std::max(rc, h->g_cut);
+    return rc * 1.001f;
+}
+
+// OPT template bits of the cluster-kernel instance that nb_variant selects (see launch_nb_cells_p).
+int nb_launch_opt(const mmx_handle_s *h) {
+    const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) | ((h->nb_variant & 128) ? 0 : 8) |
+                    ((h->nb_variant & 256) ? 16 : 0) | ((h->nb_variant & 512) ? 32 : 0) |
+                    ((h->nb_variant & 1024) ? 64 : 0) | ((h->nb_variant & 2048) ? 128 : 0);
+    if (h->nb_force_plain) return 10; // clamp mask + per-bead cull, per-bead energies: not LEAN, length scale 1
+    if (opt == 142) return 142;
+    switch (opt & 127) {
+    case 14: case 30: case 46: case 22: case 78: case 62: case 6: case 12: case 10: return opt & 127;
+    default: return 0;
+    }
+}
+
+// Derived constants refreshed before every launch sequence.
+void refresh_params(mmx_handle_s *h) {
+    FFParams &P = h->P;
+    P.n = h->n;
+    P.n_all = h->n_all;
+    P.own_lo = h->own_lo;
+    P.n_own = h->n_own;
+    const float inf = std::numeric_limits<float>::infinity();
+    P.ev_rc2 = (P.use_ev && h->ev_cut > 0.f) ? h->ev_cut * h->ev_cut : inf;
+    P.g_rc2 = (P.use_gauss && h->g_cut > 0.f) ? h->g_cut * h->g_cut : inf;
+    if (all_pairs(h)) {
+        P.rc2max = inf;
+    } else {
+        float rc = 0.f;
+        if (P.use_ev) rc = std::max(rc, h->ev_cut);
+        if (P.use_gauss) rc = std::max(rc, h->g_cut);
+        P.rc2max = rc * rc;
+    }
+    P.ev_pmode = (P.ev_power == 6.0f) ? 6 : (P.ev_power == 3.0f) ? 3 : 0;
+    P.use_gauss = (h->has_cob || h->has_scb) ? 1 : 0;
+    for (int i = 0; i < 25; ++i) P.table[i] = (h->has_cob ? h->tab_cob[i] : 0.f) + (h->has_scb ? h->tab_scb[i] : 0.f);
+    P.g_inv_rc2 = 1.0f / (h->g_rc * h->g_rc);
+    P.g_c2 = (float)(-1.4426950408889634 / (2.0 * (double)h->g_rc * (double)h->g_rc));
+    // alternative functional forms
+    FormParams &Q = h->Q;
+    Q.ev_form = h->forms[MMX_SEL_EV];
+    Q.ev_gc2 = (float)(-1.4426950408889634 / (2.0 * (double)P.ev_sigma * (double)P.ev_sigma));
+    Q.ev_inv_s2 = 1.0f / (P.ev_sigma * P.ev_sigma);
+    Q.has_cob = h->has_cob ? 1 : 0;
+    Q.has_scb = h->has_scb ? 1 : 0;
+    Q.cob_form = h->forms[MMX_SEL_COB];
+    Q.scb_form = h->forms[MMX_SEL_SCB];
+    for (int i = 0; i < 25; ++i) {
+        Q.tab_cob[i] = h->has_cob ? h->tab_cob[i] : 0.f;
+        Q.tab_scb[i] = h->has_scb ? h->tab_scb[i] : 0.f;
+    }
+    for (int l = 0; l < 5; ++l) Q.cob_a[l] = Q.tab_cob[l * 5 + l];
+    Q.g_rcomp = h->g_rc;
+    Q.g_yuk = (float)(-1.4426950408889634 / (double)h->g_rc);
+    Q.lam_form = h->forms[MMX_SEL_LAMINA];
+    Q.cf_form = h->forms[MMX_SEL_CENTRAL];
+    Q.loop_form = h->forms[MMX_SEL_LOOPS];
+    Q.chb_form = h->forms[MMX_SEL_CHB];
+    Q.generic_pairs = ((P.use_ev && Q.ev_form != 0) || (h->has_cob && Q.cob_form != 0) ||
+                       (h->has_scb && Q.scb_form != 0)) ? 1 : 0;
+    // the default cluster-kernel instance with Gaussians on works in scaled length units (exp2(-r'^2))
+    // (the kernel's LEAN condition: clamp mask, one cutoff, merged energies, no rank-2 / no-sweep variant)
+    h->nb_force_plain = false;
+    const int lo = nb_launch_opt(h);
+    const bool lean = !Q.generic_pairs && h->nb_variant != 1 && !all_pairs(h) &&
+                      (!(P.use_ev && P.use_gauss) || P.ev_rc2 == P.g_rc2) && (lo & 2) && (lo & 4) && !(lo & 1) && !(lo & 16);
+    h->nb_scale = (lean && P.use_gauss) ? std::sqrt(-P.g_c2) : 1.f;
+    // the clamp mask needs (scaled cutoff)^2 well below 1e6: an extreme r_comp falls back to a non-lean instance
+    h->nb_force_plain = lean && P.use_gauss && !(P.rc2max * h->nb_scale * h->nb_scale < 1e5f);
+    if (h->nb_force_plain) h->nb_scale = 1.f;
+}
+
+int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
+
+// ---- profiling helpers ----------------------------------------------------------------------
+bool prof_begin(mmx_handle_s *h, int slot, EventPair &ep) {
+    h->launches[slot]++;
+    if (h->profile <= 0) return false;
+    if ((h->launches[slot] - 1) % h->profile != 0) return false;
+    if (h->ev_pool.empty()) return false;
+    ep = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    ep.slot = slot;
+    (void)hipEventRecord(ep.a, h->stream);
+    return true;
+}
+void prof_end(mmx_handle_s *h, bool on, EventPair &ep) {
+    if (!on) return;
+    (void)hipEventRecord(ep.b, h->stream);
+    h->ev_used.push_back(ep);
+}
+void prof_collect(mmx_handle_s *h, mmx_stats *out) {
+    for (auto &ep : h->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess && out) {
+            out->kernel_ns[ep.slot] += (double)ms * 1e6;
+            out->kernel_samples[ep.slot] += 1;
+        }
+        h->ev_pool.push_back(ep);
+    }
+    h->ev_used.clear();
+}
+
+// ---- launch sequences -----------------------------------------------------------------------
+template <int PMODE>
+void launch_nb_cells_p(mmx_handle_s *h, int grid) {
+    const FFParams &P = h->P;
+#define NBJ(PM, EV, GA, SC, OPT)                                                                            \
+    hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
+                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part, h->nb_scale)
+#define NBC(EV, GA)                                                                                         \
+    do {                                                                                                    \
+        if (h->Q.generic_pairs) { /* non-default functional forms: one generic instance per term combination */ \
+            hipLaunchKernelGGL((k_nb_clusters_j<0, EV, GA, false, 14, true>), dim3(grid), dim3(256), 0,       \
+                               h->stream, P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g,  \
+                               h->part, 1.f, h->formp);                                                     \
+        } else if (h->nb_variant == 1)                                                                      \
+            hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
+                               h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
+        else if (!(EV && GA) || P.ev_rc2 == P.g_rc2) {                                                      \
+            /* default: cutoff by v_fma clamp + one energy accumulator pair per lane + per-bead cull;       \
+               nb_variant bits 32/64/128 switch these off one by one (A/B timing) */                        \
+            const int opt = nb_launch_opt(h);                                                               \
+            if (opt == 142) { NBJ(PMODE, EV, GA, true, 142); break; }                                       \
+            if (opt == 14 && h->nb_skip_energy) { NBJ(PMODE, EV, GA, true, 14 | 512); break; }              \
+            switch (opt) { /* A/B and diagnosis instances keep the plain block -> cluster mapping */        \
+            case 14: NBJ(PMODE, EV, GA, true, 14); break;                                                   \
+            case 30: NBJ(PMODE, EV, GA, true, 30); break;                                                   \
+            case 46: NBJ(PMODE, EV, GA, true, 46); break;                                                   \
+            case 22: NBJ(PMODE, EV, GA, true, 22); break;                                                   \
+            case 78: NBJ(PMODE, EV, GA, true, 78); break;                                                   \
+            case 62: NBJ(PMODE, EV, GA, true, 62); break;                                                   \
+            case 6: NBJ(PMODE, EV, GA, true, 6); break;                                                     \
+            case 12: NBJ(PMODE, EV, GA, true, 12); break;                                                   \
+            case 10: NBJ(PMODE, EV, GA, true, 10); break;                                                   \
+            default: NBJ(PMODE, EV, GA, true, 0); break;                                                    \
+            }                                                                                               \
+        } else                                                                                              \
+            NBJ(PMODE, EV, GA, false, 0);                                                                   \
+    } while (0)
+    if (P.use_ev && P.use_gauss) NBC(true, true);
+    else if (P.use_ev) NBC(true, false);
+    else NBC(false, true);
+#undef NBC
+#undef NBJ
+}
+
+template <int PMODE>
+void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
+    const FFParams &P = h->P;
+    dim3 b(256), gdim((h->n + 255) / 256, h->ap_slices);
+#define NBA(EV, GA)                                                                                         \
+    do {                                                                                                    \
+        const bool nocut = (!(EV) || std::isinf(P.ev_rc2)) && (!(GA) || std::isinf(P.g_rc2));               \
+        if (h->Q.generic_pairs)                                                                             \
+            hipLaunchKernelGGL((k_nb_allpairs<0, EV, GA, true>), gdim, b, 0, h->stream, P, h->pos4,          \
+                               tiles_per_slice, h->fpart, h->epart, h->st, h->formp);                       \
+        else if (nocut) /* the pure NoCutoff case (the reference's semantics): no masks in the pair loop */  \
+            hipLaunchKernelGGL((k_nb_allpairs_lean<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4,       \
+                               tiles_per_slice, h->fpart, h->epart, h->st);                                 \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_nb_allpairs<PMODE, EV, GA>), gdim, b, 0, h->stream, P, h->pos4,            \
+                               tiles_per_slice, h->fpart, h->epart, h->st);                                 \
+    } while (0)
+    if (P.use_ev && P.use_gauss) NBA(true, true);
+    else if (P.use_ev) NBA(true, false);
+    else NBA(false, true);
+#undef NBA
+}
+
+int nb_grid(const mmx_handle_s *h) {
+    if (h->nb_variant == 1) { // v1: one block per {cell, 64-bead chunk}
+        int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
+        int g = items + items / 4 + 64;
+        return std::max(256, std::min(g, kPartStride));
+    }
+    // cluster kernel: 4 clusters (waves) per block, grid-stride beyond the estimate
+    int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
+    int g = (cl + cl / 8) / 4 + 64;
+    return (std::max(256, std::min(g, kPartStride)) + 7) & ~7; // multiple of 8: whole rounds over the XCDs
+}
+
+// Fills pos4 of every bead from the host-set global positions (multi-GPU: beads of other ranks are
+// needed as ghosts before the first all-gather of a call).
+__global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const float *__restrict__ xg,
+                                                       const int8_t *__restrict__ labels, float4 *__restrict__ pos4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_all) return;
+    if (i < n)
+        pos4[i] = make_float4(xg[3 * i], xg[3 * i + 1], xg[3 * i + 2], __int_as_float((i << 3) | ((int)labels[i] + 2)));
+    else
+        pos4[i] = make_float4(3e18f, 3e18f, 3e18f, __int_as_float(-8 + 2)); // padding of the last slice
+}
+
+enum PackMode { PACK_PLAIN = 0, PACK_MOVE = 1, PACK_MD = 2 };
+
+DirArgs dir_args(const mmx_handle_s *h) { return DirArgs{h->g, h->gp, h->S, h->Y, (size_t)h->n4 * 4}; }
+
+
+bool has_comm(const mmx_handle_s *h) { return h->comm != nullptr || h->lcomm != nullptr; }
+
+__global__ void k_local_sum(int world, int count, double *const *__restrict__ boxes, double *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i >= count) return;
+    double r = 0.0;
+    for (int q = 0; q < world; ++q) r += boxes[q][i]; // rank order: every rank gets the same bits
+    out[i] = r;
+}
+
+// Loopback collectives.  Protocol per call (p = parity of the call number): [stage own data] -> record ready[r][p]
+// -> host barrier -> wait ready[q][p] of every rank, read their data -> record done[r][p] -> host barrier -> wait
+// done[q][p] of every rank (nobody may overwrite what another rank is still reading).
+bool local_begin(mmx_handle_s *h, int &p) {
+    LocalComm &L = *h->lcomm;
+    p = (int)(h->coll_seq++ & 1);
+    (void)hipEventRecord(L.ready[h->rank * 2 + p], h->stream);
+    if (!L.barrier()) return false;
+    for (int q = 0; q < L.world; ++q)
+        if (q != h->rank) (void)hipStreamWaitEvent(h->stream, L.ready[q * 2 + p], 0);
+    return true;
+}
+bool local_end(mmx_handle_s *h, int p) {
+    LocalComm &L = *h->lcomm;
+    (void)hipEventRecord(L.done[h->rank * 2 + p], h->stream);
+    if (!L.barrier()) return false;
+    for (int q = 0; q < L.world; ++q)
+        if (q != h->rank) (void)hipStreamWaitEvent(h->stream, L.done[q * 2 + p], 0);
+    return true;
+}
+
+// In-place all-gather of the position slices (ghost beads of every term).
+void coll_allgather_pos4(mmx_handle_s *h) {
+    if (h->comm) {
+        (void)g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat, h->comm,
+                               h->stream);
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        for (int q = 0; q < L.world; ++q)
+            if (q != h->rank)
+                (void)hipMemcpyAsync(h->pos4 + (size_t)q * h->slice, L.h[q]->pos4 + (size_t)q * h->slice,
+                                     sizeof(float4) * (size_t)h->slice, hipMemcpyDeviceToDevice, h->stream);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+}
+
+// In-place fp64 sum of `count` (<= 64) doubles over the ranks.
+void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
+    if (h->comm) {
+        (void)g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, h->stream);
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        const int p0 = (int)(h->coll_seq & 1);
+        (void)hipMemcpyAsync(L.mailbox[h->rank * 2 + p0], buf, sizeof(double) * count, hipMemcpyDeviceToDevice, h->stream);
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        hipLaunchKernelGGL(k_local_sum, dim3(1), dim3(64), 0, h->stream, L.world, count, h->lbox[p], buf);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+}
+
+void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
+
+// Pack (+ trial move / integrator step), then the cell build.  With `bonded` set, the bonded terms of the evaluation
+// -- which only need pos4 -- are enqueued with it: inside the launch of the cell scan ("overlap_bonded", default), or
+// right behind the pack.
+void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr) {
+    const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
+    const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
+    const bool dd = h->world > 1 || h->n_own != h->n;
+    const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h);
+    if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
+        MdParams M = h->md;
+        M.step_lo = (uint32_t)h->md_step;
+        M.step_hi = (uint32_t)(h->md_step >> 32);
+#define MDP(K)                                                                                              \
+    do {                                                                                                    \
+        if (fuse_count)                                                                                     \
+            hipLaunchKernelGGL((k_md_pack<K, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial,      \
+                               h->grid + (h->build_idx & 1), h->cell_of, h->rank_in_cell, h->count);        \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,   \
+                               h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial);     \
+    } while (0)
+        if (h->md_kind == MD_LANGEVIN) MDP(MD_LANGEVIN);
+        else if (h->md_kind == MD_VERLET) MDP(MD_VERLET);
+        else if (h->md_kind == MD_AMD) MDP(MD_AMD);
+        else MDP(MD_BROWNIAN);
+#undef MDP
+    } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
+        GridParams *cur = h->grid + (h->build_idx & 1);
+        if (mode == PACK_MOVE) // trial move of the minimizer: also forms the new direction after an accepted step
+            hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+                               h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
+                               h->count, dir_args(h));
+        else
+            hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
+                               h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
+    } else if (mode == PACK_MOVE)
+        hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+                           h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h));
+    else
+        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
+                           h->labels, h->pos4, h->bbox_part, h->st);
+    if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
+        coll_allgather_pos4(h);
+    const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
+    if (bonded && !in_scan) enqueue_bonded(h, *bonded, false);
+    if (has_nb(h) && !all_pairs(h)) {
+        const float hm = hmin_of(h);
+        GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
+        if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
+            hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
+                               dd ? hm : 0.f, cur, h->st);
+        if (!fuse_count)
+            hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
+                               cur, h->cell_of, h->rank_in_cell, h->count, h->st);
+        const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next};
+        if (in_scan) { // block 0 scans, the others are the bonded pass (four virtual 256-thread blocks each)
+            const int nvb = grid_beads(h->n_own);
+            const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+            const bool loops_on = h->n_rows > 0 && h->lstart;
+            hipLaunchKernelGGL((k_scan_bonded<kChunk>), dim3(1 + (nvb + 3) / 4), dim3(1024), 0, h->stream, sa, h->st,
+                               h->P, h->pos4, bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner,
+                               h->loop_r0, h->cf_w, h->g, h->part, h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb);
+            enqueue_bonded(h, *bonded, true);
+        } else {
+            hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
+        }
+        hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
+                           h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
+        // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order
+        if (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640)
+            hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(2048), dim3(256), 0, h->stream, cur, h->start,
+                               h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
+        else
+            hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(1024), dim3(256), 0, h->stream, cur, h->start,
+                               h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
+        h->gcur = cur;
+        h->build_idx++;
+    }
+}
+
+// Bonded terms + confinement (+ chromosomal blocks): the FIRST writers of the gradient in an evaluation (they read
+// pos4 only); the pair kernel adds its forces afterwards.  in_scan: the fused bonded pass already went out inside
+// k_scan_bonded, only its bookkeeping and the chromosomal blocks are left.
+void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan) {
+    EventPair ep{};
+    const int gb = grid_beads(h->n_own);
+    const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+    const bool loops_on = h->n_rows > 0 && h->lstart;
+    bool on;
+    if (in_scan) {
+        h->launches[MMX_K_CONFINE]++;
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
+    } else if (h->fused_bonded) {
+        // backbone + loops + confinement in one pass; booked in the "confine" timing slot
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL(k_bonded_fused, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, bb_on ? h->flags : nullptr,
+                           loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part, h->st,
+                           h->Q.loop_form, h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
+        A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
+    } else {
+        (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
+        if (bb_on) {
+            on = prof_begin(h, MMX_K_BACKBONE, ep);
+            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                               h->st);
+            prof_end(h, on, ep);
+            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
+        }
+        if (h->n_rows > 0) {
+            const int gl = std::min((h->n_rows + 255) / 256, 1024);
+            on = prof_begin(h, MMX_K_LOOPS, ep);
+            hipLaunchKernelGGL(k_loops, dim3(gl), dim3(256), 0, h->stream, h->P, h->n_rows, h->pos4, h->row_bead,
+                               h->row_start, h->partner, h->loop_r0, h->g, h->part, h->st, h->Q.loop_form);
+            prof_end(h, on, ep);
+            A.nblk[P_LOOP] = gl;
+        }
+        on = prof_begin(h, MMX_K_CONFINE, ep);
+        hipLaunchKernelGGL(k_confine, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part, h->st,
+                           h->Q.lam_form, h->Q.cf_form);
+        prof_end(h, on, ep);
+    }
+    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = gb;
+    if (h->P.use_chb && h->chrom_of) {
+        const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
+        on = prof_begin(h, MMX_K_CHB, ep);
+#define CHB(F)                                                                                              \
+    hipLaunchKernelGGL((k_chb<F>), dim3(gc), dim3(256), 0, h->stream, h->P, h->pos4, h->chrom_of, h->chrom_lo,    \
+                       h->chrom_hi, h->g, h->part, h->st)
+        if (h->Q.chb_form == 0) CHB(0);
+        else if (h->Q.chb_form == 1) CHB(1);
+        else CHB(2);
+#undef CHB
+        prof_end(h, on, ep);
+        A.nblk[P_CHB] = std::min(gc, kPartStride);
+    }
+}
+
+// What follows the forces of an evaluation.
+enum { FOLD_NONE = 0, // nothing (MD steps whose energies nobody reads)
+       FOLD_PLAIN,    // fold the energies (mmx_compute, MD reports)
+       FOLD_MIN };    // minimizer: history pass, then energies + line search + direction coefficients
+
+// One full energy+gradient evaluation: pack/move, [bonded terms || cell build], pair kernel, fold.
+void enqueue_eval(mmx_handle_s *h, int mode, int fold) {
+    EventPair ep{};
+    CtlArgs A{};
+    bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
+    enqueue_build(h, mode, false, &A);
+    prof_end(h, on, ep);
+    on = prof_begin(h, MMX_K_NONBONDED, ep);
+    if (!has_nb(h)) {
+        // the bonded pass wrote the whole gradient
+    } else if (all_pairs(h)) {
+        const int tiles = (h->n + 255) / 256;
+        const int tps = (tiles + h->ap_slices - 1) / h->ap_slices;
+        switch (h->P.ev_pmode) {
+        case 6: launch_nb_allpairs_p<6>(h, tps); break;
+        case 3: launch_nb_allpairs_p<3>(h, tps); break;
+        default: launch_nb_allpairs_p<0>(h, tps); break;
+        }
+        const int gf = grid_beads(h->n);
+        hipLaunchKernelGGL(k_nb_allpairs_fold, dim3(gf), dim3(256), 0, h->stream, h->n, h->ap_slices, h->fpart,
+                           h->epart, h->g, h->part, h->st);
+        A.nblk[P_EV] = A.nblk[P_GAUSS] = gf;
+    } else {
+        const int gn = nb_grid(h);
+        switch (h->P.ev_pmode) {
+        case 6: launch_nb_cells_p<6>(h, gn); break;
+        case 3: launch_nb_cells_p<3>(h, gn); break;
+        default: launch_nb_cells_p<0>(h, gn); break;
+        }
+        A.nblk[P_EV] = A.nblk[P_GAUSS] = gn;
+    }
+    prof_end(h, on, ep);
+    if (fold == FOLD_NONE) return;
+
+    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
+    if (fold == FOLD_MIN) {
+        // (s, y) of the step this evaluation would accept, its Gram rows, g.d and x.x: before the decision, so that
+        // decision and direction coefficients are ONE launch (and, multi-GPU, one all-reduce)
+        on = prof_begin(h, MMX_K_LBFGS, ep);
+        hipLaunchKernelGGL(k_history, dim3(gh, kHistGroups), dim3(256), 0, h->stream, h->n4, (const float4 *)h->x,
+                           (const float4 *)h->xp, (const float4 *)h->g, (const float4 *)h->gp, (const float4 *)h->d,
+                           (float4 *)h->S, (float4 *)h->Y, h->rows, h->st);
+        prof_end(h, on, ep);
+    }
+    on = prof_begin(h, MMX_K_REDUCE, ep);
+    if (fold == FOLD_MIN) {
+        if (!has_comm(h)) {
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
+        } else { // energies, Gram rows, g.d, x.x of all ranks: ONE fp64 all-reduce of 57 doubles per evaluation
+            hipLaunchKernelGGL(k_reduce_all, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
+            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
+        }
+        // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
+    } else if (!has_comm(h)) {
+        hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
+    } else { // energies of all ranks: one fp64 all-reduce of 16 doubles
+        hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
+        coll_allreduce(h, h->st->sums, 16);
+        hipLaunchKernelGGL(k_controller_decide, dim3(1), dim3(64), 0, h->stream, h->st);
+    }
+    prof_end(h, on, ep);
+}
+
+int push_state(mmx_handle_s *h) {
+    HIPCHK(h, hipMemcpyAsync(h->st, h->st_host, sizeof(MinState), hipMemcpyHostToDevice, h->stream));
+    return MMX_OK;
+}
+int pull_state(mmx_handle_s *h) {
+    HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
+    if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
+    if (h->st_host->max_per_cell > 0) h->last_max_per_cell = h->st_host->max_per_cell;
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, "loopback collective timed out: every rank of the group must make the same call from its own thread");
+    return MMX_OK;
+}
+
+int ensure_allpairs_scratch(mmx_handle_s *h) {
+    if (!all_pairs(h) || !has_nb(h)) return MMX_OK;
+    const int tiles = (h->n + 255) / 256;
+    int slices = std::max(1, std::min(64, (2048 + tiles - 1) / tiles));
+    slices = std::min(slices, tiles);
+    if (slices != h->ap_slices || !h->fpart) {
+        if (h->fpart) (void)hipFree(h->fpart);
+        if (h->epart) (void)hipFree(h->epart);
+        h->fpart = nullptr;
+        h->epart = nullptr;
+        HIPCHK(h, dalloc(&h->fpart, (size_t)slices * h->n));
+        HIPCHK(h, dalloc(&h->epart, (size_t)slices * h->n));
+        h->ap_slices = slices;
+    }
+    return MMX_OK;
+}
+
+// First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
+int prime_items(mmx_handle_s *h) {
+    if (!has_nb(h) || all_pairs(h)) return MMX_OK;
+    enqueue_build(h, PACK_PLAIN, true);
+    return pull_state(h);
+}
+
+int prepare(mmx_handle_s *h) {
+    if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set (mmx_set_positions)");
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_params(h);
+    if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
+        return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
+    if (has_nb(h) && !all_pairs(h) && h->n_all > (1 << 24)) // the cluster kernel addresses spos4 with 32-bit offsets
+        return fail(h, MMX_ERR_BAD_ARG, "the cell-list pair kernel supports up to 2^24 beads (the largest Hilbert start the "
+                                        "reference can build)");
+    if (h->Q.generic_pairs && h->nb_variant == 1 && has_nb(h) && !all_pairs(h))
+        return fail(h, MMX_ERR_STATE, "nb_variant 1 only implements the default functional forms");
+    int rc = ensure_allpairs_scratch(h);
+    if (rc) return rc;
+    if (h->Q.generic_pairs) {
+        if (!h->formp) HIPCHK(h, dalloc(&h->formp, (size_t)1));
+        HIPCHK(h, hipMemcpyAsync(h->formp, &h->Q, sizeof(FormParams), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // h->Q is pageable host memory that may change afterwards
+    }
+    if (h->xg && h->pos4_dirty) { // ghosts of the first evaluation come from the host-set global positions
+        hipLaunchKernelGGL(k_fill_pos4_all, dim3((h->n_all + 255) / 256), dim3(256), 0, h->stream, h->n, h->n_all,
+                           h->xg, h->labels, h->pos4);
+        h->pos4_dirty = false;
+    }
+    return MMX_OK;
+}
+
+} // namespace

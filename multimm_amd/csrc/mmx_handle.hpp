@@ -1,0 +1,197 @@
+// mmx_handle.hpp -- the engine handle behind `mmx_handle` (device buffers, options, profiling state), the RCCL entry
+// points resolved at run time, and the in-process loopback communicator.  Host code of libmmx.so; included by
+// mmx_api.hip only (one translation unit).
+#pragma once
+#include "../../include/mmx.h"
+#include "mmx_bonded.hpp"
+#include "mmx_cells.hpp"
+#include "mmx_common.hpp"
+#include "mmx_lbfgs.hpp"
+#include "mmx_md.hpp"
+#include "mmx_nonbonded.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the symbols are resolved with dlopen/dlsym when a communicator is requested
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+
+using namespace mmx;
+
+namespace {
+
+constexpr int kChunk = 64;
+constexpr int kMaxEvents = 8192;
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+} // namespace
+
+// RCCL entry points, loaded lazily (single-GPU users never need librccl.so)
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static bool load_rccl(std::string &err) {
+    static std::mutex mu; // handles may be driven from several threads (one per rank in loopback runs)
+    std::lock_guard<std::mutex> lock(mu);
+    if (g_rccl.lib) return true;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        err = std::string("cannot load librccl.so: ") + dlerror();
+        return false;
+    }
+#define RSYM(field, name)                                                                                  \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name);                                               \
+    if (!g_rccl.field) {                                                                                   \
+        err = std::string("librccl.so lacks ") + name;                                                     \
+        return false;                                                                                      \
+    }
+    RSYM(GetUniqueId, "ncclGetUniqueId");
+    RSYM(CommInitRank, "ncclCommInitRank");
+    RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllGather, "ncclAllGather");
+    RSYM(AllReduce, "ncclAllReduce");
+    RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+    g_rccl.lib = lib;
+    return true;
+}
+
+// In-process loopback communicator (mmx_comm_init_local): the ranks of a decomposed system are handles of ONE
+// process on ONE device, each driven by its own host thread.  Collectives = host barrier + HIP events +
+// device-to-device copies, summed in rank order.  It exists so that the multi-rank control flow (slices, ghosts,
+// identical decisions on every rank) can be executed and tested on a single GPU; production runs use RCCL.
+struct mmx_handle_s;
+struct LocalComm {
+    int world = 0;
+    std::vector<mmx_handle_s *> h;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool broken = false;
+    std::vector<hipEvent_t> ready, done; // [rank*2 + parity]
+    std::vector<double *> mailbox;       // [rank*2 + parity] -> 64 doubles on the device
+    ~LocalComm() {
+        for (auto e : ready) (void)hipEventDestroy(e);
+        for (auto e : done) (void)hipEventDestroy(e);
+        for (auto m : mailbox) (void)hipFree(m);
+    }
+    // Host barrier over the driving threads; false when a rank gave up (timeout / error) so that nobody hangs.
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return generation != gen || broken; })) broken = true;
+        if (broken) cv.notify_all();
+        return !broken;
+    }
+};
+
+struct mmx_handle_s {
+    int n = 0, n4 = 0, device = 0;
+    // domain decomposition (single GPU: rank 0 of 1, owns every bead)
+    int rank = 0, world = 1, slice = 0; // slice = beads per rank (n padded to world * slice = n_all)
+    int n_all = 0, own_lo = 0, n_own = 0;
+    ncclComm_t comm = nullptr;
+    std::shared_ptr<LocalComm> lcomm; // in-process loopback communicator (tests on one GPU)
+    unsigned long long coll_seq = 0;  // collectives issued so far (parity selects the event / mailbox set)
+    bool coll_failed = false;
+    double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
+    float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
+    bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation
+    hipStream_t stream = nullptr;
+    FFParams P{};
+    bool have_pos = false;
+    // vectors (float, padded to n4*4)
+    float *x = nullptr, *xp = nullptr, *g = nullptr, *gp = nullptr, *d = nullptr, *S = nullptr, *Y = nullptr;
+    float4 *pos4 = nullptr;
+    int8_t *labels = nullptr;
+    uint8_t *flags = nullptr;
+    float *cf_w = nullptr;
+    int *chrom_of = nullptr, *chrom_lo = nullptr, *chrom_hi = nullptr; // chromosomal blocks: id per bead, range per id
+    // cells
+    int *cell_of = nullptr, *count = nullptr, *rank_in_cell = nullptr, *start = nullptr, *istart = nullptr,
+        *perm = nullptr;
+    int2 *items = nullptr;
+    int *cstart = nullptr;                       // cluster offsets per cell
+    unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
+    float nb_scale = 1.f;                        // length scale of spos4 / cluster boxes (see k_nb_clusters_j, LEAN)
+    bool nb_force_plain = false;                 // scaled units unusable (extreme r_comp): unscaled, non-lean instance
+    bool nb_skip_energy = false;                 // MD steps between reports: pair forces only (default instance)
+    int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)
+    int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
+    float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
+    int last_clusters = -1;
+    GridParams *grid = nullptr;  // [2]: grid of this build / of the next one (ping-pong)
+    GridParams *gcur = nullptr;  // grid the last enqueued build used (what the pair kernel reads)
+    int build_idx = 0;
+    float *bbox_part = nullptr;  // [6][ceil(n/256)] per-block bounding boxes of k_pack
+    int maxcells = 262144;
+    int max_items = 0;
+    int last_items = -1;
+    // reductions / state
+    double *part = nullptr, *rows = nullptr;
+    MinState *st = nullptr;      // device
+    MinState *st_host = nullptr; // pinned
+    // loops (CSR over beads carrying a loop end)
+    int n_loops = 0, n_rows = 0;
+    int *row_bead = nullptr, *row_start = nullptr, *partner = nullptr;
+    int *lstart = nullptr; // [n_own + 1] loop entries per owned bead (same partner / r0 arrays; fused bonded kernel)
+    float *loop_r0 = nullptr;
+    // all-pairs scratch
+    float4 *fpart = nullptr;
+    float2 *epart = nullptr;
+    int ap_slices = 0;
+    // compartments
+    float tab_cob[25]{}, tab_scb[25]{};
+    bool has_cob = false, has_scb = false;
+    float ev_cut = 0.f, g_cut = 0.f, g_rc = 0.15f;
+    // molecular dynamics (mmx_md_*): velocities, low-order position bits, integrator constants
+    float *v = nullptr, *xlo = nullptr;
+    double *ke_part = nullptr, *ke_out = nullptr;
+    bool md_configured = false, md_forces_valid = false;
+    int md_kind = 0;
+    double md_dt = 0.0, md_temp = 0.0, md_friction = 0.0, md_mass = 1.0;
+    double amd_alpha = 100.0, amd_e = 1000.0; // config.py:255-256
+    uint64_t md_seed = 0, md_step = 0;
+    MdParams md{};
+    int forms[MMX_N_SELECTORS]{}; // functional form per term selector (0 = default)
+    FormParams Q{};               // derived constants of the non-default forms (host copy)
+    FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
+    // options
+    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
+    // profiling
+    std::vector<EventPair> ev_pool, ev_used;
+    int64_t launches[MMX_N_KERNELS]{};
+    std::string err;
+};
