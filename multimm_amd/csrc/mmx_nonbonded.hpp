@@ -264,8 +264,10 @@ __device__ __forceinline__ int prefix_count(unsigned long long mask) {
 constexpr int kCl = 8;        // beads per cluster
 constexpr int kListCap = 448; // accepted j-clusters buffered per wave before a sweep
 
+// Occupancy bound: 6 waves/SIMD = 80 VGPRs for the energy instances (7 would spill 32 B per lane, measured -3 %); the
+// forces-only instances of MD (OPT & 512) fit 72 VGPRs without scratch and take 7 (+0.5 %; p = 3 would spill 12 B).
 template <int PMODE, bool EV, bool GAUSS, bool SAMECUT, int OPT, bool FORMS = false>
-__global__ __launch_bounds__(256, FORMS ? 2 : 6) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
+__global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 : 6)) void k_nb_clusters_j(const FFParams P, const float4 *__restrict__ spos4,
                                                        const float4 *__restrict__ cl_lo,
                                                        const float4 *__restrict__ cl_hi,
                                                        const int *__restrict__ cstart,
