@@ -300,9 +300,13 @@ __global__ __launch_bounds__(256) void k_history(int n4, const float4 *__restric
 
 // Gram update + two-loop recursion in coefficient space (liblbfgs lbfgs() main-loop tail), run by ONE
 // thread on the folded (multi-GPU: all-reduced) Gram rows.
-__device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const double *s_rows) {
+// G: the 13x13 Gram matrix -- st->gram itself, or a copy of it in LDS that the caller loaded with all threads and
+// stores back afterwards (the recursion reads 12 rows one after the other: 12 dependent L2 round trips on global
+// memory, 5 us of single-thread time; ~0.5 us out of LDS).
+// ysl: the curvatures <y_k, s_k> of the stored pairs, loaded by the caller BEFORE any store to *st (a load of
+// st->ys[j] inside the recursion cannot be hoisted over those stores: 12 more dependent round trips).
+__device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const double *s_rows, double *G, double *ysl) {
     constexpr int NB = MMX_NBASIS, M = MMX_M, IG = 2 * MMX_M;
-    double *G = st->gram;
     const bool store = st->store_hist != 0;
     const int slot = st->end;
     if (store) {
@@ -320,6 +324,7 @@ __device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const dou
     if (store) {
         const double ys = G[slot * NB + (M + slot)], yy = G[(M + slot) * NB + (M + slot)];
         st->ys[slot] = ys;
+        ysl[slot] = ys;
         const int bound = M <= st->k ? M : st->k;
         st->bound = bound;
         st->k += 1;
@@ -330,7 +335,7 @@ __device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const dou
             j = (j + M - 1) % M;
             double sd = 0.0;
             for (int b = 0; b < NB; ++b) sd += c[b] * G[j * NB + b];
-            alpha[j] = sd / st->ys[j];
+            alpha[j] = sd / ysl[j];
             c[M + j] -= alpha[j];
         }
         const double sc = ys / yy;
@@ -338,7 +343,7 @@ __device__ __forceinline__ void coef_decide(MinState *__restrict__ st, const dou
         for (int i = 0; i < bound; ++i) {
             double yd = 0.0;
             for (int b = 0; b < NB; ++b) yd += c[b] * G[(M + j) * NB + b];
-            const double beta = yd / st->ys[j];
+            const double beta = yd / ysl[j];
             c[j] += alpha[j] - beta;
             j = (j + 1) % M;
         }
@@ -399,19 +404,31 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
     __shared__ double s_task[kMaxTasks];
     __shared__ double s_out[P_NSLOTS];
     __shared__ double s_rows[MMX_NROWSUM];
+    __shared__ double s_G[MMX_NBASIS * MMX_NBASIS];
     __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    __shared__ int s_accepted;
+    __shared__ double s_ys[MMX_M];
     double acc[3];
     rows_load<MMX_NROWSUM>(rows, nblk_rows, acc); // nblk_rows <= 256 (enqueue_history)
+    // the Gram matrix rides in the same latency round as the partials
+    const double gval = threadIdx.x < MMX_NBASIS * MMX_NBASIS ? st->gram[threadIdx.x] : 0.0;
+    const double yval = threadIdx.x < MMX_M ? st->ys[threadIdx.x] : 0.0;
     slot_counts(A, s_n);
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    rows_finish<MMX_NROWSUM>(acc, s_rows);
-    if (threadIdx.x != 0) return;
-    double sums[P_NSLOTS];
+    if (threadIdx.x < MMX_NBASIS * MMX_NBASIS) s_G[threadIdx.x] = gval;
+    if (threadIdx.x < MMX_M) s_ys[threadIdx.x] = yval;
+    rows_finish<MMX_NROWSUM>(acc, s_rows); // ends with a barrier: s_G is complete too
+    if (threadIdx.x == 0) {
+        double sums[P_NSLOTS];
 #pragma unroll
-    for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
-    dots_from_rows(sums, s_rows);
-    controller_decide(st, sums);
-    if (st->accepted) coef_decide(st, s_rows);
+        for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
+        dots_from_rows(sums, s_rows);
+        controller_decide(st, sums);
+        s_accepted = st->accepted;
+        if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
+    }
+    __syncthreads();
+    if (s_accepted && threadIdx.x < MMX_NBASIS * MMX_NBASIS) st->gram[threadIdx.x] = s_G[threadIdx.x];
 }
 
 // Multi-GPU: fold -> st->sums (+ st->rowsum) -> ncclAllReduce (fp64 sum, in place) -> decide on every rank.
@@ -455,11 +472,13 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    double ysl[MMX_M];
+    for (int k = 0; k < MMX_M; ++k) ysl[k] = st->ys[k];
     double sums[P_NSLOTS];
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
     dots_from_rows(sums, st->rowsum);
     controller_decide(st, sums);
-    if (st->accepted) coef_decide(st, st->rowsum);
+    if (st->accepted) coef_decide(st, st->rowsum, st->gram, ysl);
 }
 
 // d = sum_a coef[a] * B_a (with xp <- x, gp <- g) is formed per bead by the next trial move: k_pack<.., DIR> in
