@@ -107,8 +107,8 @@ int mmx_abi_version(void);
  * [r*slice, min(N, (r+1)*slice)), slice = ceil(N/world): forces, energies and the L-BFGS state of those
  * beads live on its GPU.  Every setter still takes the arrays of the WHOLE system.  Per evaluation the
  * ranks all-gather their position slices (ghost beads for pair, bond, angle and loop terms) and
- * all-reduce 16 doubles (energies, g.d, g.g, x.x); per accepted iteration 40 doubles (Gram rows) --
- * RCCL, issued on the handle's stream, no host round trip.  Without a communicator a multi-rank
+ * all-reduce once: 57 doubles in the minimizer (energies, the three Gram rows an accepted step would change, g.d,
+ * x.x), 16 in a plain evaluation -- RCCL, issued on the handle's stream, no host round trip.  Without a communicator a multi-rank
  * handle still evaluates its owned beads against the positions last set by the host (unit tests). */
 int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out);
 int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world);
