@@ -1,7 +1,8 @@
-// mmx_bonded.hpp -- K3 backbone bonds+angles, K4 loop restraints, K5 confinement/lamina/central (+ dots).
+// mmx_bonded.hpp -- K3 backbone bonds+angles, K4 loop restraints, K5 confinement/lamina/central.
 // All three are per-bead gather kernels: the thread of bead i computes every contribution to
 // the gradient of bead i itself (neighbours come from L1/L2), so there are no atomics and the result
-// is bitwise reproducible.  Each does g[i] += dE/dx_i.
+// is bitwise reproducible.  The separate kernels each do g[i] += dE/dx_i; the fused pass (the default) WRITES g[i]:
+// it is the first writer of the gradient in an evaluation and the pair kernels add to it (see k_scan_bonded).
 #pragma once
 #include "mmx_cells.hpp"
 #include "mmx_common.hpp"
