@@ -13,9 +13,10 @@ ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collect
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
 pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
 "cpu_baseline" = the in-repo fp64 oracle (OpenMM is not installed; kind "port") timed on the host cores
-on a bounded sample of the same workload.  At N = 1 a third object, "replicas_per_gpu", reports -- outside the timed
-region and never as part of `value` -- the aggregate rate of three independent replicas sharing the GPU
-(`run_ensemble(..., concurrent=3)`): a single minimization leaves the GPU idle in its latency-bound launches.
+on a bounded sample of the same workload.  With `--replicas-per-gpu 3` (N = 1) a third object, "replicas_per_gpu",
+reports -- outside the timed region and never as part of `value` -- the aggregate rate of three independent replicas
+sharing the GPU (`run_ensemble(..., concurrent=3)`): a single minimization leaves the GPU idle in its latency-bound
+launches.  Off by default: its concurrent kernels would mix into a profile of the default command.
 """
 from __future__ import annotations
 
@@ -52,9 +53,10 @@ def parse_args():
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
                     help="N > 1: 'ensemble' = one replica per GPU (config 4, weak scaling, no collective); "
                          "'dd' = ONE system decomposed over the GPUs (config 5, strong scaling, RCCL)")
-    ap.add_argument("--replicas-per-gpu", type=int, default=3,
-                    help="extra leg at N=1 (never part of `value`): aggregate rate of this many replicas sharing the GPU; "
-                         "<= 1 disables")
+    ap.add_argument("--replicas-per-gpu", type=int, default=0,
+                    help="extra leg at N=1 (never part of `value`, off by default so that a profile of the default "
+                         "command contains the timed minimization only): aggregate rate of this many replicas sharing "
+                         "the GPU, e.g. 3")
     ap.add_argument("--serial-bonded", action="store_true",
                     help="bonded terms on the main stream instead of beside the cell build (A/B of the overlap)")
     ap.add_argument("--separate-bonded", action="store_true",

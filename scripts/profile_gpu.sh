@@ -8,9 +8,9 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd $R
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-seconds 0 --replicas-per-gpu 0 > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-seconds 0 > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --replicas-per-gpu 0 > $OUT/pmc_$C.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/pmc_$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
