@@ -93,6 +93,18 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             }
             HIPCHK(h, hipMemcpy(h->spos4 + (size_t)h->n_all * 8, farc, sizeof(farc), hipMemcpyHostToDevice));
         }
+        // half-shell pair kernel: force per cluster slot (single-domain handles only) and its LDS window.  Above 64 KB of
+        // LDS per workgroup the runtime wants to be told; a device that refuses keeps the full-shell kernel.
+        if (h->world == 1) {
+            h->fstride = (h->n_all + 1) * 8;
+            HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
+            h->n3_cap = n3_configure(kN3MaxCap);
+            // an item ends at a row end, at 32 clusters, or at a cell boundary: never more than cells + clusters / 32
+            h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 256 + 64;
+            HIPCHK(h, dalloc(&h->n3_items, (size_t)h->n3_max_items));
+            h->n_cus = prop.multiProcessorCount;
+            HIPCHK(h, dalloc(&h->n3_dbg, (size_t)8));
+        }
         HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all * 2)); // interleaved {lo, hi} box records
         HIPCHK(h, dalloc(&h->cl_hi, (size_t)1));             // (kept as a kernel argument, unused)
         HIPCHK(h, dalloc(&h->grid, 2));
@@ -210,7 +222,7 @@ int mmx_destroy(mmx_handle h) try {
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
-                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist})
+                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->n3_dbg})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
@@ -565,6 +577,12 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
+    else if (k.rfind("n3_dbg", 0) == 0 && k.size() == 7 && h->n3_dbg) { // n3_dbg0..7: cycle counters of k_nb_n3 (diagnosis)
+        unsigned long long v[8];
+        HIPCHK(h, hipMemcpy(v, h->n3_dbg, sizeof(v), hipMemcpyDeviceToHost));
+        *value = (double)v[k[6] - '0'];
+        if (k[6] == '7') HIPCHK(h, hipMemset(h->n3_dbg, 0, sizeof(v))); // reading the last one clears them
+    }
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)

@@ -342,6 +342,8 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
         cstart[G.ncells] = tot_c;
         st->n_clusters = tot_c;
         st->n_big = tot_d;
+        st->n3_items = 0; // k_n3_items (next in the stream) counts them
+        st->n3_queue = 0;
         *grid_next = GN;
         int m = 0;
         for (int w = 0; w < 16; ++w) m = max(m, s_m[w]);

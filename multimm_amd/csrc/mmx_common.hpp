@@ -89,6 +89,8 @@ struct MinState {
     int n_clusters; // 8-bead clusters of the last cell build
     int order_fallbacks; // cells too large for the in-LDS sort since the state was pushed (arrival order kept)
     int n_big;           // cells of > 64 beads in the last cell build (sorted by a whole block each)
+    int n3_items;        // work items of the half-shell pair kernel (k_n3_items, after every cell scan)
+    int n3_queue;        // ... and the head of their queue (persistent workgroups pull from it)
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;

@@ -103,10 +103,24 @@ void refresh_params(mmx_handle_s *h) {
     const int lo = nb_launch_opt(h);
     const bool lean = !Q.generic_pairs && h->nb_variant != 1 && !all_pairs(h) &&
                       (!(P.use_ev && P.use_gauss) || P.ev_rc2 == P.g_rc2) && (lo & 2) && (lo & 4) && !(lo & 1) && !(lo & 16);
+    h->nb_lean = lean;
     h->nb_scale = (lean && P.use_gauss) ? std::sqrt(-P.g_c2) : 1.f;
     // the clamp mask needs (scaled cutoff)^2 well below 1e6: an extreme r_comp falls back to a non-lean instance
     h->nb_force_plain = lean && P.use_gauss && !(P.rc2max * h->nb_scale * h->nb_scale < 1e5f);
-    if (h->nb_force_plain) h->nb_scale = 1.f;
+    if (h->nb_force_plain) {
+        h->nb_scale = 1.f;
+        h->nb_lean = false;
+    }
+}
+
+// The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
+// caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
+// forces it off (A/B timing).
+bool use_n3(const mmx_handle_s *h) {
+    if (!h->nb_lean || h->n3_cap <= 0 || !h->fsort || !h->n3_items || h->world > 1 || h->n_own != h->n) return false;
+    if (h->nb_variant & 8192) return false;
+    if (h->nb_variant & 4096) return true;
+    return !h->deterministic && (h->nb_variant & 0xffff & ~(4096 | 8192)) == 0;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
@@ -141,9 +155,60 @@ void prof_collect(mmx_handle_s *h, mmx_stats *out) {
 }
 
 // ---- launch sequences -----------------------------------------------------------------------
+// LDS force window of k_nb_n3: `want` clusters when the runtime grants the dynamic LDS beyond the default 64 KB per
+// workgroup (gfx950 has 160 KB per CU), else what fits in 64 KB next to the kernel's ~35 KB of static LDS.
+int n3_configure(int want) {
+    const int bytes = (int)n3_lds_bytes(want);
+    bool ok = true;
+#define N3ATTR(PM, EV, GA, NE)                                                                              \
+    ok = ok && hipFuncSetAttribute((const void *)k_nb_n3<PM, EV, GA, NE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   bytes) == hipSuccess
+#define N3ATTR_PM(PM)                                                                                       \
+    N3ATTR(PM, true, true, false); N3ATTR(PM, true, true, true); N3ATTR(PM, true, false, false);            \
+    N3ATTR(PM, true, false, true); N3ATTR(PM, false, true, false); N3ATTR(PM, false, true, true)
+    N3ATTR_PM(6);
+    N3ATTR_PM(3);
+    N3ATTR_PM(0);
+#undef N3ATTR_PM
+#undef N3ATTR
+    if (!ok) (void)hipGetLastError();
+    return ok ? want : 0; // refused: the full-shell kernel stays in charge
+}
+
+int n3_grid(const mmx_handle_s *h) { return std::max(1, h->n_cus); } // one persistent workgroup per CU
+
+template <int PMODE>
+void launch_nb_n3_p(mmx_handle_s *h, int grid) {
+    const FFParams &P = h->P;
+    const int cap = h->n3_cap;
+    const size_t lds = n3_lds_bytes(cap);
+#define N3(EV, GA)                                                                                          \
+    do {                                                                                                    \
+        if (h->nb_skip_energy)                                                                              \
+            hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
+                               h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
+                               h->nb_scale, cap, (h->nb_variant >> 16) & 255, h->n3_dbg);                   \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
+                               h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
+                               h->nb_scale, cap, (h->nb_variant >> 16) & 255, h->n3_dbg);                   \
+    } while (0)
+    if (P.use_ev && P.use_gauss) N3(true, true);
+    else if (P.use_ev) N3(true, false);
+    else N3(false, true);
+#undef N3
+    const int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
+    const int gu = std::max(64, std::min((cl * 8 + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->spos4, h->fsort, h->fstride, h->g, h->st);
+}
+
 template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
+    if (use_n3(h)) {
+        launch_nb_n3_p<PMODE>(h, grid);
+        return;
+    }
 #define NBJ(PM, EV, GA, SC, OPT)                                                                            \
     hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
                        h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part, h->nb_scale)
@@ -208,6 +273,7 @@ void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
 }
 
 int nb_grid(const mmx_handle_s *h) {
+    if (use_n3(h)) return n3_grid(h);
     if (h->nb_variant == 1) { // v1: one block per {cell, 64-bead chunk}
         int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
         int g = items + items / 4 + 64;
@@ -369,6 +435,9 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         } else {
             hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
         }
+        if (use_n3(h)) // work items of the half-shell pair kernel: needs the scan's cluster offsets only
+            hipLaunchKernelGGL(k_n3_items, dim3(32), dim3(256), 0, h->stream, cur, h->cstart, h->n3_items, h->n3_cap,
+                               h->n3_max_items, h->st);
         hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                            h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order

@@ -9,6 +9,7 @@
 #include "mmx_lbfgs.hpp"
 #include "mmx_md.hpp"
 #include "mmx_nonbonded.hpp"
+#include "mmx_nonbonded_n3.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types only: the symbols are resolved with dlopen/dlsym when a communicator is requested
@@ -152,6 +153,13 @@ struct mmx_handle_s {
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
     int last_clusters = -1;
+    float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
+    int fstride = 0;
+    bool nb_lean = false;                        // the lean pair loop applies (default forms, one cutoff): refresh_params
+    int n3_cap = 0;                              // LDS force window of k_nb_n3 in clusters (0: not usable on this device)
+    N3Item *n3_items = nullptr;                  // its work items (k_n3_items, after every cell scan)
+    int n3_max_items = 0, n_cus = 0;
+    unsigned long long *n3_dbg = nullptr;        // [8] cycle counters of k_nb_n3 (nb_variant diagnosis bit)
     GridParams *grid = nullptr;  // [2]: grid of this build / of the next one (ping-pong)
     GridParams *gcur = nullptr;  // grid the last enqueued build used (what the pair kernel reads)
     int build_idx = 0;
