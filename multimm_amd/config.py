@@ -57,6 +57,9 @@ class SimulationConfig:
 
     PLATFORM: str = "MI355X"
     DEVICE: int = 0
+    # engine-only key, named after the OpenMM platform property ("DeterministicForces", false by default there too):
+    # True selects the full-shell pair kernel, whose summation order is fixed (bitwise reproducible runs)
+    DETERMINISTIC_FORCES: bool = False
     MODELLING_LEVEL: str = ""
     N_BEADS: int = 50000
     OUT_PATH: str = "results"

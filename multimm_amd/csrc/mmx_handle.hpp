@@ -197,7 +197,7 @@ struct mmx_handle_s {
     FormParams Q{};               // derived constants of the non-default forms (host copy)
     FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
     // options
-    int deterministic = 1, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
+    int deterministic = 0, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
     // profiling
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};

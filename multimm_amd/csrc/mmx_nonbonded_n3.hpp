@@ -9,7 +9,7 @@
 // float atomics") -- one flush per 64-bead batch would need ~280 MB of them per evaluation at 200 000 beads, one flush
 // per work item needs a tenth of that, in 256-byte contiguous wave instructions.
 //
-// Work item (k_n3_items builds the list after every cell scan) = a run of up to 32 consecutive clusters of one ROW of
+// Work item (k_n3_items builds the list after every cell scan) = a run of up to 16 consecutive clusters of one ROW of
 // the cell grid (x is the fastest cell index, so a row is one contiguous stretch of the cell-sorted cluster list); the
 // run may span several cells when they are sparse.  Half shell by cells: the j candidates of the run are, in
 // increasing cluster order, (0) the clusters of its own row from the run's first cluster to the end of the cell after
@@ -43,13 +43,14 @@ namespace mmx {
 
 constexpr int kN3Waves = 16;        // waves per workgroup
 constexpr int kN3Threads = kN3Waves * 64;
-constexpr int kN3ItemClusters = 32; // i-clusters per work item (grabbed one at a time by the waves)
+constexpr int kN3ItemClusters = 16; // i-clusters per work item (grabbed one at a time by the waves)
 constexpr int kN3List = 128;        // accepted j-clusters buffered per wave before a sweep
-constexpr int kN3MaxCap = 608;      // largest LDS window, in clusters (14 cells of 43 clusters: the lattice start)
-// A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 32 units cannot
+constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two windows in flight: 160 KB of LDS, all of it)
+// A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
 // overflow; a larger one (overlapping beads) bypasses LDS with a global float atomic.
 constexpr float kN3Fix = 8192.f;
-constexpr float kN3FixLim = 67108864.f * 0.999f; // 2^26 units = 8192 kJ/mol/nm
+constexpr float kN3FixLim = 134217728.f * 0.999f; // 2^27 units = 16384 kJ/mol/nm
+static_assert(kN3ItemClusters * 134217728.0 <= 2147483648.0, "a window slot must not overflow");
 
 struct N3Item { // 64 bytes
     int a, n;          // i-clusters [a, a + n)
@@ -59,10 +60,22 @@ struct N3Item { // 64 bytes
     int pad1[2];
 };
 
-// dynamic LDS of k_nb_n3 for a window of `cap` clusters: force sums, two candidate buffers (boxes + ids)
+// dynamic LDS of k_nb_n3 for windows of `cap` clusters: two force windows, two box buffers, four id buffers
 constexpr size_t n3_lds_bytes(int cap) {
-    return sizeof(int) * 3 * ((size_t)cap * 8 + 8) + 2 * (sizeof(float4) * 2 * ((size_t)cap + 1) + sizeof(int) * ((size_t)cap + 8));
+    return sizeof(int) * 2 * 3 * ((size_t)cap * 8 + 8) + sizeof(float4) * 2 * 2 * ((size_t)cap + 1) + sizeof(int) * 4 * ((size_t)cap + 8);
 }
+
+// Control block of the unit pipeline (LDS).  Unit v uses force window v & 1, box buffer v & 1, id buffer v & 3 (while
+// unit v + 2 is staged, the ids of v - 1 and v are still needed by their flushes and those of v + 1 by its compute).
+struct N3Ctl {
+    int grab[2];     // next i-cluster of the unit in this parity
+    int done[2];     // waves that have run out of i-clusters of it
+    int ready[2];    // highest unit number whose window, boxes and ids are in place
+    int fl_epoch[2]; // unit whose window is being flushed (job open)
+    int fl_next[2], fl_done[2], fl_total[2], fl_nwin[2], fl_ids[2];
+    int error;
+};
+constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gives up (a bug, not a state of the data)
 
 // ---- item builder ---------------------------------------------------------------------------------------------
 // One thread per row of the cell grid walks the row's clusters and cuts them into runs: at most kN3ItemClusters
@@ -182,41 +195,39 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           double *__restrict__ part, const float sc, const int cap,
                                                           const int diag = 0, unsigned long long *__restrict__ dbg = nullptr) {
     if (st->phase == PH_DONE) return;
-    unsigned long long t_cmp = 0, t_stage = 0, t_bar = 0, t_flush = 0, t_mark = 0; // diag & 128: where the time goes
-    // dynamic LDS: [3][cap*8 + 8] int force sums per window slot, x | y | z (fixed point, see kN3Fix; the last 8 slots
-    // are a dummy cluster), then two candidate buffers {[cap + 1][2] float4 boxes, [cap + 8] cluster ids}
+    (void)dbg;
+    // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
+    // 8 slots are a dummy cluster), two box buffers [cap + 1][2] float4, four id buffers [cap + 8] int
     extern __shared__ __attribute__((aligned(16))) int s_f[];
     __shared__ unsigned short s_list[kN3Waves][kN3List + 72];
     __shared__ float4 s_ring[kN3Waves][128];
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ float s_arow[kN3Waves][kCl * 8];
     __shared__ double s_e[2][kN3Waves];
-    __shared__ int s_item[4]; // queue positions of the units to come (ring of 3) ...
-    __shared__ int s_grab[2]; // ... and the next i-cluster of the current unit (one counter per parity)
+    __shared__ int s_desc[2][16]; // unit descriptors: a, n, T, wlo, rlo[5], rn[5], id buffer
+    __shared__ N3Ctl ctl;
     // the wave index in a scalar register: hipcc cannot prove threadIdx.x >> 6 uniform and would otherwise keep the
     // scalar i beads in vector registers
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane >> 3, slot = lane & 7;
     const int fstr = cap * 8 + 8;
-    int *sfx = s_f, *sfy = s_f + fstr, *sfz = s_f + 2 * fstr;
-    const int cand_ints = 8 * (cap + 1) + (cap + 8); // one candidate buffer, in 4-byte words
-    int *cand0 = s_f + 3 * fstr;
+    int *const box0 = s_f + 2 * 3 * fstr;           // box buffers
+    int *const ids0 = box0 + 2 * 8 * (cap + 1);     // id buffers
     const int far_cl = P.n_all; // a resident all-padding cluster (8 beads at -1e18)
     const int n_items = st->n3_items;
     if (threadIdx.x < 40) {
         const bool in5 = (threadIdx.x & 7) < 5;
         s_tab[threadIdx.x] = in5 ? P.table[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.f;
     }
-    for (int q = threadIdx.x * 4; q < 3 * fstr; q += kN3Threads * 4) *reinterpret_cast<int4 *>(s_f + q) = make_int4(0, 0, 0, 0);
-    if (threadIdx.x < 16) { // list padding points at window entry `cap` of either buffer: the dummy cluster
-        int *jc = cand0 + (threadIdx.x >> 3) * cand_ints + 8 * (cap + 1);
-        jc[cap + (threadIdx.x & 7)] = far_cl;
-    }
+    for (int q = threadIdx.x * 4; q < 2 * 3 * fstr; q += kN3Threads * 4) *reinterpret_cast<int4 *>(s_f + q) = make_int4(0, 0, 0, 0);
+    if (threadIdx.x < 32) // list padding points at window entry `cap` of every id buffer: the dummy cluster
+        ids0[(threadIdx.x >> 3) * (cap + 8) + cap + (threadIdx.x & 7)] = far_cl;
     if (threadIdx.x == 0) {
-        // the first two units of this workgroup; everything after them is fetched two units ahead
-        s_item[0] = atomicAdd(&st->n3_queue, 2);
-        s_item[1] = s_item[0] + 1;
-        s_grab[0] = s_grab[1] = 0;
+        ctl.grab[0] = ctl.grab[1] = ctl.done[0] = ctl.done[1] = 0;
+        ctl.ready[0] = ctl.ready[1] = -1;
+        ctl.fl_epoch[0] = ctl.fl_epoch[1] = -100;
+        ctl.fl_next[0] = ctl.fl_next[1] = ctl.fl_done[0] = ctl.fl_done[1] = ctl.fl_total[0] = ctl.fl_total[1] = 0;
+        ctl.error = 0;
     }
     __syncthreads();
     unsigned short *list = s_list[wave];
@@ -251,71 +262,171 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     }
     double acc_ev = 0.0, acc_g = 0.0;
 
-    // Stages window [wlo, wlo + cap) of item `it` into candidate buffer `buf`: this wave's share (every 16th group of
-    // 64 candidates).  Candidate k of the concatenated runs -> cluster id, box.
-    auto stage = [&](const N3Item &it, int wlo, int buf) {
-        float4 *box = reinterpret_cast<float4 *>(cand0 + buf * cand_ints);
-        int *jcs = cand0 + buf * cand_ints + 8 * (cap + 1);
-        const int nwin = min(it.T, wlo + cap) - wlo;
-        int woff[5];
-        woff[0] = 0;
+    volatile int *vready = ctl.ready, *vepoch = ctl.fl_epoch;
+    // Flush job of parity p (window of unit `unit`): takes one chunk of 256 window slots if there is one left.
+    // fsort[slot] -= sum / 2^13; the 8 slots of a cluster are contiguous, neighbouring candidates mostly too: 256-byte
+    // atomic wave instructions.  Zeroes what it flushes; whoever hands in the last token declares unit + 2 ready.
+    auto help_flush = [&](int p, int unit) {
+        if (vepoch[p] != unit) return;
+        const int total = ctl.fl_total[p];
+        int c = total;
+        if (lane == 0 && *(volatile int *)&ctl.fl_next[p] < total) c = atomicAdd(&ctl.fl_next[p], 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= total) return;
+        int *wx = s_f + p * 3 * fstr, *wy = wx + fstr, *wz = wy + fstr;
+        const int *jcs = ids0 + ctl.fl_ids[p] * (cap + 8);
+        const int nsl = ctl.fl_nwin[p] * 8;
 #pragma unroll
-        for (int r = 1; r < 5; ++r) woff[r] = woff[r - 1] + it.rn[r - 1];
-        for (int k = wave * 64 + lane; k < nwin; k += kN3Threads) {
-            const int kk = wlo + k;
-            int jc = it.rlo[0] + kk;
-#pragma unroll
-            for (int r = 1; r < 5; ++r) jc = kk >= woff[r] ? it.rlo[r] + (kk - woff[r]) : jc;
-            jcs[k] = jc;
-            box[2 * k] = cl_box[2 * jc];
-            box[2 * k + 1] = cl_box[2 * jc + 1];
+        for (int r = 0; r < 4; ++r) {
+            const int e = c * 256 + r * 64 + lane;
+            if (e < nsl) {
+                const int vx = wx[e], vy = wy[e], vz = wz[e];
+                if ((vx | vy | vz) != 0) {
+                    wx[e] = 0;
+                    wy[e] = 0;
+                    wz[e] = 0;
+                    if (!(diag & 1)) {
+                        const int gs = jcs[e >> 3] * kCl + (e & 7);
+                        atomicAdd(fsort + gs, unfix * (float)vx);
+                        atomicAdd(fsort + fstride + gs, unfix * (float)vy);
+                        atomicAdd(fsort + 2 * fstride + gs, unfix * (float)vz);
+                    }
+                }
+            }
         }
+        if (c == 0 && lane < 8) wx[cap * 8 + lane] = wy[cap * 8 + lane] = wz[cap * 8 + lane] = 0; // the dummy cluster
+        wave_lds_sync();
+        if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == total) vready[p] = unit + 2;
     };
-    auto load_item = [&](int q) {
-        N3Item it;
-        const int4 *p = reinterpret_cast<const int4 *>(items + (q < n_items ? q : 0));
-        const int4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-        it.a = __builtin_amdgcn_readfirstlane(v0.x);
-        it.n = __builtin_amdgcn_readfirstlane(v0.y);
-        it.T = __builtin_amdgcn_readfirstlane(v0.z);
-        it.pad0 = 0;
-        it.rlo[0] = __builtin_amdgcn_readfirstlane(v1.x);
-        it.rlo[1] = __builtin_amdgcn_readfirstlane(v1.y);
-        it.rlo[2] = __builtin_amdgcn_readfirstlane(v1.z);
-        it.rlo[3] = __builtin_amdgcn_readfirstlane(v1.w);
-        it.rlo[4] = __builtin_amdgcn_readfirstlane(v2.x);
-        it.rn[0] = __builtin_amdgcn_readfirstlane(v2.y);
-        it.rn[1] = __builtin_amdgcn_readfirstlane(v2.z);
-        it.rn[2] = __builtin_amdgcn_readfirstlane(v2.w);
-        it.rn[3] = __builtin_amdgcn_readfirstlane(v3.x);
-        it.rn[4] = __builtin_amdgcn_readfirstlane(v3.y);
-        it.pad1[0] = it.pad1[1] = 0;
-        if (q >= n_items) it.n = 0; // past the end of the queue: an empty unit (every wave sees the same)
-        return it;
+    // Decides what unit `v` is (the next pass of the item of unit v - 1, or the next item of the queue), stages its
+    // window -- candidate k of the concatenated runs -> cluster id, box -- and writes its descriptor.  One wave.
+    auto stage_unit = [&](int v) {
+        const int p = v & 1, ib = v & 3;
+        int a = 0, n = 0, T = 0, wlo = 0, rlo[5], rn[5];
+        bool fetch = true;
+        if (v > 0) { // unit v - 1 sits in the other parity
+            const int *pd = s_desc[p ^ 1];
+            n = __builtin_amdgcn_readfirstlane(pd[1]);
+            T = __builtin_amdgcn_readfirstlane(pd[2]);
+            wlo = __builtin_amdgcn_readfirstlane(pd[3]) + cap;
+            if (n == 0) fetch = false; // the queue has run dry: stays dry
+            else if (wlo < T) {        // next pass of the same item
+                fetch = false;
+                a = __builtin_amdgcn_readfirstlane(pd[0]);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    rlo[r] = __builtin_amdgcn_readfirstlane(pd[4 + r]);
+                    rn[r] = __builtin_amdgcn_readfirstlane(pd[9 + r]);
+                }
+            }
+        }
+        if (fetch) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(&st->n3_queue, 1);
+            q = __builtin_amdgcn_readfirstlane(q);
+            n = 0;
+            wlo = 0;
+            if (q < n_items) {
+                const int4 *pi = reinterpret_cast<const int4 *>(items + q);
+                const int4 v0 = pi[0], v1 = pi[1], v2 = pi[2], v3 = pi[3];
+                a = __builtin_amdgcn_readfirstlane(v0.x);
+                n = __builtin_amdgcn_readfirstlane(v0.y);
+                T = __builtin_amdgcn_readfirstlane(v0.z);
+                rlo[0] = __builtin_amdgcn_readfirstlane(v1.x);
+                rlo[1] = __builtin_amdgcn_readfirstlane(v1.y);
+                rlo[2] = __builtin_amdgcn_readfirstlane(v1.z);
+                rlo[3] = __builtin_amdgcn_readfirstlane(v1.w);
+                rlo[4] = __builtin_amdgcn_readfirstlane(v2.x);
+                rn[0] = __builtin_amdgcn_readfirstlane(v2.y);
+                rn[1] = __builtin_amdgcn_readfirstlane(v2.z);
+                rn[2] = __builtin_amdgcn_readfirstlane(v2.w);
+                rn[3] = __builtin_amdgcn_readfirstlane(v3.x);
+                rn[4] = __builtin_amdgcn_readfirstlane(v3.y);
+            }
+        }
+        if (n > 0) {
+            float4 *box = reinterpret_cast<float4 *>(box0 + p * 8 * (cap + 1));
+            int *jcs = ids0 + ib * (cap + 8);
+            const int nwin = min(T, wlo + cap) - wlo;
+            int woff[5];
+            woff[0] = 0;
+#pragma unroll
+            for (int r = 1; r < 5; ++r) woff[r] = woff[r - 1] + rn[r - 1];
+            for (int k = lane; k < nwin; k += 64) {
+                const int kk = wlo + k;
+                int jc = rlo[0] + kk;
+#pragma unroll
+                for (int r = 1; r < 5; ++r) jc = kk >= woff[r] ? rlo[r] + (kk - woff[r]) : jc;
+                jcs[k] = jc;
+                box[2 * k] = cl_box[2 * jc];
+                box[2 * k + 1] = cl_box[2 * jc + 1];
+            }
+        }
+        if (lane < 16) {
+            int val = 0;
+            if (n > 0) {
+                val = lane == 0 ? a : lane == 1 ? n : lane == 2 ? T : lane == 3 ? wlo : lane == 14 ? ib : 0;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    val = lane == 4 + r ? rlo[r] : val;
+                    val = lane == 9 + r ? rn[r] : val;
+                }
+            }
+            s_desc[p][lane] = val;
+        }
+        wave_lds_sync();
     };
 
-    // ---- unit pipeline: u = units done so far; unit u lives in candidate buffer u & 1
-    int qpos = 0; // ring position of the current item's queue index in s_item
-    N3Item cur = load_item(s_item[0]);
-    int wlo = 0;
-    if (cur.n > 0) stage(cur, 0, 0);
-    __syncthreads();
-    for (int u = 0; cur.n > 0; ++u) {
-        const int buf = u & 1;
-        const float4 *s_box = reinterpret_cast<const float4 *>(cand0 + buf * cand_ints);
-        const int *s_jc = cand0 + buf * cand_ints + 8 * (cap + 1);
-        const int nwin = min(cur.T, wlo + cap) - wlo;
-        const bool last_pass = wlo + cap >= cur.T;
-        // what comes after this unit: the next pass of the same item, or the next item of the queue
-        if (threadIdx.x == 0 && last_pass) s_item[(qpos + 2) % 3] = atomicAdd(&st->n3_queue, 1); // two items ahead
+    // ---- unit pipeline.  No workgroup barrier: a wave that runs out of i-clusters of unit v moves on to unit v + 1
+    // (other window, other buffers); the LAST wave to leave unit v opens the flush of its window and stages unit
+    // v + 2 meanwhile; the flush itself is done, a chunk at a time, by the waves that want to start unit v + 2.
+    if (wave == 0) {
+        stage_unit(0);
+        if (lane == 0) vready[0] = 0;
+        stage_unit(1);
+        if (lane == 0) vready[1] = 1;
+    }
+    for (int v = 0;; ++v) {
+        const int p = v & 1;
+        bool failed = false;
+        for (int spins = 0; vready[p] < v; ++spins) {
+            help_flush(p, v - 2);
+            __builtin_amdgcn_s_sleep(2);
+            if (spins > kN3SpinLimit || *(volatile int *)&ctl.error) {
+                failed = true;
+                break;
+            }
+        }
+        if (failed) {
+            if (lane == 0) {
+                ctl.error = 1;
+                st->nan_seen = 1; // surfaces as a failed evaluation
+            }
+            break;
+        }
+        wave_lds_sync();
+        const int *dd = s_desc[p];
+        const int D_n = __builtin_amdgcn_readfirstlane(dd[1]);
+        if (D_n == 0) { // the queue is dry; unit v - 1 may still need its window flushed
+            for (int spins = 0; v > 0 && vready[p ^ 1] < v + 1 && spins < kN3SpinLimit && !*(volatile int *)&ctl.error; ++spins) {
+                help_flush(p ^ 1, v - 1);
+                __builtin_amdgcn_s_sleep(2);
+            }
+            break;
+        }
+        const int D_a = __builtin_amdgcn_readfirstlane(dd[0]), D_T = __builtin_amdgcn_readfirstlane(dd[2]),
+                  wlo = __builtin_amdgcn_readfirstlane(dd[3]), D_ib = __builtin_amdgcn_readfirstlane(dd[14]);
+        const float4 *s_box = reinterpret_cast<const float4 *>(box0 + p * 8 * (cap + 1));
+        const int *s_jc = ids0 + D_ib * (cap + 8);
+        int *sfx = s_f + p * 3 * fstr, *sfy = sfx + fstr, *sfz = sfy + fstr;
+        const int nwin = min(D_T, wlo + cap) - wlo;
         // ---- compute: grab i-clusters of the item one at a time
-        if (diag & 128) t_mark = __builtin_amdgcn_s_memtime();
         for (;;) {
             int gi = 0;
-            if (lane == 0) gi = atomicAdd(&s_grab[buf], 1);
+            if (lane == 0) gi = atomicAdd(&ctl.grab[p], 1);
             gi = __builtin_amdgcn_readfirstlane(gi);
-            if (gi >= cur.n) break;
-            const int icl = cur.a + gi;
+            if (gi >= D_n) break;
+            const int icl = D_a + gi;
             const float4 lo_i = cl_box[2 * icl], hi_i = cl_box[2 * icl + 1];
             float4 pv = spos4[(size_t)icl * kCl + slot];
             const int own_w = __float_as_int(pv.w);
@@ -341,7 +452,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             float ee = 0.f, eg = 0.f;
             // the i-cluster's own place in the window: candidates before it have lower cluster ids (i-clusters of this
             // item or of an earlier one: they take those pairs); it is itself a candidate (the self tile)
-            const int own_k = (icl - cur.rlo[0]) - wlo;
+            const int own_k = (icl - D_a) - wlo;
             if (own_k < nwin) {
                 const int own_lc = own_k >= 0 ? own_k : -1;
                 const int k0 = max(own_k, 0);
@@ -449,7 +560,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             }
                             const bool self = (jslot >> 3) == own_lc;
                             if (!NOENERGY) {
-                                // self tile: both orders of a pair were swept (weight 1/2), and the r = 0 pair goes out again
+                                // self tile: both orders of a pair were swept (weight 1/2), and the r = 0 pair -- swept with
+                                // the rest -- goes out again in the batch it came in with (its value, eself, is formed by
+                                // the very operations of the loop: what is left of it is the rounding of the up to 7 small
+                                // terms that shared an accumulator with it, ~1e-4 kJ/mol per bead, random in sign)
                                 if (EV) ee = fmaf(self ? eb - eself : eb, self ? 0.5f : 1.f, ee);
                                 if (GAUSS) eg = fmaf(self ? gb + arow[(jslot & 7) * 8 + lj] : gb, self ? 0.5f : 1.f, eg);
                             }
@@ -498,67 +612,26 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 acc_g += (double)wave_sum(eg);
             }
         }
-        // ---- out of i-clusters: stage the next unit into the other candidate buffer
-        if (diag & 128) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            t_cmp += t - t_mark;
-            t_mark = t;
-        }
-        N3Item nxt = cur;
-        int nwlo = wlo + cap, nqpos = qpos;
-        if (last_pass) {
-            nqpos = (qpos + 1) % 3;
-            nxt = load_item(s_item[nqpos]); // written two units ago, behind a barrier
-            nwlo = 0;
-        }
-        if (nxt.n > 0) stage(nxt, nwlo, buf ^ 1);
-        if (diag & 128) {
-            __builtin_amdgcn_s_waitcnt(0);
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            t_stage += t - t_mark;
-            t_mark = t;
-        }
-        __syncthreads(); // every wave is done with the window and with the staging of the next unit
-        if (diag & 128) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            t_bar += t - t_mark;
-            t_mark = t;
-        }
-        // ---- flush the window: fsort[slot] -= sum / 2^13 (the 8 slots of a cluster are contiguous, neighbouring
-        // candidates mostly too: 256-byte atomic wave instructions), and zero it for the next unit
-        for (int e = threadIdx.x; e < ((diag & 32) ? 0 : nwin * 8); e += kN3Threads) {
-            const int vx = sfx[e], vy = sfy[e], vz = sfz[e];
-            if ((vx | vy | vz) != 0) {
-                sfx[e] = 0;
-                sfy[e] = 0;
-                sfz[e] = 0;
-                if (!(diag & 1)) {
-                    const int gs = s_jc[e >> 3] * kCl + (e & 7);
-                    atomicAdd(fsort + gs, unfix * (float)vx);
-                    atomicAdd(fsort + fstride + gs, unfix * (float)vy);
-                    atomicAdd(fsort + 2 * fstride + gs, unfix * (float)vz);
-                }
+        // ---- out of i-clusters: leave the unit; the last wave to do so opens the flush and stages unit v + 2
+        wave_lds_sync();
+        int d = 0;
+        if (lane == 0) d = atomicAdd(&ctl.done[p], 1);
+        d = __builtin_amdgcn_readfirstlane(d);
+        if (d == kN3Waves - 1) {
+            if (lane == 0) {
+                ctl.grab[p] = 0;
+                ctl.done[p] = 0;
+                ctl.fl_nwin[p] = nwin;
+                ctl.fl_ids[p] = D_ib;
+                ctl.fl_total[p] = (nwin * 8 + 255) >> 8;
+                ctl.fl_next[p] = 0;
+                ctl.fl_done[p] = 0;
             }
+            wave_lds_sync();
+            if (lane == 0) vepoch[p] = v; // the job is open
+            stage_unit(v + 2);
+            if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
         }
-        if (threadIdx.x < 8) sfx[cap * 8 + threadIdx.x] = sfy[cap * 8 + threadIdx.x] = sfz[cap * 8 + threadIdx.x] = 0;
-        if (threadIdx.x == 0) s_grab[buf] = 0; // this parity is used again two units from now
-        cur = nxt;
-        wlo = nwlo;
-        qpos = nqpos;
-        if (diag & 128) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            t_flush += t - t_mark;
-            t_mark = t;
-        }
-        __syncthreads();
-        if (diag & 128) t_bar += __builtin_amdgcn_s_memtime() - t_mark;
-    }
-    if ((diag & 128) && dbg && lane == 0) {
-        atomicAdd(dbg + 0, t_cmp);
-        atomicAdd(dbg + 1, t_stage);
-        atomicAdd(dbg + 2, t_bar);
-        atomicAdd(dbg + 3, t_flush);
-        atomicAdd(dbg + 4, 1ull);
     }
     if (lane == 0) {
         s_e[0][wave] = acc_ev;

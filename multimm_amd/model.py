@@ -124,6 +124,7 @@ class MultiMM:
             # the analogue of model.py:862-871's platform fallback, except that there is no CPU platform here
             raise MMXError(e.code, f"MI355X platform unavailable ({e}); choose another PLATFORM in the reference "
                                    "MultiMM to run on OpenMM") from e
+        self.engine.set_option("deterministic", 1.0 if self.args.DETERMINISTIC_FORCES else 0.0)
         self.engine.load_system(self.system)
 
     # --- model.py:859-897 -----------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Half-shell pair kernel (nb_variant bit 4096) against the full-shell kernel (nb_variant 0) and, for small systems,
+"""Half-shell pair kernel (default) against the full-shell kernel (option deterministic) and, for small systems,
 against the fp64 oracle: energies, forces, and timing at the lattice start and after a short relaxation.
 usage: n3_check.py [workload ...]      (run on the GPU box)"""
 import sys
@@ -16,7 +16,7 @@ for name in cases:
             et_ref, F_ref = Oracle(s).eval()
             with engine_for(s) as eng:
                 for v in (0, 4096):
-                    eng.set_option("nb_variant", v)
+                    eng.set_option("deterministic", 0 if v else 1)
                     et, F = eng.compute()
                     de = np.abs(et - et_ref).max() / np.abs(et_ref).sum()
                     df = np.abs(F - F_ref).max() / np.abs(F_ref).max()
@@ -27,11 +27,11 @@ for name in cases:
     eng = engine_for(s)
     for state in ("lattice", "relaxed"):
         if state == "relaxed":
-            eng.set_option("nb_variant", 0)
+            eng.set_option("deterministic", 1)
             eng.minimize(tolerance=0.0, max_iters=300)
         res = {}
         for v in (0, 4096):
-            eng.set_option("nb_variant", v)
+            eng.set_option("deterministic", 0 if v else 1)
             et, F = eng.compute()
             us, _ = eng.time_kernel(K_NONBONDED, 20)
             res[v] = (et, F, us)

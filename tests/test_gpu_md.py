@@ -84,6 +84,7 @@ def test_amd_trajectory_matches_restatement(regime):
     n_steps, dt = 60, 0.01
     v0 = md_velocities(s.n_beads, 310.0, BEAD_MASS_AMU, 3).astype(np.float32)
     with engine_for(s) as eng:
+        eng.set_option("deterministic", 1)   # the Verlet comparison below is bit for bit
         et, _ = eng.compute()
         u0 = float(np.sum(et))
         alpha, e = (2000.0, u0 + 3000.0) if regime == "boosted" else (100.0, u0 - 1e9)
@@ -135,6 +136,7 @@ def test_step_calls_compose_bitwise():
     out = []
     for chunks in ((20,), (7, 13)):
         with engine_for(s) as eng:
+            eng.set_option("deterministic", 1)
             eng.md_configure("langevin", dt_ps=0.005, seed=9)
             eng.set_velocities_to_temperature(310.0, seed=9)
             for c in chunks:
