@@ -181,8 +181,15 @@ int mmx_disable_term(mmx_handle h, int32_t term);
 
 /* ---- tunables that are not part of the physics ------------------------------------------------
  * key                 meaning                                                      default
- * "deterministic"     1: order beads inside cells by id (bitwise reproducible)        1
- * "profile"           k>0: HIP-event time every k-th launch of each kernel slot       0
+ * "deterministic"     0: half-shell pair kernel (every pair once, reaction through LDS and float
+ *                     atomics: results reproducible to rounding, as OpenMM's GPU platforms with
+ *                     DeterministicForces=false); 1: full-shell pair kernel with a fixed summation
+ *                     order (bitwise reproducible runs, ~15 % slower)                 0
+ * "profile"           k>0: HIP-event time the kernel slots of every k-th evaluation of a
+ *                     minimization (every k-th launch of a slot elsewhere)            0
+ * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them
+ *                     per graph, even) instead of launching them one by one; same bits; slower on
+ *                     ROCm 7.2 at every size measured, kept for A/B     0
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0
  * "fused_bonded"      1: backbone + loops + confinement in one pass; 0: the three kernels

@@ -99,8 +99,8 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             h->fstride = (h->n_all + 1) * 8;
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
             h->n3_cap = n3_configure(kN3MaxCap);
-            // an item ends at a row end, at 32 clusters, or at a cell boundary: never more than cells + clusters / 32
-            h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 256 + 64;
+            // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16
+            h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 16 + 64;
             HIPCHK(h, dalloc(&h->n3_items, (size_t)h->n3_max_items));
             h->n_cus = prop.multiProcessorCount;
             HIPCHK(h, dalloc(&h->n3_dbg, (size_t)8));
@@ -219,6 +219,7 @@ int mmx_destroy(mmx_handle h) try {
     if (!h) return MMX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    graph_drop(h);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
@@ -563,6 +564,8 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "nb_variant") h->nb_variant = (int)value;
     else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
     else if (k == "overlap_bonded") h->overlap_bonded = value != 0.0;
+    else if (k == "use_graph") h->use_graph = value != 0.0;
+    else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -576,6 +579,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "nb_variant") *value = h->nb_variant;
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
+    else if (k == "use_graph") *value = h->use_graph;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else if (k.rfind("n3_dbg", 0) == 0 && k.size() == 7 && h->n3_dbg) { // n3_dbg0..7: cycle counters of k_nb_n3 (diagnosis)
         unsigned long long v[8];
@@ -647,18 +651,50 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
+    h->prof_eval = 1; // the first evaluation is a profiling sample when profiling is on
     enqueue_eval(h, PACK_PLAIN, FOLD_MIN);
-    if ((rc = pull_state(h))) return rc;
+    if ((rc = pull_state(h))) {
+        h->prof_eval = -1;
+        return rc;
+    }
     local.e_initial = h->st_host->fx;
+    // Trial evaluations: pairs of them are replayed from a hipGraph (single-GPU runs; option use_graph), except the
+    // every profile-th evaluation, which goes out launch by launch with HIP events around every kernel slot.
+    const bool graphs = h->use_graph && !has_comm(h) && h->world == 1;
+    bool have_graph = false;
+    GraphKey gkey{};
+    long long eval_no = 1;
     while (h->st_host->phase != PH_DONE) {
         int batch = h->poll_interval;
         if (max_iters > 0) batch = std::max(1, std::min(batch, max_iters - h->st_host->iters));
-        for (int b = 0; b < batch; ++b) {
-            enqueue_eval(h, PACK_MOVE, FOLD_MIN);
+        if (graphs && (!have_graph || !(gkey == graph_key(h)))) {
+            gkey = graph_key(h);
+            have_graph = graph_capture(h);
         }
-        if ((rc = pull_state(h))) return rc;
+        for (int b = 0; b < batch;) {
+            const bool s0 = h->profile > 0 && eval_no % h->profile == 0, s1 = h->profile > 0 && (eval_no + 1) % h->profile == 0;
+            bool sampled = false; // a profiling sample inside the span a replay would cover?
+            for (int k = 0; k < h->graph_evals; ++k) sampled = sampled || (h->profile > 0 && (eval_no + k) % h->profile == 0);
+            (void)s1;
+            if (have_graph && !sampled && b + h->graph_evals <= batch && (h->build_idx & 1) == h->gkey_parity && graph_replay(h)) {
+                b += h->graph_evals;
+                eval_no += h->graph_evals;
+                continue;
+            }
+            h->prof_eval = s0 ? 1 : 0;
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN);
+            ++b;
+            ++eval_no;
+        }
+        if ((rc = pull_state(h))) {
+            h->prof_eval = -1;
+            graph_drop(h);
+            return rc;
+        }
         if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
     }
+    h->prof_eval = -1;
+    graph_drop(h);
     HIPCHK(h, hipGetLastError());
     const MinState &s = *h->st_host;
     if (s.status <= MMX_MIN_LS_MIN_STEP && s.evals > 1) {

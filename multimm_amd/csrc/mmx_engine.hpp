@@ -128,8 +128,10 @@ int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
 // ---- profiling helpers ----------------------------------------------------------------------
 bool prof_begin(mmx_handle_s *h, int slot, EventPair &ep) {
     h->launches[slot]++;
-    if (h->profile <= 0) return false;
-    if ((h->launches[slot] - 1) % h->profile != 0) return false;
+    if (h->profile <= 0 || h->capturing) return false;
+    // minimizer: whole evaluations are sampled (every profile-th one; the others may be graph replays); elsewhere
+    // every profile-th launch of the slot
+    if (h->prof_eval >= 0 ? !h->prof_eval : (h->launches[slot] - 1) % h->profile != 0) return false;
     if (h->ev_pool.empty()) return false;
     ep = h->ev_pool.back();
     h->ev_pool.pop_back();
@@ -436,7 +438,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
         }
         if (use_n3(h)) // work items of the half-shell pair kernel: needs the scan's cluster offsets only
-            hipLaunchKernelGGL(k_n3_items, dim3(32), dim3(256), 0, h->stream, cur, h->cstart, h->n3_items, h->n3_cap,
+            hipLaunchKernelGGL(k_n3_items, dim3(256), dim3(256), 0, h->stream, cur, h->cstart, h->n3_items,
                                h->n3_max_items, h->st);
         hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                            h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
@@ -579,6 +581,67 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold) {
         hipLaunchKernelGGL(k_controller_decide, dim3(1), dim3(64), 0, h->stream, h->st);
     }
     prof_end(h, on, ep);
+}
+
+// ---- hipGraph replay of the minimizer's evaluation -------------------------------------------------------------
+// The launch sequence of a trial evaluation is fixed and device-driven (enqueue_eval: what the kernels do is decided by
+// MinState on the device), so TWO consecutive evaluations (the cell grid ping-pongs between two buffers) are captured
+// once per mmx_minimize call and replayed.  The key holds every host-side quantity that shapes the launches; when a
+// poll changes one of them the graph is captured again.
+struct GraphKey {
+    int items, clusters, order_cap, n3, parity;
+    bool operator==(const GraphKey &o) const {
+        return items == o.items && clusters == o.clusters && order_cap == o.order_cap && n3 == o.n3 && parity == o.parity;
+    }
+};
+GraphKey graph_key(const mmx_handle_s *h) {
+    return GraphKey{h->last_items, h->last_clusters, (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640) ? 1 : 0,
+                    use_n3(h) ? 1 : 0, h->build_idx & 1};
+}
+void graph_drop(mmx_handle_s *h) {
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->gexec = nullptr;
+    h->graph = nullptr;
+}
+// Captures two trial evaluations.  Returns false (and leaves the direct path in charge) when the runtime refuses.
+bool graph_capture(mmx_handle_s *h) {
+    graph_drop(h);
+    const int idx0 = h->build_idx;
+    GridParams *const gcur0 = h->gcur;
+    int64_t saved[MMX_N_KERNELS];
+    for (int k = 0; k < MMX_N_KERNELS; ++k) saved[k] = h->launches[k];
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    h->capturing = true;
+    for (int k = 0; k < h->graph_evals; ++k) enqueue_eval(h, PACK_MOVE, FOLD_MIN);
+    h->capturing = false;
+    const hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+    for (int k = 0; k < MMX_N_KERNELS; ++k) { // what one replay adds to the launch counters
+        h->glaunches[k] = h->launches[k] - saved[k];
+        h->launches[k] = saved[k];
+    }
+    h->build_idx = idx0;
+    h->gcur = gcur0;
+    if (e != hipSuccess || !h->graph || hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        graph_drop(h);
+        return false;
+    }
+    h->gkey_parity = idx0 & 1;
+    return true;
+}
+bool graph_replay(mmx_handle_s *h) {
+    if (hipGraphLaunch(h->gexec, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    h->build_idx += h->graph_evals;
+    h->gcur = h->grid + ((h->build_idx - 1) & 1);
+    for (int k = 0; k < MMX_N_KERNELS; ++k) h->launches[k] += h->glaunches[k];
+    return true;
 }
 
 int push_state(mmx_handle_s *h) {

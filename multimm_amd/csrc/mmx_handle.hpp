@@ -198,6 +198,15 @@ struct mmx_handle_s {
     FormParams *formp = nullptr;  // device copy read by the FORMS instances of the pair kernels
     // options
     int deterministic = 0, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
+    // hipGraph of consecutive minimizer evaluations (captured per mmx_minimize call, see graph_capture).  OFF by default:
+    // on ROCm 7.2 / MI355X replaying loses to launch-by-launch submission at every size measured
+    int use_graph = 0, graph_evals = 2; // evaluations per graph (even: the cell grid ping-pongs)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool capturing = false;
+    int gkey_parity = 0;
+    int64_t glaunches[MMX_N_KERNELS]{};
+    int prof_eval = -1; // minimizer: 1 / 0 = this evaluation is / is not a profiling sample; -1 = per-slot sampling
     // profiling
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};

@@ -78,11 +78,17 @@ struct N3Ctl {
 constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gives up (a bug, not a state of the data)
 
 // ---- item builder ---------------------------------------------------------------------------------------------
-// One thread per row of the cell grid walks the row's clusters and cuts them into runs: at most kN3ItemClusters
-// clusters, and spanning more than one cell only while the candidate set of the run still fits the LDS window.
+// One wave per row of the cell grid, lanes = cells of the row.  A cell of >= kN3Dense clusters is cut into equal runs
+// of at most kN3ItemClusters clusters by itself (a run that left a dense cell would drag the candidates of five more
+// cells into its window); the sparse cells between two dense ones (or row ends) form a segment that is cut into runs
+// of kN3ItemClusters clusters from its start, wherever the cell boundaries fall.  Run starts follow from a segmented
+// prefix sum over the lanes, so nothing walks the row sequentially.
+constexpr int kN3Dense = 22; // 19 cells (a run across a cell boundary) of fewer clusters than this still fit one window
+
 struct N3Row {
     const int *cstart;
     int nx, base[5]; // cell index of x = 0 in the five candidate rows (-1: the row does not exist)
+    // candidate runs of i-clusters [a, ...) that live in cells xa..xb of row base[0]; returns T
     __device__ __forceinline__ int T(int a, int xa, int xb, int *rlo, int *rn) const {
         const int x0 = max(xa - 1, 0), x1 = min(xb + 1, nx - 1);
         rlo[0] = a;
@@ -102,86 +108,122 @@ struct N3Row {
     }
 };
 
-template <bool EMIT>
-__device__ __forceinline__ int n3_walk_row(const N3Row &R, int cap, N3Item *__restrict__ out) {
-    const int *cs = R.cstart + R.base[0];
-    const int c_hi = cs[R.nx];
-    int a = cs[0], xa = 0, count = 0;
-    while (a < c_hi) {
-        while (cs[xa + 1] <= a) ++xa; // cell of cluster a
-        int n = min(kN3ItemClusters, c_hi - a);
-        int xb = xa;
-        while (cs[xb + 1] < a + n) ++xb; // cell of the run's last cluster
-        int rlo[5], rn[5];
-        int t = R.T(a, xa, xb, rlo, rn);
-        while (xb > xa && t > cap) { // too many candidates: end the run with the cell before xb
-            n = cs[xb] - a;
-            xb = xa;
-            while (cs[xb + 1] < a + n) ++xb;
-            t = R.T(a, xa, xb, rlo, rn);
-        }
-        if (EMIT) {
-            N3Item it;
-            it.a = a;
-            it.n = n;
-            it.T = t;
-            it.pad0 = 0;
+// Per 64-cell chunk of a row: clusters of my cell, whether it is dense, the segment-relative cluster offset p of
+// its first cluster (sparse cells), and the number of runs that START in it.  carry_p / carry_dense: state at the
+// chunk's left edge (wave-uniform, updated for the next chunk).
+struct N3Cell {
+    int c0, n, p, runs;
+    bool dense;
+};
+__device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart of the row */, int nx, int x, int lane,
+                                          int &carry_p, bool &carry_dense) {
+    N3Cell C;
+    const bool valid = x < nx;
+    C.c0 = valid ? cs[x] : 0;
+    C.n = valid ? cs[x + 1] - C.c0 : 0;
+    C.dense = C.n >= kN3Dense;
+    bool prev_dense = __shfl_up((int)C.dense, 1, 64) != 0;
+    if (lane == 0) prev_dense = carry_dense;
+    // segmented inclusive sum of the sparse cells' cluster counts; a segment starts at a dense cell (which counts 0
+    // itself) and at the cell after one
+    int sum = C.dense ? 0 : C.n;
+    bool head = C.dense || prev_dense;
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                it.rlo[r] = rlo[r];
-                it.rn[r] = rn[r];
-            }
-            it.pad1[0] = it.pad1[1] = 0;
-            out[count] = it;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int s2 = __shfl_up(sum, o, 64);
+        const bool h2 = __shfl_up((int)head, o, 64) != 0;
+        if (lane >= o) {
+            if (!head) sum += s2;
+            head = head || h2;
         }
-        ++count;
-        a += n;
     }
-    return count;
+    if (!head) sum += carry_p; // no segment start at or before this lane inside the chunk
+    C.p = sum - (C.dense ? 0 : C.n);
+    C.runs = 0;
+    if (valid && C.n > 0)
+        C.runs = C.dense ? (C.n + kN3ItemClusters - 1) / kN3ItemClusters
+                         : (C.p + C.n + kN3ItemClusters - 1) / kN3ItemClusters - (C.p + kN3ItemClusters - 1) / kN3ItemClusters;
+    carry_p = __shfl(sum, 63, 64);
+    carry_dense = __shfl((int)C.dense, 63, 64) != 0;
+    return C;
 }
 
 __global__ __launch_bounds__(256) void k_n3_items(const GridParams *__restrict__ grid, const int *__restrict__ cstart,
-                                                  N3Item *__restrict__ items, int cap, int max_items,
-                                                  MinState *__restrict__ st) {
+                                                  N3Item *__restrict__ items, int max_items, MinState *__restrict__ st) {
     if (st->phase == PH_DONE) return;
-    __shared__ int s_w[4], s_base;
     const GridParams G = *grid;
-    const int nrows = G.ny * G.nz;
+    const int nrows = G.ny * G.nz, nx = G.nx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // rows are dealt out in blocks of 256 to the workgroups (usually one round)
-    for (int r0 = blockIdx.x * 256; r0 < nrows; r0 += gridDim.x * 256) {
-        const int row = r0 + threadIdx.x;
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
         N3Row R;
         R.cstart = cstart;
-        R.nx = G.nx;
-        int cnt = 0;
-        if (row < nrows) {
-            const int y = row % G.ny, z = row / G.ny;
-            R.base[0] = row * G.nx;
-            R.base[1] = y + 1 < G.ny ? (row + 1) * G.nx : -1;
+        R.nx = nx;
+        const int y = row % G.ny, z = row / G.ny;
+        R.base[0] = row * nx;
+        R.base[1] = y + 1 < G.ny ? (row + 1) * nx : -1;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-                R.base[3 + dy] = (z + 1 < G.nz && y + dy >= 0 && y + dy < G.ny) ? (row + G.ny + dy) * G.nx : -1;
-            cnt = n3_walk_row<false>(R, cap, nullptr);
-        }
-        // exclusive scan of the counts over the workgroup, then one atomic for the workgroup's slice of the item list
-        int inc = cnt;
+        for (int dy = -1; dy <= 1; ++dy)
+            R.base[3 + dy] = (z + 1 < G.nz && y + dy >= 0 && y + dy < G.ny) ? (row + G.ny + dy) * nx : -1;
+        const int *cs = cstart + R.base[0];
+        const int c_hi = cs[nx];
+        if (c_hi == cs[0]) continue; // empty row
+        // pass 1: runs of the row
+        int total = 0, carry_p = 0;
+        bool carry_dense = true; // the row start opens a segment
+        for (int xc = 0; xc < nx; xc += 64) {
+            const N3Cell C = n3_cell(cs, nx, xc + lane, lane, carry_p, carry_dense);
+            int r = C.runs;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += u;
+            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            total += r;
         }
-        __syncthreads();
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_w[w];
-        if (threadIdx.x == 0) s_base = atomicAdd(&st->n3_items, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
-        __syncthreads();
-        const int first = s_base + woff + inc - cnt;
-        if (row < nrows && cnt > 0) {
-            if (first + cnt <= max_items) n3_walk_row<true>(R, cap, items + first);
-            else st->nan_seen = 1; // cannot happen (the list holds one item per cluster): surface it as a failed evaluation
+        int first = 0;
+        if (lane == 0) first = atomicAdd(&st->n3_items, total);
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (first + total > max_items) { // cannot happen (the list has room for a run per cell plus one per 16 clusters)
+            if (lane == 0) st->nan_seen = 1; // surfaces as a failed evaluation
+            continue;
+        }
+        // pass 2: emit
+        carry_p = 0;
+        carry_dense = true;
+        for (int xc = 0; xc < nx; xc += 64) {
+            const int x = xc + lane;
+            const N3Cell C = n3_cell(cs, nx, x, lane, carry_p, carry_dense);
+            int inc = C.runs; // inclusive scan of the run counts: where my runs go
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += u;
+            }
+            const int chunk_total = __shfl(inc, 63, 64);
+            const int at = first + inc - C.runs;
+            for (int j = 0; j < C.runs; ++j) {
+                int a, n, xb = x;
+                if (C.dense) { // runs of equal length (27 clusters: 14 + 13, not 16 + 11)
+                    a = C.c0 + (int)(((long long)C.n * j) / C.runs);
+                    n = C.c0 + (int)(((long long)C.n * (j + 1)) / C.runs) - a;
+                } else {
+                    const int m0 = (C.p + kN3ItemClusters - 1) / kN3ItemClusters * kN3ItemClusters; // first run start at or after p
+                    a = C.c0 + (m0 - C.p) + j * kN3ItemClusters;
+                    n = min(kN3ItemClusters, c_hi - a);
+                    while (a + n > cs[xb + 1]) { // the run goes on into the next cell, unless that one is dense
+                        if (cs[xb + 2] - cs[xb + 1] >= kN3Dense) {
+                            n = cs[xb + 1] - a;
+                            break;
+                        }
+                        ++xb;
+                    }
+                }
+                N3Item it;
+                it.a = a;
+                it.n = n;
+                it.T = R.T(a, x, xb, it.rlo, it.rn);
+                it.pad0 = 0;
+                it.pad1[0] = it.pad1[1] = 0;
+                items[at + j] = it;
+            }
+            first += chunk_total;
         }
     }
 }
@@ -324,6 +366,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             int q = 0;
             if (lane == 0) q = atomicAdd(&st->n3_queue, 1);
             q = __builtin_amdgcn_readfirstlane(q);
+            // the list is in (roughly) ascending row order; taking it from the far end measured ~5 % faster at 200 000
+            // beads (an item's flush targets its own row and the rows above it: descending order keeps the workgroups
+            // in flight off each other's target rows); diag & 64: ascending, for the A/B
+            if (!(diag & 64) && q < n_items) q = n_items - 1 - q;
             n = 0;
             wlo = 0;
             if (q < n_items) {

@@ -127,6 +127,22 @@ def test_half_shell_kernel_dense_cells_and_overlapping_beads():
     _check(ChromatinSystem(3000, gas, np.array([0, 3000]), labels[:3000], ff=ff), 0.6, "sparse gas", e_atol=0.1)
 
 
+def test_graph_replay_equals_direct_launches_bitwise():
+    """Option use_graph: the trial evaluations of the minimizer replayed from a hipGraph (pairs of evaluations, or 8 at
+    a time) instead of launch by launch -- same kernels, same arguments, same order: the same bits."""
+    s = synthetic_system("gw_200k", n_beads=20000, jitter=0.03, seed=4, **ALL_ON)
+    res = []
+    for use_graph, per_graph in ((0, 2), (1, 2), (1, 8)):
+        with engine_for(s) as eng:
+            eng.set_option("deterministic", 1)
+            eng.set_option("use_graph", use_graph)
+            eng.set_option("graph_evals", per_graph)
+            st = eng.minimize(tolerance=0.0, max_iters=70)
+            res.append((st.iterations, st.evaluations, st.e_final, eng.get_positions()))
+    for r in res[1:]:
+        assert r[:3] == res[0][:3] and np.array_equal(r[3], res[0][3])
+
+
 def test_generic_ev_power():
     for p in (3.0, 4.5):
         _check(synthetic_system("chr1_50k", n_beads=2000, jitter=0.02, EV_POWER=p), 0.6, f"EV_POWER={p}")
