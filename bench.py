@@ -12,8 +12,9 @@ ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collect
 
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
 pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
-"cpu_baseline" = the in-repo fp64 oracle (OpenMM is not installed; kind "port") timed on the host cores
-on a bounded sample of the same workload.  With `--replicas-per-gpu 3` (N = 1) a third object, "replicas_per_gpu",
+"cpu_baseline" = OpenMM's CPU platform when `import openmm` works on the box (probed at run time, kind "openmm"),
+else the in-repo fp64 oracle (kind "port", with the import error recorded) timed on the host cores on a bounded
+sample of the same workload.  With `--replicas-per-gpu 3` (N = 1) a third object, "replicas_per_gpu",
 reports -- outside the timed region and never as part of `value` -- the aggregate rate of three independent replicas
 sharing the GPU (`run_ensemble(..., concurrent=3)`): a single minimization leaves the GPU idle in its latency-bound
 launches.  Off by default: its concurrent kernels would mix into a profile of the default command.
@@ -107,10 +108,28 @@ def replicas_per_gpu_leg(workload: str, n_beads, cutoff: float, device: int, k: 
 
 
 def cpu_baseline(system, budget_s: float) -> dict | None:
-    """fp64 oracle (same cell list, same L-BFGS rule) on all host cores, bounded sample."""
+    """CPU baseline on this box's host cores, bounded sample.  North star: OpenMM's CPU platform -- probed at run time
+    (oracle/openmm_probe.py): when ``import openmm`` works, the same System (built by this repo's host code) is
+    minimized by LocalEnergyMinimizer with the same cutoff (kind "openmm"), plus NoCutoff as the reference runs it on a
+    20 000-bead sample of the workload; otherwise (this image) the import error is recorded and the in-repo fp64
+    C+OpenMP oracle with the same cell list and L-BFGS rule is timed (kind "port")."""
     if budget_s <= 0:
         return None
+    from oracle.openmm_probe import probe, openmm_minimize
     from oracle.oracle import Oracle, max_threads
+    cores = max_threads()
+    mm, why = probe()
+    if mm is not None:
+        from multimm_amd import synthetic_system
+        one = openmm_minimize(system, 1, "CPU", cores)           # sizes the sample
+        iters = int(max(1, min(50, budget_s / max(one["seconds"], 1e-3))))
+        res = openmm_minimize(system, iters, "CPU", cores)
+        small = synthetic_system(system.name.split("@")[0], n_beads=20000, NB_CUTOFF=0.0)
+        nocut = openmm_minimize(small, 3, "CPU", cores)
+        return {"value": res["iters_per_s"], "unit": "iters/s", "cores": cores, "kind": "openmm",
+                "sample": f"{iters} LocalEnergyMinimizer iterations ({res['seconds']:.1f} s) of the same {system.n_beads}-bead "
+                          f"system on OpenMM's CPU platform, CutoffNonPeriodic at {system.ff.NB_CUTOFF} nm; {why}",
+                "nocutoff_20k_iters_per_s": nocut["iters_per_s"]}
     orc = Oracle(system)
     t0 = time.perf_counter()
     orc.eval()
@@ -120,11 +139,11 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
     _, st = orc.minimize(tolerance=0.0, max_iters=iters)
     dt = time.perf_counter() - t0
     return {
-        "value": st.iterations / dt, "unit": "iters/s", "cores": max_threads(), "kind": "port",
+        "value": st.iterations / dt, "unit": "iters/s", "cores": cores, "kind": "port",
         "sample": f"{st.iterations} L-BFGS iterations ({st.evaluations} evaluations, {dt:.1f} s) of the same "
-                  f"{system.n_beads}-bead system from the same start, fp64 C+OpenMP oracle with the same cutoff "
-                  f"(OpenMM not installed on this box)",
+                  f"{system.n_beads}-bead system from the same start, fp64 C+OpenMP oracle with the same cutoff",
         "evals_per_s": st.evaluations / dt,
+        "openmm": {"available": False, "probe": why},
     }
 
 
@@ -212,19 +231,26 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))["bytes_per_launch"]
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_nb_clusters_j" if args.cutoff > 0 else "k_nb_allpairs",
+            det = bool(eng.get_option("deterministic"))
+            kname = "k_nb_allpairs" if args.cutoff <= 0 else ("k_nb_clusters_j" if (det or dd) else "k_nb_n3")
+            roofline = {"bound": "hbm", "kernel": kname,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "launch_us": nb_us,
-                        "samples": int(st.kernel_samples[K_NONBONDED])}
+                        "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc pass (profiles/nb_traffic.json)"
+                        if traffic is not None and args.nb_traffic_bytes is None else "command line" if traffic is not None else None,
+                        "launch_us": nb_us, "samples": int(st.kernel_samples[K_NONBONDED]),
+                        "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md section 5): see valu_view"}
             if census:
-                pairs = census["pairs_within_cutoff"]  # directed pairs (each pair visited from both ends)
+                directed = census["pairs_within_cutoff"]     # the census walks every bead's full shell
+                pairs = directed / 2.0                        # unique pairs: what the physics needs evaluated
                 tf = pairs * FLOP_PER_PAIR / (nb_us * 1e-6) / 1e12
                 roofline["valu_view"] = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": tf / VALU_PEAK_TFLOPS, "pairs_within_cutoff": pairs,
-                                         "pair_candidates": census["pair_candidates"]}
+                                         "frac": tf / VALU_PEAK_TFLOPS, "unique_pairs_within_cutoff": pairs,
+                                         "pair_candidates": census["pair_candidates"],
+                                         "flop_per_pair": FLOP_PER_PAIR}
                 if n == 200000:  # issue-slot occupancy of the same kernel from the committed PMC pass
                     try:
-                        roofline["valu_view"]["issue"] = json.load(open(os.path.join(ROOT, "profiles", "nb_valu.json")))
+                        roofline["valu_view"]["issue_from_committed_profile"] = json.load(
+                            open(os.path.join(ROOT, "profiles", "nb_valu.json")))
                     except Exception:
                         pass
         kern = {k: v for k, v in d["kernel_us_mean"].items() if v}

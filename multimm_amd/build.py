@@ -22,11 +22,34 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: libmmx.so cannot be built (ROCm toolchain required)")
 
 
+STAMP = LIB + ".stamp"
+
+
+def source_stamp() -> str:
+    """Hash of everything the library is built from (csrc/, include/mmx.h, this recipe) plus the compiler's version:
+    the library on disk is current iff the stamp written beside it matches -- file times do not survive a copy to
+    another machine, content does."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(DEPS) + [os.path.abspath(__file__)]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    try:
+        ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout
+    except Exception:
+        ver = "no hipcc"
+    h.update(ver.encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    try:
+        return open(STAMP).read().strip() != source_stamp()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -44,6 +67,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(source_stamp() + "\n")
     return LIB
 
 

@@ -51,6 +51,9 @@ def parse_bool(text: Any) -> bool:
     raise ValueError(f"cannot parse boolean {text!r}")
 
 
+NOCUTOFF_MAX_BEADS = 50000   # exact NoCutoff up to here when the ini gives no NB_CUTOFF (789 iterations/s at 50 000 beads)
+
+
 @dataclass
 class SimulationConfig:
     """Subset of the reference's SimulationConfig that the minimizer path reads."""
@@ -60,6 +63,7 @@ class SimulationConfig:
     # engine-only key, named after the OpenMM platform property ("DeterministicForces", false by default there too):
     # True selects the full-shell pair kernel, whose summation order is fixed (bitwise reproducible runs)
     DETERMINISTIC_FORCES: bool = False
+    NB_CUTOFF_AUTO: bool = False   # set by load_config: the ini did not name NB_CUTOFF (see there)
     MODELLING_LEVEL: str = ""
     N_BEADS: int = 50000
     OUT_PATH: str = "results"
@@ -171,4 +175,10 @@ def load_config(path_or_dict) -> SimulationConfig:
                 setattr(cfg, key, sval if sval is None else str(sval))
     cfg.ff = dataclasses.replace(cfg.ff, **ffkw)
     cfg.apply_modelling_level()
+    # NB_CUTOFF not given (every ini written for the reference): follow the reference -- OpenMM NoCutoff, every pair
+    # (model.py:181-217 never sets a cutoff) -- as long as the exact all-pairs kernel is cheap; above 50 000 beads the
+    # cell-list kernels with plain truncation at 0.6 nm take over, and MultiMM.add_forcefield says so in the log.
+    cfg.NB_CUTOFF_AUTO = "NB_CUTOFF" not in raw
+    if cfg.NB_CUTOFF_AUTO:
+        cfg.ff = dataclasses.replace(cfg.ff, NB_CUTOFF=0.0 if int(cfg.N_BEADS) <= NOCUTOFF_MAX_BEADS else 0.6)
     return cfg

@@ -702,6 +702,11 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
         const int g4 = std::min((h->n4 + 255) / 256, 1024);
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->xp, (float4 *)h->x);
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->gp, (float4 *)h->g);
+        if (h->world > 1) { // every rank reverted its own slice: what the others hold of it (pos4) is the rejected trial point
+            hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, h->own_lo,
+                               h->x, h->labels, h->pos4);
+            if (has_comm(h)) coll_allgather_pos4(h);
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     prof_collect(h, &local);
@@ -821,8 +826,18 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     int rc = prepare(h);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
+    // The forces of the current positions are cached between calls (md_forces_valid), and so must be their potential
+    // energy: the aMD integrator reads it (st->ftrial) in the first pack of this call, before any evaluation.
+    const bool keep = h->md_forces_valid;
+    const double ftrial_prev = h->st_host->ftrial;
+    double eterms_prev[9];
+    for (int t = 0; t < 9; ++t) eterms_prev[t] = h->st_host->eterms[t];
     std::memset(h->st_host, 0, sizeof(MinState));
     h->st_host->phase = PH_IDLE;
+    if (keep) {
+        h->st_host->ftrial = ftrial_prev;
+        for (int t = 0; t < 9; ++t) h->st_host->eterms[t] = eterms_prev[t];
+    }
     if ((rc = push_state(h))) return rc;
     if (!h->md_forces_valid) {
         // positions / parameters changed: low-order position bits restart at zero, forces are recomputed
@@ -926,6 +941,7 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
                 case 3: launch_nb_cells_p<3>(h, gn); break;
                 default: launch_nb_cells_p<0>(h, gn); break;
                 }
+                launch_nb_finish(h);
             }
             bytes = 32.0 * h->n;
             break;

@@ -199,6 +199,12 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     else if (P.use_ev) N3(true, false);
     else N3(false, true);
 #undef N3
+}
+
+// What has to follow the half-shell kernel: forces from cluster-slot order into the gradient (outside the "nonbonded"
+// timing bracket of enqueue_eval, so that the slot's HIP-event time is the pair kernel's own, as rocprofv3 reports it).
+void launch_nb_finish(mmx_handle_s *h) {
+    if (!use_n3(h)) return;
     const int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     const int gu = std::max(64, std::min((cl * 8 + 255) / 256, 2048));
     hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->spos4, h->fsort, h->fstride, h->g, h->st);
@@ -299,6 +305,15 @@ __global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const f
         pos4[i] = make_float4(3e18f, 3e18f, 3e18f, __int_as_float(-8 + 2)); // padding of the last slice
 }
 
+// pos4 of the owned beads from x, whatever the minimizer's phase (after a reverted line search: the state is DONE)
+__global__ __launch_bounds__(256) void k_repack_own(int n_own, int own_lo, const float *__restrict__ x,
+                                                    const int8_t *__restrict__ labels, float4 *__restrict__ pos4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_own) return;
+    const int bead = own_lo + i;
+    pos4[bead] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], __int_as_float((bead << 3) | ((int)labels[bead] + 2)));
+}
+
 enum PackMode { PACK_PLAIN = 0, PACK_MOVE = 1, PACK_MD = 2 };
 
 DirArgs dir_args(const mmx_handle_s *h) { return DirArgs{h->g, h->gp, h->S, h->Y, (size_t)h->n4 * 4}; }
@@ -335,11 +350,19 @@ bool local_end(mmx_handle_s *h, int p) {
     return true;
 }
 
+// Every RCCL call's result is kept: a failed collective leaves stale ghosts or unreduced sums behind, so the next
+// poll (pull_state) returns MMX_ERR_RCCL instead of carrying on to a wrong result.
+void rccl_check(mmx_handle_s *h, ncclResult_t r, const char *what) {
+    if (r == ncclSuccess || h->coll_failed) return;
+    h->coll_failed = true;
+    h->coll_error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+}
+
 // In-place all-gather of the position slices (ghost beads of every term).
 void coll_allgather_pos4(mmx_handle_s *h) {
     if (h->comm) {
-        (void)g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat, h->comm,
-                               h->stream);
+        rccl_check(h, g_rccl.AllGather(h->pos4 + (size_t)h->rank * h->slice, h->pos4, (size_t)h->slice * 4, ncclFloat,
+                                       h->comm, h->stream), "ncclAllGather");
     } else if (h->lcomm && !h->coll_failed) {
         LocalComm &L = *h->lcomm;
         int p;
@@ -355,7 +378,7 @@ void coll_allgather_pos4(mmx_handle_s *h) {
 // In-place fp64 sum of `count` (<= 64) doubles over the ranks.
 void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
     if (h->comm) {
-        (void)g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, h->stream);
+        rccl_check(h, g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, h->stream), "ncclAllReduce");
     } else if (h->lcomm && !h->coll_failed) {
         LocalComm &L = *h->lcomm;
         const int p0 = (int)(h->coll_seq & 1);
@@ -551,6 +574,7 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold) {
         A.nblk[P_EV] = A.nblk[P_GAUSS] = gn;
     }
     prof_end(h, on, ep);
+    if (has_nb(h) && !all_pairs(h)) launch_nb_finish(h);
     if (fold == FOLD_NONE) return;
 
     const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
@@ -654,7 +678,15 @@ int pull_state(mmx_handle_s *h) {
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
     if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
     if (h->st_host->max_per_cell > 0) h->last_max_per_cell = h->st_host->max_per_cell;
-    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, "loopback collective timed out: every rank of the group must make the same call from its own thread");
+    if (h->comm && g_rccl.CommGetAsyncError && !h->coll_failed) { // errors RCCL found after the call returned
+        ncclResult_t ar = ncclSuccess;
+        if (g_rccl.CommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+            rccl_check(h, ar, "asynchronous RCCL error");
+    }
+    if (h->coll_failed)
+        return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error
+                                         : "loopback collective timed out: every rank of the group must make the same "
+                                           "call from its own thread");
     return MMX_OK;
 }
 

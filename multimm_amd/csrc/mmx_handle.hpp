@@ -51,6 +51,11 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
 };
 static RcclApi g_rccl;
 static bool load_rccl(std::string &err) {
@@ -76,7 +81,12 @@ static bool load_rccl(std::string &err) {
     RSYM(AllGather, "ncclAllGather");
     RSYM(AllReduce, "ncclAllReduce");
     RSYM(GetErrorString, "ncclGetErrorString");
+    RSYM(Send, "ncclSend");
+    RSYM(Recv, "ncclRecv");
+    RSYM(GroupStart, "ncclGroupStart");
+    RSYM(GroupEnd, "ncclGroupEnd");
 #undef RSYM
+    g_rccl.CommGetAsyncError = (decltype(g_rccl.CommGetAsyncError))dlsym(lib, "ncclCommGetAsyncError");
     g_rccl.lib = lib;
     return true;
 }
@@ -127,6 +137,7 @@ struct mmx_handle_s {
     std::shared_ptr<LocalComm> lcomm; // in-process loopback communicator (tests on one GPU)
     unsigned long long coll_seq = 0;  // collectives issued so far (parity selects the event / mailbox set)
     bool coll_failed = false;
+    std::string coll_error;           // what failed (RCCL error string); empty: loopback time-out
     double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
     float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
     bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation

@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 
 from . import cif
-from .config import SimulationConfig, load_config
+from .config import NOCUTOFF_MAX_BEADS, SimulationConfig, load_config
 from .engine import Engine, MMXError
 from .hilbert import hilbert_points
 from .system import ChromatinSystem, chrom_strength_per_bead, set_radiuses, synthetic_system
@@ -125,6 +125,17 @@ class MultiMM:
             raise MMXError(e.code, f"MI355X platform unavailable ({e}); choose another PLATFORM in the reference "
                                    "MultiMM to run on OpenMM") from e
         self.engine.set_option("deterministic", 1.0 if self.args.DETERMINISTIC_FORCES else 0.0)
+        rc = float(self.system.ff.NB_CUTOFF)
+        if rc > 0.0:
+            # measured on one MI355X, scripts/cutoff_tolerance.py / tests/test_gpu_cutoff.py
+            logger.warning("Pair terms are truncated at NB_CUTOFF = %.3g nm%s; the reference evaluates every pair (OpenMM "
+                           "NoCutoff).  Measured against NoCutoff at 50 000 beads: total energy -0.4 kJ/mol per bead "
+                           "(2.5e-3 of it), forces within 2.3 kJ/mol/nm per component (6e-4 relative L2; the convergence "
+                           "tolerance is 10), converged structures agree in R_g to 1.5 %% and in energy to 1.5 %%.  "
+                           "Set NB_CUTOFF = 0 in the ini for the exact all-pairs kernel.", rc,
+                           " (chosen automatically above %d beads)" % NOCUTOFF_MAX_BEADS if self.args.NB_CUTOFF_AUTO else "")
+        else:
+            logger.info("Pair terms: every pair, no cutoff (the reference's OpenMM NoCutoff semantics)")
         self.engine.load_system(self.system)
 
     # --- model.py:859-897 -----------------------------------------------------------------------------

@@ -43,9 +43,6 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(MMXError) as ei:
         Engine(100)
     assert ei.value.code == -2
-    src = "".join(open(os.path.join(ROOT, "multimm_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "multimm_amd"))
-                  if f.endswith(".py"))
-    assert "oracle" not in src.replace("the oracle", "").replace("through the oracle", "").lower() or True
 
 
 def test_product_package_never_imports_oracle():

@@ -130,6 +130,25 @@ def test_md_with_exact_all_pairs_forces():
     assert abs(st.kinetic - sr.kinetic) <= 1e-4 * sr.kinetic
 
 
+def test_amd_step_calls_compose_bitwise():
+    """aMD reads the potential energy of the current positions in the first step of a call; the forces (and that energy)
+    are cached between calls: step(30) + step(30) must be step(60), also in the boosted regime where the energy
+    decides the force scale (run_md() calls md_step in chunks of the sampling interval, model.py:907-995)."""
+    s = _relaxed(n=3000, iters=100)
+    out = []
+    for chunks in ((60,), (30, 30), (1, 59)):
+        with engine_for(s) as eng:
+            eng.set_option("deterministic", 1)
+            et, _ = eng.compute()
+            eng.md_configure("amd", dt_ps=0.01, amd_alpha=2000.0, amd_e=float(np.sum(et)) + 3000.0)
+            eng.set_velocities_to_temperature(310.0, seed=5)
+            for c in chunks:
+                st = eng.md_step(c)
+            out.append((eng.get_positions(), eng.get_velocities(), st.potential, st.step_count))
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1]) and o[2:] == out[0][2:]
+
+
 def test_step_calls_compose_bitwise():
     """step(20) == step(7) + step(13): the step counter indexes the noise, forces are cached between calls."""
     s = _relaxed(n=3000, iters=100)

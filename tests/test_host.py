@@ -168,3 +168,15 @@ def test_initial_structure_types():
     assert r.max() <= 1.0 and abs(r.mean() - 0.75) < 0.01 and np.abs(ball.mean(axis=0)).max() < 0.02  # uniform in the ball
     with pytest.raises(ValueError, match="Invalid option for initial structure: 'zigzag'"):
         compute_init_struct(10, "zigzag")
+
+
+def test_ini_without_nb_cutoff_follows_the_reference(tmp_path):
+    """An ini written for the reference (no NB_CUTOFF key) runs NoCutoff up to 50 000 beads; above, the truncation is
+    chosen and logged."""
+    from multimm_amd.config import load_config
+    assert load_config(dict(PLATFORM="MI355X", N_BEADS=5000)).ff.NB_CUTOFF == 0.0
+    assert load_config(dict(PLATFORM="MI355X", N_BEADS=50000)).ff.NB_CUTOFF == 0.0
+    big = load_config(dict(PLATFORM="MI355X", N_BEADS=200000))
+    assert big.ff.NB_CUTOFF == 0.6 and big.NB_CUTOFF_AUTO
+    assert load_config(dict(PLATFORM="MI355X", N_BEADS=200000, NB_CUTOFF=0)).ff.NB_CUTOFF == 0.0
+    assert load_config(dict(PLATFORM="MI355X", MODELLING_LEVEL="GW")).ff.NB_CUTOFF == 0.6
