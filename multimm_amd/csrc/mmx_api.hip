@@ -223,7 +223,9 @@ int mmx_destroy(mmx_handle h) try {
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
-                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->n3_dbg})
+                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->n3_dbg, (void *)h->dd_boxes,
+                    (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
+                    (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref})
         if (p) (void)hipFree(p);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
@@ -277,6 +279,12 @@ int mmx_get_positions(mmx_handle h, float *xyz) try {
     // the owned slice is taken from the L-BFGS point itself
     int rc = prepare(h);
     if (rc) return rc;
+    if (has_comm(h)) { // a collective: every rank calls it (between calls a rank only holds its own beads and its halo)
+        hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+                           h->labels, h->pos4);
+        coll_allgather_pos4(h);
+        h->dd_lists_valid = false;
+    }
     std::vector<float4> p4((size_t)h->n);
     HIPCHK(h, hipMemcpyAsync(p4.data(), h->pos4, sizeof(float4) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -382,6 +390,16 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
             er0[q] = r0[l];
         }
     }
+    // decomposed runs: the owner of a loop end always needs the other end (static part of the ghost lists)
+    h->dd_loop_mask.assign((size_t)std::max(h->n_own, 1), 0ull);
+    if (h->world > 1 && h->world <= kDDMaxWorld)
+        for (int l = 0; l < n_loops; ++l) {
+            const int rm = m[l] / h->slice, rn = n[l] / h->slice;
+            if (rm == rn) continue;
+            if (rm == h->rank) h->dd_loop_mask[m[l] - h->own_lo] |= 1ull << rn;
+            if (rn == h->rank) h->dd_loop_mask[n[l] - h->own_lo] |= 1ull << rm;
+        }
+    h->dd_static_dirty = true;
     for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0, (void *)h->lstart})
         if (p) (void)hipFree(p);
     h->row_bead = h->row_start = h->partner = h->lstart = nullptr;
@@ -544,7 +562,7 @@ int mmx_disable_term(mmx_handle h, int32_t term) try {
     case MMX_T_GAUSS: h->has_cob = h->has_scb = false; h->P.use_gauss = 0; break;
     case MMX_T_BOND: h->P.use_bond = 0; break;
     case MMX_T_ANGLE: h->P.use_angle = 0; break;
-    case MMX_T_LOOP: h->n_rows = 0; h->n_loops = 0; break;
+    case MMX_T_LOOP: h->n_rows = 0; h->n_loops = 0; h->dd_loop_mask.clear(); h->dd_static_dirty = true; break;
     case MMX_T_CONTAINER: h->P.use_container = 0; break;
     case MMX_T_LAMINA: h->P.use_lamina = 0; break;
     case MMX_T_CENTRAL: h->P.use_central = 0; break;
@@ -565,6 +583,11 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
     else if (k == "overlap_bonded") h->overlap_bonded = value != 0.0;
     else if (k == "use_graph") h->use_graph = value != 0.0;
+    else if (k == "dd_halo") h->dd_halo = value != 0.0;
+    else if (k == "dd_skin") {
+        if (!(value > 0.0)) return fail(h, MMX_ERR_BAD_ARG, "dd_skin must be positive");
+        h->dd_skin = h->dd_skin_cur = (float)value;
+    }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
@@ -580,6 +603,13 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "use_graph") *value = h->use_graph;
+    else if (k == "dd_halo") *value = h->dd_halo;
+    else if (k == "dd_skin") *value = h->dd_skin;
+    else if (k == "dd_skin_now") *value = h->dd_skin_cur;
+    else if (k == "dd_ghosts") *value = h->dd_nghost;                       // read-only statistics of a decomposed run
+    else if (k == "dd_redecompositions") *value = (double)h->dd_redecompositions;
+    else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
+    else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else if (k.rfind("n3_dbg", 0) == 0 && k.size() == 7 && h->n3_dbg) { // n3_dbg0..7: cycle counters of k_nb_n3 (diagnosis)
         unsigned long long v[8];
@@ -651,6 +681,8 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
+    h->dd_skin_cur = std::max(h->dd_skin_cur, h->dd_skin);
+    h->dd_last_rebuild_eval = 0;
     h->prof_eval = 1; // the first evaluation is a profiling sample when profiling is on
     enqueue_eval(h, PACK_PLAIN, FOLD_MIN);
     if ((rc = pull_state(h))) {
@@ -690,6 +722,31 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             h->prof_eval = -1;
             graph_drop(h);
             return rc;
+        }
+        while (h->st_host->phase == PH_HALT) {
+            // decomposed run: an evaluation found the ghost lists out of date and decided nothing.  New lists at the
+            // trial point (the pack of the repeated evaluation writes it again), then the evaluation itself.
+            h->st_host->phase = h->st_host->halt_phase;
+            h->st_host->dd_stale = 0;
+            // early in a minimization beads move fast: a skin that lasted fewer than 8 evaluations is doubled (more
+            // ghosts per exchange, fewer host round trips); the poll loop below halves it again when things calm down
+            if (h->st_host->evals - h->dd_last_rebuild_eval < 8) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 1.6f);
+            h->dd_last_rebuild_eval = h->st_host->evals;
+            if ((rc = push_state(h))) return rc;
+            h->prof_eval = 0;
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN, true);
+            if (h->dd_rc != MMX_OK) return h->dd_rc;
+            if ((rc = pull_state(h))) return rc;
+        }
+        if (use_halo(h) && h->dd_skin_cur > h->dd_skin && h->st_host->evals - h->dd_last_rebuild_eval >= 128 &&
+            h->st_host->phase != PH_DONE) {
+            // 128 evaluations without a stale list: try half the skin (the lists are rebuilt by the next evaluation)
+            h->dd_skin_cur = std::max(h->dd_skin, 0.5f * h->dd_skin_cur);
+            h->dd_last_rebuild_eval = h->st_host->evals;
+            h->prof_eval = 0;
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN, true);
+            if (h->dd_rc != MMX_OK) return h->dd_rc;
+            if ((rc = pull_state(h))) return rc;
         }
         if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
     }
@@ -852,11 +909,20 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         // aMD reads the potential energy of the current positions at every step
         const bool report = h->md_kind == MD_AMD || s + 1 == n_steps || (s + 1) % poll_every == 0;
         h->nb_skip_energy = !report;
-        enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE);
+        // decomposed runs: new ghost lists at the first step of a call that has none and after every poll (a bead moves
+        // ~1e-5 nm per step: the skin outlasts the poll interval by orders of magnitude; checked below all the same)
+        const bool redecomp = use_halo(h) && (!h->dd_lists_valid || (s > 0 && s % poll_every == 0));
+        enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE, redecomp);
         h->nb_skip_energy = false;
         h->md_step++;
+        if (h->dd_rc != MMX_OK) return h->dd_rc;
         if ((s + 1) % poll_every == 0) { // bound the queue depth; learn the cluster count
             if ((rc = pull_state(h))) return rc;
+            if (h->st_host->sums[12] > 0.5) { // all-reduced: every rank sees it
+                h->md_forces_valid = false;
+                return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two "
+                                              "re-decompositions: step too large for the decomposed run");
+            }
             const double f = h->st_host->ftrial;
             if (!(f - f == 0.0)) {
                 h->md_forces_valid = false;
@@ -872,6 +938,10 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     hipLaunchKernelGGL(k_md_kinetic_fold, dim3(1), dim3(256), 0, h->stream, gk, h->ke_part, h->ke_out);
     if (has_comm(h)) coll_allreduce(h, h->ke_out, 1);
     if ((rc = pull_state(h))) return rc;
+    if (h->st_host->sums[12] > 0.5) {
+        h->md_forces_valid = false;
+        return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two re-decompositions");
+    }
     double ke = 0.0;
     HIPCHK(h, hipMemcpy(&ke, h->ke_out, sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(h, hipGetLastError());

@@ -128,7 +128,7 @@ __device__ __forceinline__ void backbone_bead(const FFParams &P, const float4 *_
 __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4 *__restrict__ pos4,
                                                   const uint8_t *__restrict__ flags, float *__restrict__ g,
                                                   double *__restrict__ part, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double eb = 0.0, ea = 0.0;
     for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
                                                const int *__restrict__ partner, const float *__restrict__ r0,
                                                float *__restrict__ g, double *__restrict__ part,
                                                const MinState *__restrict__ st, const int loop_form) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double e = 0.0;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
                                                  const float *__restrict__ cf_w, float *__restrict__ g,
                                                  double *__restrict__ part, const MinState *__restrict__ st,
                                                  const int lam_form, const int cf_form) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double ec = 0.0, el = 0.0, ef = 0.0;
     const bool any = P.use_container | P.use_lamina | P.use_central;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_bonded_fused(const FFParams P, const fl
                                                       const float *__restrict__ cf_w, float *__restrict__ g,
                                                       double *__restrict__ part, const MinState *__restrict__ st,
                                                       const int loop_form, const int lam_form, const int cf_form) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     bonded_fused_block<256>(P, pos4, flags, lstart, partner, r0, cf_w, g, part, loop_form, lam_form, cf_form,
                             (int)blockIdx.x, (int)gridDim.x, s_w);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_scan_bonded(const ScanArgs a, MinState
                                                       const float *__restrict__ cf_w, float *__restrict__ g,
                                                       double *__restrict__ part, const int loop_form,
                                                       const int lam_form, const int cf_form, const int nvb) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0) {
         cell_scan_block<CHUNK>(a, st);
         return;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_chb(const FFParams P, const float4 *__r
                                              const int *__restrict__ chrom_of, const int *__restrict__ chrom_lo,
                                              const int *__restrict__ chrom_hi, float *__restrict__ g,
                                              double *__restrict__ part, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float4 s_tile[256];
     __shared__ int s_chr[256];
     __shared__ double s_w[4];

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__re
                                               const GridParams *__restrict__ grid = nullptr,
                                               int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
                                               int *__restrict__ count = nullptr, const DirArgs D = DirArgs{}) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float s_bb[6][4];
     __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
@@ -194,7 +194,7 @@ __device__ __forceinline__ GridParams grid_from_parts(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_grid_init(const float *__restrict__ bbox_part, int nblk, float hmin,
                                                    int maxcells, float expand, GridParams *__restrict__ grid,
                                                    const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float s_red[6 * 4];
     const GridParams G = grid_from_parts<256>(bbox_part, nblk, hmin, maxcells, s_red, expand);
     if (threadIdx.x == 0) *grid = G;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
                                                     const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                     int *__restrict__ rank, int *__restrict__ count,
                                                     const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     const GridParams G = *grid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool todo = i < n_all;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
 }
 template <int CHUNK>
 __global__ __launch_bounds__(1024) void k_cell_scan(const ScanArgs a, MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     cell_scan_block<CHUNK>(a, st);
 }
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
                                                    int *__restrict__ perm, unsigned long long *__restrict__ okeys,
                                                    const float4 *__restrict__ pos4, const GridParams *__restrict__ grid,
                                                    int own_lo, int n_own, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_all) return;
     const int c = cell_of[i];
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
                                                     const int *__restrict__ biglist, const float scale,
                                                     MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;

@@ -26,7 +26,9 @@ enum PartSlot {
 };
 
 // Minimizer phases (device-side state machine, one transition per evaluation).
-enum Phase { PH_IDLE = 0, PH_INIT = 1, PH_LINESEARCH = 2, PH_DONE = 3 };
+// PH_HALT (decomposed runs): an evaluation found the ghost lists out of date; nothing was decided, every kernel of the
+// evaluations still in the stream returns at once (phase >= PH_DONE), the host rebuilds the lists and repeats it.
+enum Phase { PH_IDLE = 0, PH_INIT = 1, PH_LINESEARCH = 2, PH_DONE = 3, PH_HALT = 4 };
 
 struct GridParams {
     float ox, oy, oz; // origin (bbox min)
@@ -91,6 +93,8 @@ struct MinState {
     int n_big;           // cells of > 64 beads in the last cell build (sorted by a whole block each)
     int n3_items;        // work items of the half-shell pair kernel (k_n3_items, after every cell scan)
     int n3_queue;        // ... and the head of their queue (persistent workgroups pull from it)
+    int dd_stale;        // decomposed runs: an owned bead has moved more than half the skin since the ghost lists were built
+    int halt_phase;      // phase to return to after PH_HALT
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;

@@ -390,12 +390,132 @@ void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
     }
 }
 
+// ---- ghost-bead halo (mmx_dd.hpp) -------------------------------------------------------------------------------
+bool use_halo(const mmx_handle_s *h) { return h->dd_halo && has_comm(h) && h->world > 1; }
+
+// In-place all-gather of `bytes` per rank at buf + rank * bytes; `peer(q)` = the same buffer of rank q's handle
+// (loopback communicator only).
+template <class Peer>
+void coll_allgather_small(mmx_handle_s *h, void *buf, size_t bytes, Peer peer) {
+    if (h->comm) {
+        rccl_check(h, g_rccl.AllGather((const char *)buf + (size_t)h->rank * bytes, buf, bytes, ncclChar, h->comm, h->stream),
+                   "ncclAllGather");
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        for (int q = 0; q < L.world; ++q)
+            if (q != h->rank)
+                (void)hipMemcpyAsync((char *)buf + (size_t)q * bytes, (const char *)peer(L.h[q]) + (size_t)q * bytes, bytes,
+                                     hipMemcpyDeviceToDevice, h->stream);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+}
+
+// The halo exchange of one evaluation: exactly the listed entries, one message per pair of ranks that share any.
+void coll_halo_exchange(mmx_handle_s *h) {
+    const size_t S = (size_t)h->slice;
+    if (h->comm) {
+        rccl_check(h, g_rccl.GroupStart(), "ncclGroupStart");
+        for (int q = 0; q < h->world; ++q) {
+            if (q == h->rank) continue;
+            if (h->dd_scnt[q] > 0)
+                rccl_check(h, g_rccl.Send(h->dd_sendbuf + q * S, (size_t)h->dd_scnt[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclSend");
+            if (h->dd_rcnt[q] > 0)
+                rccl_check(h, g_rccl.Recv(h->dd_recvbuf + q * S, (size_t)h->dd_rcnt[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclRecv");
+        }
+        rccl_check(h, g_rccl.GroupEnd(), "ncclGroupEnd");
+    } else if (h->lcomm && !h->coll_failed) {
+        LocalComm &L = *h->lcomm;
+        int p;
+        if (!local_begin(h, p)) { h->coll_failed = true; return; }
+        for (int q = 0; q < L.world; ++q)
+            if (q != h->rank && h->dd_rcnt[q] > 0) // what rank q packed for me
+                (void)hipMemcpyAsync(h->dd_recvbuf + q * S, L.h[q]->dd_sendbuf + (size_t)h->rank * S,
+                                     sizeof(float4) * (size_t)h->dd_rcnt[q], hipMemcpyDeviceToDevice, h->stream);
+        if (!local_end(h, p)) h->coll_failed = true;
+    }
+    h->dd_exchanges++;
+    for (int q = 0; q < h->world; ++q) h->dd_bytes_sent += (long long)h->dd_scnt[q] * 16;
+}
+
+int dd_alloc(mmx_handle_s *h) {
+    if (h->dd_boxes) return MMX_OK;
+    const size_t W = (size_t)h->world, S = (size_t)h->slice;
+    HIPCHK(h, dalloc(&h->dd_boxes, W * 6));
+    HIPCHK(h, dalloc(&h->dd_static, (size_t)std::max(h->n_own, 1)));
+    HIPCHK(h, dalloc(&h->dd_send_ids, W * S));
+    HIPCHK(h, dalloc(&h->dd_send_cnt, W));
+    HIPCHK(h, dalloc(&h->dd_cntmat, W * W));
+    HIPCHK(h, dalloc(&h->dd_ghost_ids, W * S));
+    HIPCHK(h, dalloc(&h->dd_sendbuf, W * S));
+    HIPCHK(h, dalloc(&h->dd_recvbuf, W * S));
+    HIPCHK(h, dalloc(&h->dd_xref, (size_t)3 * std::max(h->n_own, 1)));
+    return MMX_OK;
+}
+
+// Ranks that always need owned bead b: the owners of b-2 .. b+2 (backbone bonds and angles reach two beads across a
+// slice end) and of its loop partners (mmx_set_loops).
+int dd_upload_static(mmx_handle_s *h) {
+    std::vector<unsigned long long> m((size_t)std::max(h->n_own, 1), 0ull);
+    for (int i = 0; i < h->n_own; ++i) {
+        const int b = h->own_lo + i;
+        unsigned long long bits = (size_t)i < h->dd_loop_mask.size() ? h->dd_loop_mask[i] : 0ull;
+        for (int d = -2; d <= 2; ++d) {
+            const int o = b + d;
+            if (o < 0 || o >= h->n) continue;
+            const int r = o / h->slice;
+            if (r != h->rank) bits |= 1ull << r;
+        }
+        m[i] = bits;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dd_static, m.data(), sizeof(unsigned long long) * m.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMX_OK;
+}
+
+// Re-decomposition.  pos4 of the owned beads and bbox_part must be current (a pack has just run on the stream).
+// Synchronises with the host (the message sizes of the following halo exchanges come back from the device).
+int dd_redecompose(mmx_handle_s *h) {
+    const int gb = (h->n_own + 255) / 256;
+    const size_t W = (size_t)h->world;
+    hipLaunchKernelGGL(k_dd_bbox, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, h->dd_boxes + 6 * h->rank);
+    coll_allgather_pos4(h); // every position, once: what the lists are built from
+    coll_allgather_small(h, h->dd_boxes, 6 * sizeof(float), [](mmx_handle_s *o) { return (void *)o->dd_boxes; });
+    HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
+    const float reach = hmin_of(h) / 1.001f + h->dd_skin_cur;
+    hipLaunchKernelGGL(k_dd_build_lists, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world,
+                       h->x, h->dd_boxes, reach, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt);
+    HIPCHK(h, hipMemcpyAsync(h->dd_cntmat + W * h->rank, h->dd_send_cnt, sizeof(int) * W, hipMemcpyDeviceToDevice, h->stream));
+    coll_allgather_small(h, h->dd_cntmat, W * sizeof(int), [](mmx_handle_s *o) { return (void *)o->dd_cntmat; });
+    std::vector<int> mat(W * W);
+    HIPCHK(h, hipMemcpyAsync(mat.data(), h->dd_cntmat, sizeof(int) * W * W, hipMemcpyDeviceToHost, h->stream));
+    // the lists start a new life: reference positions, stale flag, cells of beads that are no longer ghosts
+    HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->st->dd_stale, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->cell_of, 0xff, sizeof(int) * (size_t)h->n_all, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+    h->dd_nghost = 0;
+    h->dd_off.off[0] = 0;
+    for (int q = 0; q < h->world; ++q) {
+        h->dd_scnt[q] = q == h->rank ? 0 : mat[W * h->rank + q];
+        h->dd_rcnt[q] = q == h->rank ? 0 : mat[W * q + h->rank];
+        if (h->dd_scnt[q] > h->slice || h->dd_rcnt[q] > h->slice) return fail(h, MMX_ERR_STATE, "ghost list longer than a slice");
+        h->dd_nghost += h->dd_rcnt[q];
+        h->dd_off.off[q + 1] = h->dd_nghost;
+    }
+    h->dd_lists_valid = true;
+    h->dd_redecompositions++;
+    return MMX_OK;
+}
+
 void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
 
 // Pack (+ trial move / integrator step), then the cell build.  With `bonded` set, the bonded terms of the evaluation
 // -- which only need pos4 -- are enqueued with it: inside the launch of the cell scan ("overlap_bonded", default), or
 // right behind the pack.
-void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr) {
+void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr, bool redecomp = false) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
@@ -435,7 +555,24 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
-    if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
+    if (redecomp && use_halo(h)) { // fresh ghost lists from the positions the pack has just written
+        const int rc = dd_redecompose(h);
+        if (rc != MMX_OK && h->dd_rc == MMX_OK) h->dd_rc = rc;
+    }
+    const bool halo = use_halo(h) && h->dd_lists_valid;
+    if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
+        const float half = 0.5f * h->dd_skin_cur;
+        hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
+                           half * half, h->st);
+        int mx = 1;
+        for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scnt[q], h->dd_rcnt[q]));
+        const dim3 gq(std::min((mx + 255) / 256, 256), h->world);
+        hipLaunchKernelGGL(k_dd_pack, gq, dim3(256), 0, h->stream, h->dd_send_ids, h->dd_send_cnt, h->slice, h->pos4,
+                           h->dd_sendbuf, h->st);
+        coll_halo_exchange(h);
+        hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
+                           h->dd_ghost_ids, h->st);
+    } else if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
         coll_allgather_pos4(h);
     const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
     if (bonded && !in_scan) enqueue_bonded(h, *bonded, false);
@@ -445,7 +582,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
             hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
                                dd ? hm : 0.f, cur, h->st);
-        if (!fuse_count)
+        const int gl = (h->n_own + h->dd_nghost + 255) / 256; // owned beads + listed ghosts
+        if (halo)
+            hipLaunchKernelGGL(k_cell_count_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo,
+                               h->dd_nghost, h->dd_ghost_ids, h->pos4, cur, h->cell_of, h->rank_in_cell, h->count, h->st);
+        else if (!fuse_count)
             hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
                                cur, h->cell_of, h->rank_in_cell, h->count, h->st);
         const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next};
@@ -463,8 +604,12 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         if (use_n3(h)) // work items of the half-shell pair kernel: needs the scan's cluster offsets only
             hipLaunchKernelGGL(k_n3_items, dim3(256), dim3(256), 0, h->stream, cur, h->cstart, h->n3_items,
                                h->n3_max_items, h->st);
-        hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
-                           h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
+        if (halo)
+            hipLaunchKernelGGL(k_cell_fill_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->dd_nghost,
+                               h->dd_ghost_ids, h->cell_of, h->rank_in_cell, h->start, h->perm, h->okeys, h->pos4, cur, h->st);
+        else
+            hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
+                               h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order
         if (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(2048), dim3(256), 0, h->stream, cur, h->start,
@@ -543,11 +688,11 @@ enum { FOLD_NONE = 0, // nothing (MD steps whose energies nobody reads)
        FOLD_MIN };    // minimizer: history pass, then energies + line search + direction coefficients
 
 // One full energy+gradient evaluation: pack/move, [bonded terms || cell build], pair kernel, fold.
-void enqueue_eval(mmx_handle_s *h, int mode, int fold) {
+void enqueue_eval(mmx_handle_s *h, int mode, int fold, bool redecomp = false) {
     EventPair ep{};
     CtlArgs A{};
     bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
-    enqueue_build(h, mode, false, &A);
+    enqueue_build(h, mode, false, &A, redecomp);
     prof_end(h, on, ep);
     on = prof_begin(h, MMX_K_NONBONDED, ep);
     if (!has_nb(h)) {
@@ -710,7 +855,8 @@ int ensure_allpairs_scratch(mmx_handle_s *h) {
 // First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
 int prime_items(mmx_handle_s *h) {
     if (!has_nb(h) || all_pairs(h)) return MMX_OK;
-    enqueue_build(h, PACK_PLAIN, true);
+    enqueue_build(h, PACK_PLAIN, true, nullptr, true); // decomposed runs: the ghost lists of this call are built here
+    if (h->dd_rc != MMX_OK) return h->dd_rc;
     return pull_state(h);
 }
 
@@ -731,6 +877,15 @@ int prepare(mmx_handle_s *h) {
         if (!h->formp) HIPCHK(h, dalloc(&h->formp, (size_t)1));
         HIPCHK(h, hipMemcpyAsync(h->formp, &h->Q, sizeof(FormParams), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream)); // h->Q is pageable host memory that may change afterwards
+    }
+    h->dd_rc = MMX_OK;
+    if (use_halo(h)) {
+        if (h->world > kDDMaxWorld) return fail(h, MMX_ERR_BAD_ARG, "the ghost-bead halo supports up to 64 ranks");
+        if ((rc = dd_alloc(h))) return rc;
+        if (h->dd_static_dirty) {
+            if ((rc = dd_upload_static(h))) return rc;
+            h->dd_static_dirty = false;
+        }
     }
     if (h->xg && h->pos4_dirty) { // ghosts of the first evaluation come from the host-set global positions
         hipLaunchKernelGGL(k_fill_pos4_all, dim3((h->n_all + 255) / 256), dim3(256), 0, h->stream, h->n, h->n_all,

@@ -6,6 +6,7 @@
 #include "mmx_bonded.hpp"
 #include "mmx_cells.hpp"
 #include "mmx_common.hpp"
+#include "mmx_dd.hpp"
 #include "mmx_lbfgs.hpp"
 #include "mmx_md.hpp"
 #include "mmx_nonbonded.hpp"
@@ -139,6 +140,23 @@ struct mmx_handle_s {
     bool coll_failed = false;
     std::string coll_error;           // what failed (RCCL error string); empty: loopback time-out
     double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
+    // ghost-bead halo of a decomposed run with a communicator (mmx_dd.hpp); dd_halo = 0 keeps the all-gather of every position
+    int dd_halo = 1;
+    float dd_skin = 0.1f;                       // nm: the lists hold while no bead has moved more than half of it (base value)
+    float dd_skin_cur = 0.1f;                   // ... as adapted by the minimizer: doubled when lists go stale within 8
+                                                // evaluations, halved again after 128 quiet ones
+    int dd_last_rebuild_eval = 0;
+    float *dd_boxes = nullptr;                  // [world][6] owned bounding boxes (all-gathered at re-decomposition)
+    unsigned long long *dd_static = nullptr;    // [n_own] ranks that always need this bead (backbone / loop partners)
+    std::vector<unsigned long long> dd_loop_mask; // host: the loop-partner part of it (mmx_set_loops)
+    int *dd_send_ids = nullptr, *dd_send_cnt = nullptr, *dd_cntmat = nullptr, *dd_ghost_ids = nullptr;
+    float4 *dd_sendbuf = nullptr, *dd_recvbuf = nullptr; // [world][slice]
+    float *dd_xref = nullptr;                   // [3 n_own] owned positions when the lists were built
+    int dd_scnt[kDDMaxWorld]{}, dd_rcnt[kDDMaxWorld]{}, dd_nghost = 0;
+    DDOffsets dd_off{};
+    bool dd_lists_valid = false, dd_static_dirty = true;
+    int dd_rc = 0;                              // first error of a re-decomposition inside a launch sequence
+    long long dd_redecompositions = 0, dd_exchanges = 0, dd_bytes_sent = 0; // statistics (options dd_*)
     float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
     bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation
     hipStream_t stream = nullptr;

@@ -382,7 +382,7 @@ __device__ __forceinline__ void slot_counts(const CtlArgs &A, int *s_n) {
 // Plain evaluation (mmx_compute, MD reports), single GPU: fold the energy partials.
 __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const double *__restrict__ part,
                                                      MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_task[kMaxTasks];
     __shared__ double s_out[P_NSLOTS];
     __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const doub
 // direction coefficients -- one launch per evaluation.
 __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
                                                  const double *__restrict__ rows, MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     static_assert(MMX_NROWSUM <= 48, "rows_load covers 3 rows per wave");
     __shared__ double s_task[kMaxTasks];
     __shared__ double s_out[P_NSLOTS];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
 // Multi-GPU: fold -> st->sums (+ st->rowsum) -> ncclAllReduce (fp64 sum, in place) -> decide on every rank.
 __global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const double *__restrict__ part,
                                                        MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) {
+    if (st->phase >= PH_DONE) {
         if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0; // keep the collective's input finite
         return;
     }
@@ -443,17 +443,17 @@ __global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const do
     __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
     slot_counts(A, s_n);
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : (threadIdx.x == 12 && st->dd_stale) ? 1.0 : 0.0;
 }
 __global__ void k_controller_decide(MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    if (st->phase >= PH_DONE || threadIdx.x != 0) return;
     double sums[P_NSLOTS];
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
     controller_decide(st, sums);
 }
 __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
                                                      const double *__restrict__ rows, MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) {
+    if (st->phase >= PH_DONE) {
         if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0;
         if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
         return;
@@ -467,11 +467,18 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
     slot_counts(A, s_n);
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
     rows_finish<MMX_NROWSUM>(acc, s_rows);
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : 0.0;
+    // slot 12 of the all-reduced array: "some rank's ghost lists are out of date" (see k_dd_displacement)
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : (threadIdx.x == 12 && st->dd_stale) ? 1.0 : 0.0;
     if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
-    if (st->phase == PH_DONE || threadIdx.x != 0) return;
+    if (st->phase >= PH_DONE || threadIdx.x != 0) return;
+    if (st->sums[12] > 0.5) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
+        st->halt_phase = st->phase;
+        st->phase = PH_HALT;
+        st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
+        return;
+    }
     double ysl[MMX_M];
     for (int k = 0; k < MMX_M; ++k) ysl[k] = st->ys[k];
     double sums[P_NSLOTS];

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
                                                   const GridParams *__restrict__ grid,
                                                   const MinState *__restrict__ st, float *__restrict__ g,
                                                   double *__restrict__ part) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float4 s_tile[3][64];
     __shared__ float s_red[2][5][64];
     __shared__ float s_tab[32];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
                                                        const MinState *__restrict__ st, float *__restrict__ g,
                                                        double *__restrict__ part, const float sc = 1.f,
                                                        const FormParams *__restrict__ Qd = nullptr) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     FormParams Q;
     if (FORMS) Q = *Qd; // uniform loads into scalar registers; the default instances never touch it
     constexpr bool RANK2 = (OPT & 1) != 0;  // amplitude = aA_i*alpha_j + aB_i*beta_j instead of an LDS lookup
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_nb_allpairs(const FFParams P, const flo
                                                      float4 *__restrict__ fpart, float2 *__restrict__ epart,
                                                      const MinState *__restrict__ st,
                                                      const FormParams *__restrict__ Qd = nullptr) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float4 s_tile[256];
     __shared__ float s_tab[32], s_tabc[FORMS ? 32 : 1], s_tabs[FORMS ? 32 : 1];
     FormParams Q;
@@ -689,7 +689,7 @@ template <int PMODE, bool EV, bool GAUSS>
 __global__ __launch_bounds__(256) void k_nb_allpairs_lean(const FFParams P, const float4 *__restrict__ pos4,
                                                           int tiles_per_slice, float4 *__restrict__ fpart,
                                                           float2 *__restrict__ epart, const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ float4 s_tile[256];
     __shared__ float s_tab[32];
     if (threadIdx.x < 25) s_tab[threadIdx.x] = P.table[threadIdx.x];
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void k_nb_allpairs_fold(int n, int nslices, co
                                                           const float2 *__restrict__ epart, float *__restrict__ g,
                                                           double *__restrict__ part,
                                                           const MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double ev = 0.0, eg = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

@@ -150,7 +150,7 @@ __device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart o
 
 __global__ __launch_bounds__(256) void k_n3_items(const GridParams *__restrict__ grid, const int *__restrict__ cstart,
                                                   N3Item *__restrict__ items, int max_items, MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     const GridParams G = *grid;
     const int nrows = G.ny * G.nz, nx = G.nx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           float *__restrict__ fsort, const int fstride,
                                                           double *__restrict__ part, const float sc, const int cap,
                                                           const int diag = 0, unsigned long long *__restrict__ dbg = nullptr) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     (void)dbg;
     // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
     // 8 slots are a dummy cluster), two box buffers [cap + 1][2] float4, four id buffers [cap + 8] int
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 __global__ __launch_bounds__(256) void k_nb_n3_unsort(const float4 *__restrict__ spos4, float *__restrict__ fsort,
                                                       const int fstride, float *__restrict__ g,
                                                       MinState *__restrict__ st) {
-    if (st->phase == PH_DONE) return;
+    if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->n3_queue = 0;
     const int nsl = st->n_clusters * kCl;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nsl; i += gridDim.x * 256) {

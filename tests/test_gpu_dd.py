@@ -2,9 +2,10 @@
 
 The ranks are handles of this process driven by one thread each and joined by the loopback communicator
 (mmx_comm_init_local: host barrier + HIP events + device copies in rank order).  What runs is exactly the
-multi-GPU control flow of the library -- owned slices, in-place all-gather of positions, fp64 all-reduce of the
-16 slot sums per evaluation and of the 40 Gram entries per accepted iteration, identical line-search decisions on
-every rank -- with RCCL's transport replaced.  (The RCCL calls themselves: test_rccl_path_single_rank.)
+multi-GPU control flow of the library -- owned slices, ghost lists rebuilt at re-decomposition, the per-evaluation halo
+exchange of the listed beads only, ONE fp64 all-reduce per evaluation (energies, Gram rows, stale flag), identical
+line-search decisions on every rank, the halt-and-repeat protocol when a list goes stale -- with RCCL's transport
+(ncclSend/ncclRecv groups, all-gathers, all-reduce) replaced.  (The RCCL calls themselves: test_rccl_path_single_rank.)
 """
 import threading
 
@@ -20,9 +21,12 @@ ALL_ON = dict(SC_USE_SPHERICAL_CONTAINER=True, COB_USE_COMPARTMENT_BLOCKS=True, 
               IBL_USE_B_LAMINA_INTERACTION=True, CF_USE_CENTRAL_FORCE=True)
 
 
-def run_ranks(system, world, fn):
+def run_ranks(system, world, fn, **options):
     """fn(engine) on every rank concurrently; returns the per-rank results (raises the first error)."""
     engines = [engine_for(system, rank=r, world=world) for r in range(world)]
+    for e in engines:
+        for k, v in options.items():
+            e.set_option(k, v)
     Engine.comm_init_local(engines)
     out, err = [None] * world, []
 
@@ -44,7 +48,7 @@ def run_ranks(system, world, fn):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_compute_all_reduced_energies_and_owned_forces(world):
     s = synthetic_system("gw_200k", n_beads=5000, jitter=0.02, seed=2, **ALL_ON)
     with engine_for(s) as eng:
@@ -115,6 +119,55 @@ def test_md_decomposed_matches_single_domain():
     assert np.array_equal(res[0][1], res[1][1])
     assert abs(res[0][0][1] - ref[0][1]) <= 1e-4 * ref[0][1]
     assert np.abs(res[0][1] - ref[1]).max() < 1e-4
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_halo_exchange_equals_the_all_gather_of_every_position(world):
+    """The boundary-only ghost exchange (default) against the all-gather of every position (dd_halo = 0).  Same physics;
+    not always the same bits: the all-gather path also bins the foreign beads of the grid's outermost, partly empty cell
+    layer (beyond the cutoff of every owned bead: zero force), which changes how a cell's beads fall into clusters of 8
+    and with it the order of fp32 sums.  Forces agree to rounding, a minimization stays together; a rank receives only
+    its halo."""
+    s = synthetic_system("gw_200k", n_beads=12000, jitter=0.02, seed=5, **ALL_ON)
+
+    def job(e):
+        et, f = e.compute()
+        st = e.minimize(tolerance=0.0, max_iters=40)
+        stats = {k: e.get_option(k) for k in ("dd_ghosts", "dd_redecompositions", "dd_exchanges", "dd_bytes_sent")}
+        return et, f, (st.iterations, st.status, st.e_initial, st.e_final), e.get_positions(), stats, e.n_own
+
+    halo = run_ranks(s, world, job, dd_halo=1)
+    full = run_ranks(s, world, job, dd_halo=0)
+    for a, b in zip(halo, full):
+        assert np.allclose(a[0], b[0], rtol=2e-6, atol=1e-6)
+        assert np.abs(a[1] - b[1]).max() <= 1e-5 * np.abs(b[1]).max()
+        assert a[2][:2] == b[2][:2] and abs(a[2][2] - b[2][2]) <= 2e-6 * abs(b[2][2])
+        assert abs(a[2][3] - b[2][3]) <= 3e-3 * abs(b[2][2] - b[2][3])   # of the energy drop (the lattice start is chaotic)
+        assert np.abs(a[3] - b[3]).max() < 0.1
+    for r, (_, _, _, _, st, n_own) in enumerate(halo):
+        assert 0 < st["dd_ghosts"] < s.n_beads - n_own          # a halo, not everybody else
+        assert st["dd_exchanges"] > 40 and 2 <= st["dd_redecompositions"] < st["dd_exchanges"] / 2
+        assert st["dd_bytes_sent"] / st["dd_exchanges"] <= 16 * n_own * (world - 1)   # never more than the all-gather moves
+    assert all(f[4]["dd_exchanges"] == 0 for f in full)
+
+
+def test_stale_ghost_lists_halt_and_repeat():
+    """A skin so thin that nearly every trial move outruns it: the evaluation that notices decides nothing (PH_HALT on
+    every rank, through the all-reduced flag), the host rebuilds the lists at the trial point and repeats it.  The
+    minimization must come out exactly as with a comfortable skin."""
+    s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
+
+    def job(e):
+        st = e.minimize(tolerance=0.0, max_iters=30)
+        return (st.iterations, st.evaluations, st.status, st.e_final), e.get_positions(), e.get_option("dd_redecompositions")
+
+    ref = run_ranks(s, 3, job, dd_skin=1.0)
+    thin = run_ranks(s, 3, job, dd_skin=1e-5)   # doubles on every early halt: 1e-5 ... 0.02 nm over 30 iterations
+    for a, b in zip(ref, thin):   # (a wider skin lists more ghosts: cluster composition and fp32 sum order may differ)
+        assert a[0][0] == b[0][0] and a[0][2] == b[0][2] and abs(a[0][3] - b[0][3]) <= 3e-3 * abs(b[0][3])
+        assert np.abs(a[1] - b[1]).max() < 0.1
+    assert all(t[0] == thin[0][0] and np.array_equal(t[1], thin[0][1]) for t in thin)   # ranks agree bit for bit
+    assert thin[0][2] > ref[0][2] + 10      # it did halt and repeat, many times
 
 
 def test_local_communicator_argument_checks():
