@@ -8,7 +8,10 @@ over a synthetic Hilbert-curve-initialised bead system.  N = 1: BASELINE config 
 beads, GW preset = EV + compartment blocks + container + lamina + bonds + angles + loops).  N > 1:
 BASELINE config 4, one independent genome-wide replica per GPU with seeds 0..N-1 (the reference's
 ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collective, "weak" scaling.
-`value` is the whole-job rate: total iterations of all ranks / max-over-ranks wall time.
+`value` is the whole-job rate: total iterations of all ranks / max-over-ranks wall time.  At N > 1 the same JSON line
+also carries a `dd` object: BASELINE config 5, ONE gw_1m system decomposed over the N GPUs (ghost-bead halo exchange +
+one all-reduce per evaluation on RCCL), with its iterations/s, bytes exchanged per evaluation and parallel efficiency
+against one GPU minimizing the same system (never part of `value`).
 
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
 pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
@@ -52,8 +55,10 @@ def parse_args():
                     help="HIP-event time every k-th launch of each kernel slot inside the timed region "
                          "(an event pair costs ~10 us of stream time: 16 keeps the perturbation < 1 %%)")
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
-                    help="N > 1: 'ensemble' = one replica per GPU (config 4, weak scaling, no collective); "
-                         "'dd' = ONE system decomposed over the GPUs (config 5, strong scaling, RCCL)")
+                    help="what `value` is at N > 1: 'ensemble' = one gw_200k replica per GPU (config 4, weak scaling, no "
+                         "collective; the default, with the gw_1m decomposed run reported beside it as the `dd` object); "
+                         "'dd' = the timed headline itself is ONE system decomposed over the GPUs (config 5, RCCL)")
+    ap.add_argument("--no-dd-leg", action="store_true", help="N > 1, ensemble mode: skip the gw_1m decomposed leg")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="extra leg at N=1 (never part of `value`, off by default so that a profile of the default "
                          "command contains the timed minimization only): aggregate rate of this many replicas sharing "
@@ -145,6 +150,69 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
         "evals_per_s": st.evaluations / dt,
         "openmm": {"available": False, "probe": why},
     }
+
+
+def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier) -> dict:
+    """BASELINE config 5 beside the headline (N > 1): ONE gw_1m system (1 000 000 beads), bead slices owned by the
+    ranks, ghost-bead halo exchange + one fp64 all-reduce per evaluation on RCCL, issued by libmmx on its own stream.
+    Returns the `dd` object of the JSON line: job iterations/s, the ranks RCCL saw, bytes exchanged per evaluation,
+    and the parallel efficiency against ONE GPU minimizing the same system (timed on rank 0 right after).  Never part
+    of `value`; any failure is reported inside the object instead of breaking the line."""
+    import torch.distributed as dist
+    from multimm_amd import synthetic_system
+    from multimm_amd.engine import Engine, engine_for
+    from multimm_amd.parallel import broadcast_bytes, reduce_job_stats
+    out = {"workload": "gw_1m", "mode": "dd", "ranks": world}
+    stage = "setup"
+    try:
+        system = synthetic_system("gw_1m", seed=0, NB_CUTOFF=args.cutoff)
+        out["n_beads"] = system.n_beads
+        eng = engine_for(system, device=local_rank, rank=rank, world=world)
+        try:
+            stage = "rccl communicator"
+            uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128, device=tdev)
+            eng.comm_init(uid)
+            stage = "warm-up"
+            if args.warmup > 0:
+                eng.minimize(tolerance=0.0, max_iters=args.warmup)
+            b0, x0 = eng.get_option("dd_bytes_sent"), eng.get_option("dd_exchanges")
+            r0 = eng.get_option("dd_redecompositions")
+            stage = "timed minimization"
+            barrier()
+            t0 = time.perf_counter()
+            st = eng.minimize(tolerance=0.0, max_iters=args.steps)
+            barrier()
+            dt = time.perf_counter() - t0
+            dt, iters = reduce_job_stats(dt, st.iterations, "dd", device=tdev)
+            nx = max(eng.get_option("dd_exchanges") - x0, 1.0)
+            out.update({
+                "value": iters / dt, "unit": "iters/s", "iterations": iters, "evaluations": st.evaluations,
+                "ms_per_step": dt * 1e3 / max(iters, 1.0), "ranks_rccl_saw": world, "status": st.status,
+                "halo_bytes_sent_per_evaluation_rank0": (eng.get_option("dd_bytes_sent") - b0) / nx,
+                "allgather_bytes_it_replaces_per_rank": 16.0 * eng.n_own * (world - 1),
+                "allreduce_bytes_per_evaluation": 8.0 * 59,
+                "ghosts_rank0": eng.get_option("dd_ghosts"), "owned_rank0": eng.n_own,
+                "redecompositions": eng.get_option("dd_redecompositions") - r0,
+                "skin_nm_at_end": eng.get_option("dd_skin_now"),
+            })
+        finally:
+            eng.close()
+        stage = "single-GPU reference"
+        if rank == 0:
+            with engine_for(system, device=local_rank) as e1:
+                if args.warmup > 0:
+                    e1.minimize(tolerance=0.0, max_iters=args.warmup)
+                t0 = time.perf_counter()
+                s1 = e1.minimize(tolerance=0.0, max_iters=args.steps)
+                d1 = time.perf_counter() - t0
+            out["single_gpu_iters_per_s"] = s1.iterations / d1
+            out["parallel_efficiency"] = out["value"] / (world * out["single_gpu_iters_per_s"])
+            out["speedup"] = out["value"] / out["single_gpu_iters_per_s"]
+        if world > 1:
+            dist.barrier()
+    except Exception as exc:  # noqa: BLE001 -- the headline line must survive a failing extra leg
+        out["error"] = f"{stage}: {exc!r}"
+    return out
 
 
 def main():
@@ -298,6 +366,10 @@ def main():
         }
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
     eng.close()
+    if world > 1 and not dd and not args.no_dd_leg:  # every rank takes part; rank 0 carries the result
+        leg = dd_leg(args, rank, world, local_rank, tdev, barrier)
+        if rank == 0:
+            out["dd"] = leg
     if rank == 0:
         if n_gpus == 1 and args.replicas_per_gpu > 1:
             out["replicas_per_gpu"] = replicas_per_gpu_leg(args.workload, args.n_beads, args.cutoff, local_rank,

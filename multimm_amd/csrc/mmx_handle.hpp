@@ -63,8 +63,10 @@ static bool load_rccl(std::string &err) {
     static std::mutex mu; // handles may be driven from several threads (one per rank in loopback runs)
     std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.lib) return true;
-    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // the soname first: a process that already carries RCCL (PyTorch bundles its own copy) gets that very copy back,
+    // not a second instance from /opt/rocm
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) {
         err = std::string("cannot load librccl.so: ") + dlerror();

@@ -11,7 +11,7 @@ for r in csv.DictReader(open(fs[0])):
     k = r["Kernel_Name"].split("(")[0][-36:]
     a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in acc:
-    if "nb_clusters" in k:
+    if "nb_" in k:
         for c, (v, n) in acc[k].items():
             print("%-36s %-24s per-dispatch %.4g (n=%d)" % (k, c, v / n, n))
 PY
