@@ -113,6 +113,8 @@ void refresh_params(mmx_handle_s *h) {
     }
 }
 
+constexpr double kN3MinBeadsPerCell = 60.0;
+
 // The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
 // caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
 // forces it off (A/B timing).
@@ -120,7 +122,12 @@ bool use_n3(const mmx_handle_s *h) {
     if (!h->nb_lean || h->n3_cap <= 0 || !h->fsort || !h->n3_items || h->world > 1 || h->n_own != h->n) return false;
     if (h->nb_variant & 8192) return false;
     if (h->nb_variant & 4096) return true;
-    return !h->deterministic && (h->nb_variant & 0xffff & ~(4096 | 8192)) == 0;
+    if (h->deterministic || (h->nb_variant & 0xffff & ~(4096 | 8192)) != 0) return false;
+    // Which kernel is faster depends on how crowded the cells are (scripts/nb_states.py, gw_200k along a minimization):
+    // at 150 beads per grid cell (lattice start) the half-shell kernel takes 0.87 of the full-shell kernel's time, from
+    // ~50 per cell on they are level -- and the half-shell path costs two small launches more (items, unsort, ~9 us).
+    // The last poll's cell count decides; both kernels compute the same forces to rounding.
+    return h->last_ncells <= 0 || (double)h->n >= kN3MinBeadsPerCell * (double)h->last_ncells;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
@@ -823,6 +830,7 @@ int pull_state(mmx_handle_s *h) {
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
     if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
     if (h->st_host->max_per_cell > 0) h->last_max_per_cell = h->st_host->max_per_cell;
+    if (h->st_host->ncells > 0) h->last_ncells = h->st_host->ncells;
     if (h->comm && g_rccl.CommGetAsyncError && !h->coll_failed) { // errors RCCL found after the call returned
         ncclResult_t ar = ncclSuccess;
         if (g_rccl.CommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)

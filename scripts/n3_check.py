@@ -16,7 +16,7 @@ for name in cases:
             et_ref, F_ref = Oracle(s).eval()
             with engine_for(s) as eng:
                 for v in (0, 4096):
-                    eng.set_option("deterministic", 0 if v else 1)
+                    eng.set_option("nb_variant", 4096 if v else 8192)
                     et, F = eng.compute()
                     de = np.abs(et - et_ref).max() / np.abs(et_ref).sum()
                     df = np.abs(F - F_ref).max() / np.abs(F_ref).max()
@@ -31,7 +31,7 @@ for name in cases:
             eng.minimize(tolerance=0.0, max_iters=300)
         res = {}
         for v in (0, 4096):
-            eng.set_option("deterministic", 0 if v else 1)
+            eng.set_option("nb_variant", 4096 if v else 8192)
             et, F = eng.compute()
             us, _ = eng.time_kernel(K_NONBONDED, 20)
             res[v] = (et, F, us)

@@ -30,17 +30,19 @@ def _check(system, cutoff, label, e_rtol=E_RTOL, e_atol=E_ATOL):
     et_ref, F_ref = Oracle(s).eval()
     scale_e = np.abs(et_ref).sum()
     fmax = np.abs(F_ref).max()
-    # both pair kernels of the cell-list path: the default half-shell kernel (Newton's third law, atomics) and the
-    # full-shell kernel with a fixed summation order (option deterministic); without a cutoff they are the same kernel
-    for det in ((0, 1) if cutoff > 0 else (0,)):
+    # both pair kernels of the cell-list path, each forced (by default the engine picks per state, see use_n3 in
+    # mmx_engine.hpp): the half-shell kernel (Newton's third law, atomics; nb_variant bit 4096) and the full-shell kernel
+    # with a fixed summation order (what option deterministic selects); without a cutoff there is one all-pairs kernel
+    for kernel, variant, det in ((("half-shell", 4096, 0), ("full-shell", 0, 1)) if cutoff > 0 else (("all-pairs", 0, 0),)):
         with engine_for(s) as eng:
             eng.set_option("deterministic", det)
+            eng.set_option("nb_variant", variant)
             et, F = eng.compute()
         for t in range(len(TERM_NAMES)):
             assert abs(et[t] - et_ref[t]) <= e_rtol * scale_e + e_atol, (
-                f"{label} deterministic={det}: term {TERM_NAMES[t]} gpu={et[t]!r} ref={et_ref[t]!r}")
+                f"{label} {kernel}: term {TERM_NAMES[t]} gpu={et[t]!r} ref={et_ref[t]!r}")
         ferr = np.abs(F.astype(np.float64) - F_ref).max()
-        assert ferr <= F_RTOL * fmax + F_ATOL, f"{label} deterministic={det}: force err {ferr} (max |F| {fmax})"
+        assert ferr <= F_RTOL * fmax + F_ATOL, f"{label} {kernel}: force err {ferr} (max |F| {fmax})"
     return et, F
 
 
@@ -125,6 +127,24 @@ def test_half_shell_kernel_dense_cells_and_overlapping_beads():
     # kJ/mol and measured at 2e-3 (half-shell) / 5e-2 (full-shell) -- invisible next to the 1e7 kJ/mol of a chromatin
     # system, but above the 1e-3 floor of the other tests.
     _check(ChromatinSystem(3000, gas, np.array([0, 3000]), labels[:3000], ff=ff), 0.6, "sparse gas", e_atol=0.1)
+
+
+def test_pair_kernel_choice_follows_the_cell_occupancy():
+    """Default options: the half-shell kernel while the cells are crowded, the full-shell kernel once they have thinned
+    out (use_n3 in mmx_engine.hpp); a minimization that crosses the threshold switches on the way and still ends where
+    a run pinned to either kernel ends."""
+    s = synthetic_system("gw_200k", n_beads=30000, **ALL_ON)
+    ends = {}
+    for name, variant in (("auto", 0), ("half-shell", 4096), ("full-shell", 8192)):
+        with engine_for(s) as eng:
+            eng.set_option("nb_variant", variant)
+            st = eng.minimize(tolerance=0.0, max_iters=120)
+            ends[name] = (st.e_initial, st.e_final, eng.nb_census()["n_cells"])
+    e0, ef, cells = ends["auto"]
+    assert s.n_beads / cells < 60 < s.n_beads / 216          # the run started above the threshold and ended below it
+    for name in ("half-shell", "full-shell"):
+        assert abs(ends[name][0] - e0) <= 2e-6 * abs(e0)
+        assert abs(ends[name][1] - ef) <= 2e-2 * abs(e0 - ef)   # 120 iterations from the lattice: chaotic, see DESIGN.md 9
 
 
 def test_graph_replay_equals_direct_launches_bitwise():
