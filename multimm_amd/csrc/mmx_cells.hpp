@@ -523,18 +523,17 @@ __device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const
     __syncthreads();
 }
 
+// `bid` of `nblk` workgroups (k_cell_order: blockIdx / gridDim; k_order_items: the launch's first nblk workgroups)
 template <int CHUNK, int CAP>
-__global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
-                                                    const int *__restrict__ start, const int *__restrict__ istart,
-                                                    int *__restrict__ count,
-                                                    int *__restrict__ perm, int2 *__restrict__ items,
-                                                    const int *__restrict__ cstart,
-                                                    const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
-                                                    float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
-                                                    int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
-                                                    const int *__restrict__ biglist, const float scale,
-                                                    MinState *__restrict__ st) {
-    if (st->phase >= PH_DONE) return;
+__device__ __forceinline__ void cell_order_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
+                                                 const int *__restrict__ start, const int *__restrict__ istart,
+                                                 int *__restrict__ count, int *__restrict__ perm, int2 *__restrict__ items,
+                                                 const int *__restrict__ cstart, const float4 *__restrict__ pos4,
+                                                 float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
+                                                 float4 *__restrict__ cl_hi, int own_lo, int n_own,
+                                                 const unsigned long long *__restrict__ okeys,
+                                                 const int *__restrict__ biglist, const float scale,
+                                                 MinState *__restrict__ st) {
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
     const unsigned long long kmax = ~0ull;
 
     // ---- pass A: one wave per small cell
-    for (int c = blockIdx.x * 4 + wave; c < ncells; c += gridDim.x * 4) {
+    for (int c = bid * 4 + wave; c < ncells; c += nblk * 4) {
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt > 64) continue;
         if (lane == 0) count[c] = 0;
@@ -569,7 +568,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
     // flight as long as there are fewer large cells than resident blocks, wherever they sit in the grid)
     const int nbig = st->n_big;
-    for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    for (int bi = bid; bi < nbig; bi += nblk) {
         const int c = biglist[bi];
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt <= 64) continue; // (cannot happen; block-uniform)
@@ -638,6 +637,22 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
         emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, nullptr,
                       scale);
     }
+}
+
+template <int CHUNK, int CAP>
+__global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict__ grid,
+                                                    const int *__restrict__ start, const int *__restrict__ istart,
+                                                    int *__restrict__ count,
+                                                    int *__restrict__ perm, int2 *__restrict__ items,
+                                                    const int *__restrict__ cstart,
+                                                    const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
+                                                    float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
+                                                    int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
+                                                    const int *__restrict__ biglist, const float scale,
+                                                    MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
+                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, scale, st);
 }
 
 } // namespace mmx

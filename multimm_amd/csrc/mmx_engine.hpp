@@ -608,22 +608,33 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         } else {
             hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
         }
-        if (use_n3(h)) // work items of the half-shell pair kernel: needs the scan's cluster offsets only
-            hipLaunchKernelGGL(k_n3_items, dim3(256), dim3(256), 0, h->stream, cur, h->cstart, h->n3_items,
-                               h->n3_max_items, h->st);
         if (halo)
             hipLaunchKernelGGL(k_cell_fill_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->dd_nghost,
                                h->dd_ghost_ids, h->cell_of, h->rank_in_cell, h->start, h->perm, h->okeys, h->pos4, cur, h->st);
         else
             hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                                h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
-        // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order
-        if (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640)
-            hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(2048), dim3(256), 0, h->stream, cur, h->start,
+        // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order; the work items
+        // of the half-shell pair kernel are built by extra workgroups of the same launch (k_order_items)
+        const bool small_cells = h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
+        const int go = small_cells ? 2048 : 1024;
+        if (use_n3(h)) {
+            if (small_cells)
+                hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
+                                   h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
+                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->n3_items,
+                                   h->n3_max_items, h->st);
+            else
+                hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
+                                   h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
+                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->n3_items,
+                                   h->n3_max_items, h->st);
+        } else if (small_cells)
+            hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
                                h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
         else
-            hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(1024), dim3(256), 0, h->stream, cur, h->start,
+            hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
                                h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
         h->gcur = cur;
