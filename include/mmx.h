@@ -190,6 +190,16 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them
  *                     per graph, even) instead of launching them one by one; same bits; slower on
  *                     ROCm 7.2 at every size measured, kept for A/B     0
+ * "dd_halo"           decomposed runs with a communicator: 1 = ghost-bead halo exchange (lists rebuilt at
+ *                     re-decomposition, ncclSend/ncclRecv of the listed beads per evaluation);
+ *                     0 = all-gather of every position per evaluation (round-1 path, A/B)  1
+ * "dd_skin"           nm; the ghost lists hold while no bead has moved more than half of it; the
+ *                     minimizer doubles it (up to 1.6) when lists go stale within 8 evaluations
+ *                     and halves it again after 128 quiet ones                          0.1
+ * "dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_skin_now"
+ *                     (get only) statistics of the decomposed run
+ * nb_variant bits:    4096 force the half-shell pair kernel, 8192 force the full-shell one (default: chosen per
+ *                     state); the other bits select round-1 A/B and diagnosis instances
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0
  * "fused_bonded"      1: backbone + loops + confinement in one pass; 0: the three kernels
