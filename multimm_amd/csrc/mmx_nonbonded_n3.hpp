@@ -255,6 +255,29 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                  spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, scale, st);
 }
 
+// Sums v[0..7] over the 64 lanes; every lane l returns the total of v[l & 7].  Butterfly with a halving payload: after the
+// step over lane bit k a lane only carries the values whose index has its own bit k.  Fixed order => deterministic.
+__device__ __forceinline__ float fold8(const float (&v)[8], const int lane) {
+    float w[4], u[2];
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // lane ^ 1: even lanes keep v[2k], odd lanes v[2k+1]
+        const float keep = b0 ? v[2 * k + 1] : v[2 * k], give = b0 ? v[2 * k] : v[2 * k + 1];
+        w[k] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xb1, 0xf, 0xf, false)); // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { // lane ^ 2: w[k] holds index 2k + b0; keep the one whose bit 1 is b1
+        const float keep = b1 ? w[2 * k + 1] : w[2 * k], give = b1 ? w[2 * k] : w[2 * k + 1];
+        u[k] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x4e, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
+    }
+    const float keep = b2 ? u[1] : u[0], give = b2 ? u[0] : u[1]; // lane ^ 4
+    float t = keep + __shfl_xor(give, 4, 64);
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xf, 0xf, false)); // row_ror:8 = lane ^ 8
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t;
+}
+
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
 template <int PMODE, bool EV, bool GAUSS, bool NOENERGY>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
@@ -664,25 +687,18 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                     wave_lds_sync();
                 }
             }
-            // ---- i side: fold over the wave; lane s (< 8) ends up owning bead s of the i-cluster
-            float ofx = 0.f, ofy = 0.f, ofz = 0.f;
-#pragma unroll
-            for (int s = 0; s < kCl; ++s) {
-                const float a0 = wave_sum_dpp(fx[s]), a1 = wave_sum_dpp(fy[s]), a2 = wave_sum_dpp(fz[s]);
-                if (lane == s) {
-                    ofx = a0 * pscale;
-                    ofy = a1 * pscale;
-                    ofz = a2 * pscale;
-                }
-            }
+            // ---- i side: fold over the wave; lane s (< 8) ends up owning bead s of the i-cluster.  Transposed butterfly: every
+            // step halves the values a lane carries (lane bit k picks which half it keeps summing), so the 8 sums of a
+            // component cost ~27 operations instead of 8 full wave reductions (56)
+            const float ofx = fold8(fx, lane) * pscale, ofy = fold8(fy, lane) * pscale, ofz = fold8(fz, lane) * pscale;
             if (lane < kCl && own_w >= 0 && !(diag & 8)) {
                 atomicAdd(fsort + icl * kCl + lane, ofx);
                 atomicAdd(fsort + fstride + icl * kCl + lane, ofy);
                 atomicAdd(fsort + 2 * fstride + icl * kCl + lane, ofz);
             }
-            if (!NOENERGY) {
-                acc_ev += (double)escale * wave_sum((double)ee);
-                acc_g += (double)wave_sum(eg);
+            if (!NOENERGY) { // per lane; summed over the wave once, at the end of the kernel
+                acc_ev += (double)ee;
+                acc_g += (double)eg;
             }
         }
         // ---- out of i-clusters: leave the unit; the last wave to do so opens the flush and stages unit v + 2
@@ -706,6 +722,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
         }
     }
+    acc_ev = (double)escale * wave_sum(acc_ev);
+    acc_g = wave_sum(acc_g);
     if (lane == 0) {
         s_e[0][wave] = acc_ev;
         s_e[1][wave] = acc_g;
