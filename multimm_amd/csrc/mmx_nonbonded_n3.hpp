@@ -44,7 +44,7 @@ namespace mmx {
 constexpr int kN3Waves = 16;        // waves per workgroup
 constexpr int kN3Threads = kN3Waves * 64;
 constexpr int kN3ItemClusters = 16; // i-clusters per work item (grabbed one at a time by the waves)
-constexpr int kN3List = 128;        // accepted j-clusters buffered per wave before a sweep
+constexpr int kN3List = 192;        // accepted j-clusters buffered per wave before a sweep (culled 128 candidates at a time)
 constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two windows in flight: 160 KB of LDS, all of it)
 // A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
 // overflow; a larger one (overlapping beads) bypasses LDS with a global float atomic.
@@ -553,22 +553,30 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 const int own_lc = own_k >= 0 ? own_k : -1;
                 const int k0 = max(own_k, 0);
                 int nlist = 0, rcount = 0, rhead = 0;
-                for (int g = k0 & ~63; g < nwin; g += 64) {
-                    // ---- cull: 64 candidate clusters of the window per step, boxes from LDS
-                    const int k = g + lane;
-                    bool ok = false;
-                    if (k >= k0 && k < nwin) {
-                        const float4 lo_j = s_box[2 * k], hi_j = s_box[2 * k + 1];
-                        const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
-                        const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
-                        const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
-                        ok = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+                for (int g = k0 & ~63; g < nwin; g += 128) {
+                    // ---- cull: 128 candidate clusters of the window per step (two independent box reads in flight: the LDS
+                    // round trip is what a step waits for), boxes from LDS
+                    bool ok[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = g + 64 * h + lane;
+                        ok[h] = false;
+                        if (k >= k0 && k < nwin) {
+                            const float4 lo_j = s_box[2 * k], hi_j = s_box[2 * k + 1];
+                            const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
+                            const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
+                            const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
+                            ok[h] = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+                        }
                     }
-                    const unsigned long long mask = __ballot(ok);
-                    if (ok) list[nlist + prefix_count(mask)] = (unsigned short)k;
-                    nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
-                    const bool last = g + 64 >= nwin;
-                    if (nlist < kN3List - 64 && !last) continue;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned long long mask = __ballot(ok[h]);
+                        if (ok[h]) list[nlist + prefix_count(mask)] = (unsigned short)(g + 64 * h + lane);
+                        nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
+                    }
+                    const bool last = g + 128 >= nwin;
+                    if (nlist < kN3List - 128 && !last) continue;
                     if (diag & 16) { // timing diagnosis only: cull without sweep
                         fx[0] += (float)nlist;
                         nlist = 0;
