@@ -255,29 +255,6 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                  spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, scale, st);
 }
 
-// Sums v[0..7] over the 64 lanes; every lane l returns the total of v[l & 7].  Butterfly with a halving payload: after the
-// step over lane bit k a lane only carries the values whose index has its own bit k.  Fixed order => deterministic.
-__device__ __forceinline__ float fold8(const float (&v)[8], const int lane) {
-    float w[4], u[2];
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { // lane ^ 1: even lanes keep v[2k], odd lanes v[2k+1]
-        const float keep = b0 ? v[2 * k + 1] : v[2 * k], give = b0 ? v[2 * k] : v[2 * k + 1];
-        w[k] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xb1, 0xf, 0xf, false)); // quad_perm [1,0,3,2]
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { // lane ^ 2: w[k] holds index 2k + b0; keep the one whose bit 1 is b1
-        const float keep = b1 ? w[2 * k + 1] : w[2 * k], give = b1 ? w[2 * k] : w[2 * k + 1];
-        u[k] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x4e, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
-    }
-    const float keep = b2 ? u[1] : u[0], give = b2 ? u[0] : u[1]; // lane ^ 4
-    float t = keep + __shfl_xor(give, 4, 64);
-    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xf, 0xf, false)); // row_ror:8 = lane ^ 8
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    return t;
-}
-
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
 template <int PMODE, bool EV, bool GAUSS, bool NOENERGY>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
