@@ -366,6 +366,23 @@ def main():
         }
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
     eng.close()
+    if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0 and args.cutoff > 0:
+        # what the cutoff changes against the reference's NoCutoff semantics, measured in this run on chr1_50k (BASELINE
+        # config 2) with the exact all-pairs kernel as the yardstick -- outside the timed region, like the CPU baseline
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from cutoff_tolerance import compare
+            r = compare("chr1_50k", None, args.cutoff)
+            out["truncation"] = {
+                "workload": "chr1_50k", "cutoff_nm": args.cutoff, "against": "NoCutoff (exact all-pairs kernel), same start",
+                "start": {k: r["start"][k] for k in ("dE_total", "dE_per_bead", "e_total_nocutoff", "dF_rms", "dF_max",
+                                                      "dF_rel_l2", "F_rms_nocutoff")},
+                "converged": {k: r["converged"][k] for k in ("iterations_cutoff", "iterations_nocutoff", "dE_rel", "d_rg_rel",
+                                                              "d_bond_mean_nm")},
+                "asserted_by": "tests/test_gpu_cutoff.py",
+            }
+        except Exception as exc:  # noqa: BLE001
+            out["truncation"] = {"error": repr(exc)}
     if world > 1 and not dd and not args.no_dd_leg:  # every rank takes part; rank 0 carries the result
         leg = dd_leg(args, rank, world, local_rank, tdev, barrier)
         if rank == 0:
