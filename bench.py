@@ -265,6 +265,7 @@ def main():
     if args.warmup > 0:
         eng.minimize(tolerance=0.0, max_iters=args.warmup)
     eng.set_option("profile", args.profile_every)
+    n3_before = eng.get_option("n3_launches")
     barrier()
     t0 = time.perf_counter()
     st = eng.minimize(tolerance=0.0, max_iters=args.steps)
@@ -299,8 +300,10 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))["bytes_per_launch"]
                 except Exception:
                     traffic = None
-            det = bool(eng.get_option("deterministic"))
-            kname = "k_nb_allpairs" if args.cutoff <= 0 else ("k_nb_clusters_j" if (det or dd) else "k_nb_n3")
+            # the cell-list path picks its pair kernel per state: name the one that ran, and how often
+            n3_share = (eng.get_option("n3_launches") - n3_before) / max(st.kernel_launches[K_NONBONDED], 1)
+            kname = ("k_nb_allpairs" if args.cutoff <= 0 else "k_nb_n3" if n3_share > 0.99 else "k_nb_clusters_j" if n3_share < 0.01
+                     else f"k_nb_n3 ({100 * n3_share:.0f} % of the launches: the dense phase), then k_nb_clusters_j")
             roofline = {"bound": "hbm", "kernel": kname,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc pass (profiles/nb_traffic.json)"
@@ -315,7 +318,7 @@ def main():
                                          "frac": tf / VALU_PEAK_TFLOPS, "unique_pairs_within_cutoff": pairs,
                                          "pair_candidates": census["pair_candidates"],
                                          "flop_per_pair": FLOP_PER_PAIR}
-                if n == 200000:  # issue-slot occupancy of the same kernel from the committed PMC pass
+                if n == 200000:  # instruction counters of the half-shell kernel from the committed PMC pass
                     try:
                         roofline["valu_view"]["issue_from_committed_profile"] = json.load(
                             open(os.path.join(ROOT, "profiles", "nb_valu.json")))

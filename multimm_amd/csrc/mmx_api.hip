@@ -603,6 +603,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "use_graph") *value = h->use_graph;
+    else if (k == "n3_launches") *value = (double)h->n3_launches;   // read-only: how often the half-shell kernel ran
     else if (k == "dd_halo") *value = h->dd_halo;
     else if (k == "dd_skin") *value = h->dd_skin;
     else if (k == "dd_skin_now") *value = h->dd_skin_cur;

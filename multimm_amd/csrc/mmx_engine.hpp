@@ -221,6 +221,7 @@ template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
     if (use_n3(h)) {
+        h->n3_launches++;
         launch_nb_n3_p<PMODE>(h, grid);
         return;
     }

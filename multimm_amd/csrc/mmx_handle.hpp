@@ -184,6 +184,7 @@ struct mmx_handle_s {
     int last_max_per_cell = -1;                  // largest cell seen at the last poll (sizes the in-LDS sort)
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
     int last_clusters = -1;
+    long long n3_launches = 0;                   // launches of the half-shell kernel since the handle was created (option n3_launches)
     int last_ncells = -1;                        // cells of the grid at the last poll (picks the pair kernel, see use_n3)
     float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
     int fstride = 0;
