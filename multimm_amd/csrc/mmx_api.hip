@@ -103,7 +103,6 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 16 + 64;
             HIPCHK(h, dalloc(&h->n3_items, (size_t)h->n3_max_items));
             h->n_cus = prop.multiProcessorCount;
-            HIPCHK(h, dalloc(&h->n3_dbg, (size_t)8));
         }
         HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all * 2)); // interleaved {lo, hi} box records
         HIPCHK(h, dalloc(&h->cl_hi, (size_t)1));             // (kept as a kernel argument, unused)
@@ -223,7 +222,7 @@ int mmx_destroy(mmx_handle h) try {
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->xg) (void)hipFree(h->xg);
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
-                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->n3_dbg, (void *)h->dd_boxes,
+                    (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref})
         if (p) (void)hipFree(p);
@@ -612,12 +611,6 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
     else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
-    else if (k.rfind("n3_dbg", 0) == 0 && k.size() == 7 && h->n3_dbg) { // n3_dbg0..7: cycle counters of k_nb_n3 (diagnosis)
-        unsigned long long v[8];
-        HIPCHK(h, hipMemcpy(v, h->n3_dbg, sizeof(v), hipMemcpyDeviceToHost));
-        *value = (double)v[k[6] - '0'];
-        if (k[6] == '7') HIPCHK(h, hipMemset(h->n3_dbg, 0, sizeof(v))); // reading the last one clears them
-    }
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)

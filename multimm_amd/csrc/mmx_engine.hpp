@@ -196,11 +196,11 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
         if (h->nb_skip_energy)                                                                              \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               h->nb_scale, cap, (h->nb_variant >> 16) & 255, h->n3_dbg);                   \
+                               h->nb_scale, cap, (h->nb_variant >> 16) & 255);                              \
         else                                                                                                \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               h->nb_scale, cap, (h->nb_variant >> 16) & 255, h->n3_dbg);                   \
+                               h->nb_scale, cap, (h->nb_variant >> 16) & 255);                              \
     } while (0)
     if (P.use_ev && P.use_gauss) N3(true, true);
     else if (P.use_ev) N3(true, false);

@@ -192,7 +192,6 @@ struct mmx_handle_s {
     int n3_cap = 0;                              // LDS force window of k_nb_n3 in clusters (0: not usable on this device)
     N3Item *n3_items = nullptr;                  // its work items (k_n3_items, after every cell scan)
     int n3_max_items = 0, n_cus = 0;
-    unsigned long long *n3_dbg = nullptr;        // [8] cycle counters of k_nb_n3 (nb_variant diagnosis bit)
     GridParams *grid = nullptr;  // [2]: grid of this build / of the next one (ping-pong)
     GridParams *gcur = nullptr;  // grid the last enqueued build used (what the pair kernel reads)
     int build_idx = 0;

@@ -32,6 +32,9 @@
 // whose order is not fixed: results are reproducible to rounding, not bitwise.  `deterministic = 1` selects
 // k_nb_clusters_j, which is.
 //
+// `diag` (nb_variant >> 16; timing diagnosis only, results are wrong with any bit but 64): 1 no flush atomics, 2 no LDS
+// adds (and no j-side FMAs), 4 no pair arithmetic, 8 no i-side atomics, 16 cull only, 64 items in ascending order.
+//
 // Self tile: the 8 beads of the i-cluster also enter the stream as j beads.  All 64 ordered pairs of that tile are
 // evaluated, so the i side alone gets the complete intra-cluster force; the j-side sums of those lanes are dropped
 // and their energies weighted 1/2.  The r = 0 self pair has zero force and a known energy that is taken out in the
@@ -262,9 +265,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           const N3Item *__restrict__ items, MinState *__restrict__ st,
                                                           float *__restrict__ fsort, const int fstride,
                                                           double *__restrict__ part, const float sc, const int cap,
-                                                          const int diag = 0, unsigned long long *__restrict__ dbg = nullptr) {
+                                                          const int diag = 0) {
     if (st->phase >= PH_DONE) return;
-    (void)dbg;
     // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
     // 8 slots are a dummy cluster), two box buffers [cap + 1][2] float4, four id buffers [cap + 8] int
     extern __shared__ __attribute__((aligned(16))) int s_f[];
