@@ -9,7 +9,8 @@
 // float atomics") -- one flush per 64-bead batch would need ~280 MB of them per evaluation at 200 000 beads, one flush
 // per work item needs a tenth of that, in 256-byte contiguous wave instructions.
 //
-// Work item (k_n3_items builds the list after every cell scan) = a run of up to 16 consecutive clusters of one ROW of
+// Work item (n3_items_block builds the list after every cell scan, inside the launch of the in-cell ordering) = a run of
+// up to 16 consecutive clusters of one ROW of
 // the cell grid (x is the fastest cell index, so a row is one contiguous stretch of the cell-sorted cluster list); the
 // run may span several cells when they are sparse.  Half shell by cells: the j candidates of the run are, in
 // increasing cluster order, (0) the clusters of its own row from the run's first cluster to the end of the cell after
@@ -21,10 +22,13 @@
 // away, so geometry alone keeps the half shell exact.  A run whose candidates do not fit the window is processed in
 // several passes over slices of the index space (only the densest cells, e.g. the lattice start).
 //
-// Execution: ONE persistent workgroup of 16 waves per CU pulls items from a global queue.  The candidates' boxes and
-// ids of the NEXT unit (item, pass) are staged into a second LDS buffer by each wave as soon as it runs out of
-// i-clusters of the current one (which it grabs one at a time from an LDS counter), so the dependent global loads of
-// a unit's set-up hide under the pair arithmetic of the other waves; a unit costs two workgroup barriers.
+// Execution: ONE persistent workgroup of 16 waves per CU pulls items from a global queue (from its far end: descending
+// rows).  A unit = (item, slice of its candidate index space).  Two units are in flight per workgroup, each with its own
+// LDS force window and candidate buffers: waves grab the i-clusters of a unit one at a time from an LDS counter and move on
+// to the next unit when none is left; the LAST wave to leave a unit opens the flush of its window and stages the unit
+// after next (queue pop, item descriptor, candidate boxes and ids) while the others compute; the flush is done, a chunk
+// at a time, by the waves that wait for that window.  No workgroup barrier in the steady state; every wait is a bounded
+// spin that raises an error (failed evaluation) instead of hanging.
 //
 // LDS accumulation is int32 fixed point (2^-13 kJ/mol/nm): ds_add_f32 is serialised on gfx950 (measured,
 // scripts/ubench/lds_atomic.hip: 193 cycles per wave instruction against 4.5-7 for ds_add_u32), and integer sums do
