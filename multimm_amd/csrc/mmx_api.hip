@@ -1140,7 +1140,7 @@ int mmx_cluster_census(mmx_handle h, int64_t *n_clusters, double *tiles_candidat
     HIPCHK(h, dalloc(&dout, 3));
     const int ncl = h->st_host->n_clusters;
     hipLaunchKernelGGL(k_tile_census, dim3(1024), dim3(256), 0, h->stream, ncl, h->cl_lo, h->cl_hi, h->cstart,
-                       h->spos4, h->gcur, h->P.rc2max * h->nb_scale * h->nb_scale, dout);
+                       h->spos4, h->gcur, h->P.rc2max, dout);
     double res[3] = {0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

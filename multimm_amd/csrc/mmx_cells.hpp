@@ -409,8 +409,7 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, int own_lo, int n_own,
-                                              const unsigned long long *keys = nullptr, const float scale = 1.f,
-                                              const float3 org = float3{0.f, 0.f, 0.f}) {
+                                              const unsigned long long *keys = nullptr) {
     const int ncl = (cnt + 7) >> 3;
     for (int e = tid; e < ncl * 8; e += nthr) {
         float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
@@ -418,14 +417,7 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
         if (e < cnt) {
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
             const int b = keys ? (int)(unsigned)(keys[e] & 0xffffffffull) : perm[s + e];
-            p = pos4[b];
-            // the pair kernel may work in scaled length units (see k_nb_clusters_j, LEAN): scale = 1 otherwise.  Scaled
-            // coordinates are taken relative to the centre of the grid (`org`, the same for every bead of the build:
-            // the pair kernels only see differences): the product is rounded at half the magnitude, which halves the one
-            // rounding the scaled units add to the state ("where the device path stands")
-            p.x = (p.x - org.x) * scale;
-            p.y = (p.y - org.y) * scale;
-            p.z = (p.z - org.z) * scale;
+            p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
             nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
         }
         spos4[(size_t)cb * 8 + e] = p;
@@ -536,17 +528,13 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
                                                  float4 *__restrict__ cl_hi, int own_lo, int n_own,
                                                  const unsigned long long *__restrict__ okeys,
-                                                 const int *__restrict__ biglist, const float scale,
+                                                 const int *__restrict__ biglist,
                                                  MinState *__restrict__ st) {
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
     const int ncells = G.ncells;
     const unsigned long long kmax = ~0ull;
-    // common origin of the scaled cluster coordinates (none for the unscaled instances: their positions stay exact)
-    const float3 org = scale != 1.f ? float3{G.ox + 0.5f * (float)G.nx * G.h, G.oy + 0.5f * (float)G.ny * G.h,
-                                             G.oz + 0.5f * (float)G.nz * G.h}
-                                    : float3{0.f, 0.f, 0.f};
 
     // ---- pass A: one wave per small cell
     for (int c = bid * 4 + wave; c < ncells; c += nblk * 4) {
@@ -570,7 +558,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own, nullptr, scale, org);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -591,8 +579,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf,
-                          scale, org);
+            emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -642,8 +629,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         }
         else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
         // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, nullptr,
-                      scale, org);
+        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
     }
 }
 
@@ -656,11 +642,11 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
-                                                    const int *__restrict__ biglist, const float scale,
+                                                    const int *__restrict__ biglist,
                                                     MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, scale, st);
+                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st);
 }
 
 } // namespace mmx

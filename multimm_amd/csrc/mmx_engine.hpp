@@ -44,7 +44,7 @@ int nb_launch_opt(const mmx_handle_s *h) {
     const int opt = ((h->nb_variant & 32) ? 0 : 2) | ((h->nb_variant & 64) ? 0 : 4) | ((h->nb_variant & 128) ? 0 : 8) |
                     ((h->nb_variant & 256) ? 16 : 0) | ((h->nb_variant & 512) ? 32 : 0) |
                     ((h->nb_variant & 1024) ? 64 : 0) | ((h->nb_variant & 2048) ? 128 : 0);
-    if (h->nb_force_plain) return 10; // clamp mask + per-bead cull, per-bead energies: not LEAN, length scale 1
+    if (h->nb_force_plain) return 10; // clamp mask + per-bead cull, per-bead energies: not LEAN
     if (opt == 142) return 142;
     switch (opt & 127) {
     case 14: case 30: case 46: case 22: case 78: case 62: case 6: case 12: case 10: return opt & 127;
@@ -97,20 +97,15 @@ void refresh_params(mmx_handle_s *h) {
     Q.chb_form = h->forms[MMX_SEL_CHB];
     Q.generic_pairs = ((P.use_ev && Q.ev_form != 0) || (h->has_cob && Q.cob_form != 0) ||
                        (h->has_scb && Q.scb_form != 0)) ? 1 : 0;
-    // the default cluster-kernel instance with Gaussians on works in scaled length units (exp2(-r'^2))
-    // (the kernel's LEAN condition: clamp mask, one cutoff, merged energies, no rank-2 / no-sweep variant)
+    // the kernel's LEAN condition: clamp mask, one cutoff, merged energies, no rank-2 / no-sweep variant
     h->nb_force_plain = false;
     const int lo = nb_launch_opt(h);
     const bool lean = !Q.generic_pairs && h->nb_variant != 1 && !all_pairs(h) &&
                       (!(P.use_ev && P.use_gauss) || P.ev_rc2 == P.g_rc2) && (lo & 2) && (lo & 4) && !(lo & 1) && !(lo & 16);
     h->nb_lean = lean;
-    h->nb_scale = (lean && P.use_gauss) ? std::sqrt(-P.g_c2) : 1.f;
-    // the clamp mask needs (scaled cutoff)^2 well below 1e6: an extreme r_comp falls back to a non-lean instance
-    h->nb_force_plain = lean && P.use_gauss && !(P.rc2max * h->nb_scale * h->nb_scale < 1e5f);
-    if (h->nb_force_plain) {
-        h->nb_scale = 1.f;
-        h->nb_lean = false;
-    }
+    // the clamp mask needs cutoff^2 well below 1e6 nm^2: anything beyond falls back to a non-lean instance
+    h->nb_force_plain = lean && !(P.rc2max < 1e5f);
+    if (h->nb_force_plain) h->nb_lean = false;
 }
 
 constexpr double kN3MinBeadsPerCell = 60.0;
@@ -196,11 +191,11 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
         if (h->nb_skip_energy)                                                                              \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               h->nb_scale, cap, (h->nb_variant >> 16) & 255);                              \
+                               cap, (h->nb_variant >> 16) & 255);                              \
         else                                                                                                \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               h->nb_scale, cap, (h->nb_variant >> 16) & 255);                              \
+                               cap, (h->nb_variant >> 16) & 255);                              \
     } while (0)
     if (P.use_ev && P.use_gauss) N3(true, true);
     else if (P.use_ev) N3(true, false);
@@ -227,13 +222,13 @@ void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     }
 #define NBJ(PM, EV, GA, SC, OPT)                                                                            \
     hipLaunchKernelGGL((k_nb_clusters_j<PM, EV, GA, SC, OPT>), dim3(grid), dim3(256), 0, h->stream, P,      \
-                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part, h->nb_scale)
+                       h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g, h->part)
 #define NBC(EV, GA)                                                                                         \
     do {                                                                                                    \
         if (h->Q.generic_pairs) { /* non-default functional forms: one generic instance per term combination */ \
             hipLaunchKernelGGL((k_nb_clusters_j<0, EV, GA, false, 14, true>), dim3(grid), dim3(256), 0,       \
                                h->stream, P, h->spos4, h->cl_lo, h->cl_hi, h->cstart, h->gcur, h->st, h->g,  \
-                               h->part, 1.f, h->formp);                                                     \
+                               h->part, h->formp);                                                     \
         } else if (h->nb_variant == 1)                                                                      \
             hipLaunchKernelGGL((k_nb_cells<PMODE, EV, GA>), dim3(grid), dim3(192), 0, h->stream, P, h->pos4, \
                                h->perm, h->start, h->items, h->gcur, h->st, h->g, h->part);                 \
@@ -623,21 +618,21 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             if (small_cells)
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->n3_items,
+                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
                                    h->n3_max_items, h->st);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->n3_items,
+                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
                                    h->n3_max_items, h->st);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->nb_scale, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
         h->gcur = cur;
         h->build_idx++;
     }

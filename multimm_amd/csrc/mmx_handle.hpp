@@ -177,7 +177,6 @@ struct mmx_handle_s {
     int2 *items = nullptr;
     int *cstart = nullptr;                       // cluster offsets per cell
     unsigned long long *okeys = nullptr;         // sort keys in cell order (written by k_cell_fill)
-    float nb_scale = 1.f;                        // length scale of spos4 / cluster boxes (see k_nb_clusters_j, LEAN)
     bool nb_force_plain = false;                 // scaled units unusable (extreme r_comp): unscaled, non-lean instance
     bool nb_skip_energy = false;                 // MD steps between reports: pair forces only (default instance)
     int *biglist = nullptr;                      // ids of the cells of > 64 beads (written by k_cell_scan)

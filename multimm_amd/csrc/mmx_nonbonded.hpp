@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
                                                        const int *__restrict__ cstart,
                                                        const GridParams *__restrict__ grid,
                                                        const MinState *__restrict__ st, float *__restrict__ g,
-                                                       double *__restrict__ part, const float sc = 1.f,
+                                                       double *__restrict__ part,
                                                        const FormParams *__restrict__ Qd = nullptr) {
     if (st->phase >= PH_DONE) return;
     FormParams Q;
@@ -336,26 +336,24 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
     float4 *ring = s_ring[wave];
     const float *arow = s_arow[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // LEAN + GAUSS instances work in length units scaled by sc = sqrt(log2(e) / (2 r_comp^2)): spos4 and the cluster
-    // boxes arrive scaled (k_cell_order), the Gaussian becomes exp2(-r'^2) -- no multiply in front of v_exp -- and
-    // every other constant absorbs the scale.  All other instances are launched with sc = 1.
-    const float sc2 = sc * sc;
-    const float rc2 = P.rc2max * sc2;
+    // spos4 holds the beads' positions as they are (nm, bit for bit): the pair terms see the state without any rounding of
+    // their own.  (Round 1 worked in lengths scaled by sqrt(log2(e) / (2 r_comp^2)), which saves the multiply in front
+    // of v_exp -- 1 of 27 operations per pair, ~2 % of the kernel -- and costs one rounding of every coordinate at its
+    // full magnitude: 3x the force error in relative L2, 25x in the maximum)
+    const float rc2 = P.rc2max;
     const float4 far4 = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(-8 + 2)); // label 0: no amplitude
     const int far_cl = P.n_all; // cluster slot n_all of spos4 holds 8 copies of far4 (written once by mmx_create)
     const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
     const float ev_c = P.ev_eps * s3 * s3; // eps*sigma^6 (PMODE 6)
     const float tiny = 1e-20f;              // keeps r = 0 finite (self pair, coincident beads)
     // LEAN: forces are accumulated divided by the power p (EV on) and multiplied back at the fold
-    const float sc6 = sc2 * sc2 * sc2;
-    const float escale = (LEAN && EV && PMODE == 6) ? ev_c * sc6 : 1.f; // unit of the EV energies summed in the loop
-    const float pscale = (LEAN && EV) ? P.ev_power * escale * sc : 1.f;   // unit of the accumulated forces
-    const float g_k = P.g_inv_rc2 / (sc * pscale);
-    const float rs_s = P.ev_rs * sc, sigma_s = P.ev_sigma * sc;
+    const float escale = (LEAN && EV && PMODE == 6) ? ev_c : 1.f; // unit of the EV energies summed in the loop
+    const float pscale = (LEAN && EV) ? P.ev_power * escale : 1.f; // unit of the accumulated forces
+    const float g_k = P.g_inv_rc2 / pscale;
     // step(rc^2 - r^2) = sat(1e30*(rc^2 - r^2)): exact for every representable r^2 (1 ulp of 0.36 * 1e30 >> 1)
     const float nbig = -1e30f;
-    const float cut_all = 1e30f * fminf(rc2, 1e6f), cut_ev = 1e30f * fminf(P.ev_rc2 * sc2, 1e6f),
-                cut_g = 1e30f * fminf(P.g_rc2 * sc2, 1e6f);
+    const float cut_all = 1e30f * fminf(rc2, 1e6f), cut_ev = 1e30f * fminf(P.ev_rc2, 1e6f),
+                cut_g = 1e30f * fminf(P.g_rc2, 1e6f);
     double acc_ev = 0.0, acc_g = 0.0;
 
     // Optional XCD-aware work mapping (nb_variant bit 2048; OFF by default): workgroups go round-robin to the 8
@@ -529,19 +527,19 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
                         const float rinv = __builtin_amdgcn_rsqf(r2t);
                         float fs = 0.f;
                         if (EV) {
-                            const float u = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, rs_s));
+                            const float u = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, P.ev_rs));
                             float E;
                             if (PMODE == 6) { // in units of eps*sigma^6: the constant joins the scale applied at the fold
                                 const float u2 = u * u;
                                 E = (u2 * u2) * u2;
                             } else {
-                                E = P.ev_eps * ev_pow<PMODE>(sigma_s * u, P.ev_power);
+                                E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * u, P.ev_power);
                             }
                             if (!NOENERGY) ee[0] = fmaf(E, in, ee[0]);
                             fs = E * (u * rinv);
                         }
                         if (GAUSS) {
-                            const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(-r2t); // scaled units: sc^2 = -g_c2
+                                                        const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(r2t * P.g_c2);
                             if (!NOENERGY) eg[0] = fmaf(-gg, in, eg[0]);
                             fs = fmaf(-gg, g_k, fs);
                         }
@@ -605,16 +603,16 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
         const bool own = bead >= 0;
         // The self pair (r = 0, zero force) was swept with everything else: remove its energy (6400 kJ/mol per bead
         // with the default parameters, against a few kJ/mol of genuine pair energy).  The value subtracted is formed
-        // by the very operations the loop used -- same scaled constants, same order, before the common factor is
+        // by the very operations the loop used -- same constants, same order, before the common factor is
         // applied -- so that nothing systematic is left of it (a value that is merely equal in exact arithmetic
         // leaves ~1e-7 * 6400 kJ/mol per bead behind, all of one sign).
         if (own && EV && !FORMS && !NOENERGY) {
-            const float us = __builtin_amdgcn_rcpf(fmaf(tiny, __builtin_amdgcn_rsqf(tiny), LEAN ? rs_s : P.ev_rs));
+            const float us = __builtin_amdgcn_rcpf(fmaf(tiny, __builtin_amdgcn_rsqf(tiny), P.ev_rs));
             if (PMODE == 6) {
                 const float u2 = us * us;
                 tev -= LEAN ? (u2 * u2) * u2 : (u2 * u2) * (u2 * ev_c);
             } else {
-                tev -= P.ev_eps * ev_pow<PMODE>((LEAN ? sigma_s : P.ev_sigma) * us, P.ev_power);
+                tev -= P.ev_eps * ev_pow<PMODE>(P.ev_sigma * us, P.ev_power);
             }
         }
         tev *= escale; // LEAN, p = 6: the loop summed (sigma-free) u^6

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
                                                      float4 *__restrict__ cl_hi, int own_lo, int n_own,
                                                      const unsigned long long *__restrict__ okeys,
-                                                     const int *__restrict__ biglist, const float scale,
+                                                     const int *__restrict__ biglist,
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
                                                      MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, scale, st);
+                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st);
 }
 
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           const float4 *__restrict__ cl_box,
                                                           const N3Item *__restrict__ items, MinState *__restrict__ st,
                                                           float *__restrict__ fsort, const int fstride,
-                                                          double *__restrict__ part, const float sc, const int cap,
+                                                          double *__restrict__ part, const int cap,
                                                           const int diag = 0) {
     if (st->phase >= PH_DONE) return;
     // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
@@ -308,31 +308,28 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     unsigned short *list = s_list[wave];
     float4 *ring = s_ring[wave];
     const float *arow = s_arow[wave];
-    // scaled length units, factored constants: exactly the LEAN instance of k_nb_clusters_j
-    const float sc2 = sc * sc;
-    const float rc2 = P.rc2max * sc2;
+    // factored constants: exactly the LEAN instance of k_nb_clusters_j
+    const float rc2 = P.rc2max;
     const float s3 = P.ev_sigma * P.ev_sigma * P.ev_sigma;
     const float ev_c = P.ev_eps * s3 * s3;
     const float tiny = 1e-20f;
-    const float sc6 = sc2 * sc2 * sc2;
-    const float escale = (EV && PMODE == 6) ? ev_c * sc6 : 1.f;
-    const float pscale = EV ? P.ev_power * escale * sc : 1.f;
-    const float g_k = P.g_inv_rc2 / (sc * pscale);
-    const float fix_k = pscale * kN3Fix;     // scaled pair-loop units -> fixed point
+    const float escale = (EV && PMODE == 6) ? ev_c : 1.f;
+    const float pscale = EV ? P.ev_power * escale : 1.f;
+    const float g_k = P.g_inv_rc2 / pscale;
+    const float fix_k = pscale * kN3Fix;     // pair-loop units -> fixed point
     const float fix_lim = kN3FixLim / fix_k; // largest |batch sum| the fixed-point path takes
     const float unfix = -1.f / kN3Fix;       // fixed point -> force on the j bead (reaction: minus)
-    const float rs_s = P.ev_rs * sc, sigma_s = P.ev_sigma * sc;
     const float nbig = -1e30f;
     const float cut_all = 1e30f * fminf(rc2, 1e6f);
     // energy of the r = 0 self pair, by the very operations of the pair loop
     float eself = 0.f;
     if (EV && !NOENERGY) {
-        const float us = __builtin_amdgcn_rcpf(fmaf(tiny, __builtin_amdgcn_rsqf(tiny), rs_s));
+        const float us = __builtin_amdgcn_rcpf(fmaf(tiny, __builtin_amdgcn_rsqf(tiny), P.ev_rs));
         if (PMODE == 6) {
             const float u2 = us * us;
             eself = (u2 * u2) * u2;
         } else {
-            eself = P.ev_eps * ev_pow<PMODE>(sigma_s * us, P.ev_power);
+            eself = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * us, P.ev_power);
         }
     }
     double acc_ev = 0.0, acc_g = 0.0;
@@ -621,19 +618,19 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 const float rinv = __builtin_amdgcn_rsqf(r2t);
                                 float fs = 0.f;
                                 if (EV) {
-                                    const float uu = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, rs_s));
+                                    const float uu = __builtin_amdgcn_rcpf(fmaf(r2t, rinv, P.ev_rs));
                                     float E;
                                     if (PMODE == 6) {
                                         const float u2 = uu * uu;
                                         E = (u2 * u2) * u2;
                                     } else {
-                                        E = P.ev_eps * ev_pow<PMODE>(sigma_s * uu, P.ev_power);
+                                        E = P.ev_eps * ev_pow<PMODE>(P.ev_sigma * uu, P.ev_power);
                                     }
                                     if (!NOENERGY) eb = fmaf(E, in, eb);
                                     fs = E * (uu * rinv);
                                 }
                                 if (GAUSS) {
-                                    const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(-r2t);
+                                    const float gg = arow[s * 8 + lj] * __builtin_amdgcn_exp2f(r2t * P.g_c2);
                                     if (!NOENERGY) gb = fmaf(-gg, in, gb);
                                     fs = fmaf(-gg, g_k, fs);
                                 }

@@ -14,10 +14,11 @@ from multimm_amd.engine import Engine, engine_for, TERM_NAMES
 
 pytestmark = pytest.mark.gpu
 
-# fp32 tolerances of the parity claim: per-term energies within 2e-6 of sum_t |E_t| (+1e-3 kJ/mol), forces within 2e-5
-# of the largest force component (+5e-3 kJ/mol/nm).  Measured: <= 3e-7 and <= 4e-6 on every kernel path.
+# fp32 tolerances of the parity claim: per-term energies within 2e-6 of sum_t |E_t| (+1e-3 kJ/mol), forces within 4e-6
+# of the largest force component (+2e-3 kJ/mol/nm).  Measured: <= 3e-7 and <= 1e-6 on every kernel path (the pair
+# kernels read the positions unscaled, bit for bit: round 1's scaled units needed 2e-5 here).
 E_RTOL, E_ATOL = 2e-6, 1e-3
-F_RTOL, F_ATOL = 2e-5, 5e-3
+F_RTOL, F_ATOL = 4e-6, 2e-3
 # The Hilbert LATTICE start puts thousands of pairs at exactly the cutoff distance (6 lattice steps = 0.6 nm), where
 # the truncated potential jumps by E_ev(r_c) = 1.3e-3 kJ/mol: whether such a pair counts is decided by the last bit of
 # r^2, in fp32 here and in fp64 in the oracle.  Only that test gets the wider energy band.
@@ -540,10 +541,9 @@ def test_ensemble_loop_like_the_reference(tmp_path):
         assert (a.iterations, a.evaluations, a.e_initial, a.e_final) == (b.iterations, b.evaluations, b.e_initial, b.e_final)
 
 
-def test_extreme_compartment_radius_falls_back_to_unscaled_kernel():
-    """The default pair-kernel instance works in length units scaled by sqrt(log2(e)/2)/r_comp; a tiny r_comp (here
-    POL_HARMONIC_BOND_R0 = 1e-4 nm => r_comp = 1.5e-4 nm) would push the scaled cutoff beyond what the clamp mask
-    represents, so the engine must pick the unscaled instance -- and still agree with the oracle."""
+def test_extreme_compartment_radius():
+    """A tiny r_comp (here POL_HARMONIC_BOND_R0 = 1e-4 nm => r_comp = 1.5e-4 nm): the Gaussian's exponent constant
+    -log2(e) / (2 r_comp^2) = -3.2e7 nm^-2 underflows every pair to zero without producing anything non-finite."""
     s = synthetic_system("gw_200k", n_beads=1500, jitter=0.03, seed=8, COB_USE_COMPARTMENT_BLOCKS=True,
                          POL_HARMONIC_BOND_R0=1e-4, POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False,
                          SC_USE_SPHERICAL_CONTAINER=False, IBL_USE_B_LAMINA_INTERACTION=False)
