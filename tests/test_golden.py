@@ -15,7 +15,7 @@ from multimm_amd.system import ChromatinSystem, ForceFieldParams
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 META = json.load(open(os.path.join(HERE, "golden.json")))
 CASES = sorted(META["cases"])
-E_RTOL, E_ATOL, F_RTOL, F_ATOL = 2e-6, 1e-3, 2e-5, 5e-3
+E_RTOL, E_ATOL, F_RTOL, F_ATOL = 2e-6, 1e-3, 4e-6, 2e-3
 
 
 def load_case(name):

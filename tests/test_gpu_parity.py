@@ -15,17 +15,20 @@ from multimm_amd.engine import Engine, engine_for, TERM_NAMES
 pytestmark = pytest.mark.gpu
 
 # fp32 tolerances of the parity claim: per-term energies within 2e-6 of sum_t |E_t| (+1e-3 kJ/mol), forces within 4e-6
-# of the largest force component (+2e-3 kJ/mol/nm).  Measured: <= 3e-7 and <= 1e-6 on every kernel path (the pair
-# kernels read the positions unscaled, bit for bit: round 1's scaled units needed 2e-5 here).
+# of the largest force component (+2e-3 kJ/mol/nm).  Measured (run with -s: every check prints an ACC line): <= 3e-7
+# and <= 3.9e-6, typically 1e-6, on every kernel path (the pair kernels read the positions unscaled, bit for bit:
+# round 1's scaled units needed 2e-5 here).
 E_RTOL, E_ATOL = 2e-6, 1e-3
 F_RTOL, F_ATOL = 4e-6, 2e-3
 # The Hilbert LATTICE start puts thousands of pairs at exactly the cutoff distance (6 lattice steps = 0.6 nm), where
 # the truncated potential jumps by E_ev(r_c) = 1.3e-3 kJ/mol: whether such a pair counts is decided by the last bit of
-# r^2, in fp32 here and in fp64 in the oracle.  Only that test gets the wider energy band.
+# r^2, in fp32 here and in fp64 in the oracle.  Only that test gets the wider energy band -- and a wider force band:
+# the Gaussian's force does not vanish at the cutoff either (measured 5.1e-6 of max |F|, the same on both kernels).
 E_RTOL_AT_CUTOFF = 3e-5
+F_RTOL_AT_CUTOFF = 1e-5
 
 
-def _check(system, cutoff, label, e_rtol=E_RTOL, e_atol=E_ATOL):
+def _check(system, cutoff, label, e_rtol=E_RTOL, e_atol=E_ATOL, f_rtol=F_RTOL):
     from oracle.oracle import Oracle
     s = system.with_ff(NB_CUTOFF=cutoff)
     et_ref, F_ref = Oracle(s).eval()
@@ -43,7 +46,9 @@ def _check(system, cutoff, label, e_rtol=E_RTOL, e_atol=E_ATOL):
             assert abs(et[t] - et_ref[t]) <= e_rtol * scale_e + e_atol, (
                 f"{label} {kernel}: term {TERM_NAMES[t]} gpu={et[t]!r} ref={et_ref[t]!r}")
         ferr = np.abs(F.astype(np.float64) - F_ref).max()
-        assert ferr <= F_RTOL * fmax + F_ATOL, f"{label} {kernel}: force err {ferr} (max |F| {fmax})"
+        l2 = np.sqrt(((F - F_ref) ** 2).sum() / max((F_ref ** 2).sum(), 1e-300))
+        print(f"ACC {label} {kernel}: max err / max|F| = {ferr / max(fmax, 1e-300):.2e} (abs {ferr:.2e}), rel L2 = {l2:.2e}")
+        assert ferr <= f_rtol * fmax + F_ATOL, f"{label} {kernel}: force err {ferr} (max |F| {fmax})"
     return et, F
 
 
@@ -56,7 +61,7 @@ ALL_ON = dict(SC_USE_SPHERICAL_CONTAINER=True, COB_USE_COMPARTMENT_BLOCKS=True, 
 def test_all_terms_lattice(n, cutoff):
     """Hilbert lattice start (every angle exactly pi or pi/2, every bond exactly r0)."""
     _check(synthetic_system("gw_200k", n_beads=n, **ALL_ON), cutoff, f"lattice n={n} rc={cutoff}",
-           e_rtol=E_RTOL_AT_CUTOFF if cutoff > 0 else E_RTOL)
+           e_rtol=E_RTOL_AT_CUTOFF if cutoff > 0 else E_RTOL, f_rtol=F_RTOL_AT_CUTOFF if cutoff > 0 else F_RTOL)
 
 
 @pytest.mark.parametrize("n", [64, 512, 4096, 20000])
