@@ -108,7 +108,9 @@ void refresh_params(mmx_handle_s *h) {
     if (h->nb_force_plain) h->nb_lean = false;
 }
 
-constexpr double kN3MinBeadsPerCell = 60.0;
+// choice of the pair kernel: see use_n3
+constexpr double kN3CrowdedBeadsPerCell = 60.0, kN3MinBeadsPerCell = 20.0;
+constexpr int kN3MinBeadsCrowded = 80000, kN3MinBeads = 150000;
 
 // The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
 // caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
@@ -118,11 +120,23 @@ bool use_n3(const mmx_handle_s *h) {
     if (h->nb_variant & 8192) return false;
     if (h->nb_variant & 4096) return true;
     if (h->deterministic || (h->nb_variant & 0xffff & ~(4096 | 8192)) != 0) return false;
-    // Which kernel is faster depends on how crowded the cells are (scripts/nb_states.py, gw_200k along a minimization):
-    // at 150 beads per grid cell (lattice start) the half-shell kernel takes 0.87 of the full-shell kernel's time, from
-    // ~50 per cell on they are level -- and the half-shell path costs two small launches more (items, unsort, ~9 us).
-    // The last poll's cell count decides; both kernels compute the same forces to rounding.
-    return h->last_ncells <= 0 || (double)h->n >= kN3MinBeadsPerCell * (double)h->last_ncells;
+    // Which kernel is faster depends on the size of the system and on how crowded the cells are (scripts/kernel_choice.py:
+    // minimizations from the lattice with either kernel forced, iterations/s half shell against full shell):
+    //   beads      first 200 iterations (150 -> 50 beads per grid cell)    1500-3000 iterations (-> 25 per cell)
+    //   5 000           -13 %                                                  -12 %
+    //   50 000          - 4 %                                                  - 8 %
+    //   80 000          + 1 %                                                  - 5 %
+    //   110 000         + 6 %                                                    0
+    //   140 000         + 5 %                                                  + 1 %
+    //   200 000         + 6 %                                                  + 2 %
+    //   1 000 000       + 6 %                                                  + 6 %
+    // (the persistent workgroups of the half-shell kernel want several work items each; its path costs one small launch
+    // more.)  The last poll's cell count decides; both kernels compute the same forces to rounding.  Below 20 beads per
+    // cell nothing was measured: the full-shell kernel, which needs no atomics, stays.
+    if (h->last_ncells <= 0) return h->n >= kN3MinBeadsCrowded; // before the first poll: the Hilbert start is crowded
+    const double per_cell = (double)h->n / (double)h->last_ncells;
+    if (per_cell >= kN3CrowdedBeadsPerCell) return h->n >= kN3MinBeadsCrowded;
+    return per_cell >= kN3MinBeadsPerCell && h->n >= kN3MinBeads;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }

@@ -135,22 +135,27 @@ def test_half_shell_kernel_dense_cells_and_overlapping_beads():
     _check(ChromatinSystem(3000, gas, np.array([0, 3000]), labels[:3000], ff=ff), 0.6, "sparse gas", e_atol=0.1)
 
 
-def test_pair_kernel_choice_follows_the_cell_occupancy():
-    """Default options: the half-shell kernel while the cells are crowded, the full-shell kernel once they have thinned
-    out (use_n3 in mmx_engine.hpp); a minimization that crosses the threshold switches on the way and still ends where
-    a run pinned to either kernel ends."""
-    s = synthetic_system("gw_200k", n_beads=30000, **ALL_ON)
+def test_pair_kernel_choice_follows_size_and_cell_occupancy():
+    """Default options (use_n3 in mmx_engine.hpp): small systems always take the full-shell kernel; from 80 000 beads the
+    half-shell kernel runs while the cells are crowded (>= 60 beads per grid cell), from 150 000 beads down to 20 per cell.
+    A minimization that crosses a threshold switches on the way and still ends where a run pinned to either kernel ends."""
+    with engine_for(synthetic_system("gw_200k", n_beads=30000, **ALL_ON)) as eng:
+        eng.minimize(tolerance=0.0, max_iters=20)
+        assert eng.get_option("n3_launches") == 0
+    s = synthetic_system("gw_200k", n_beads=100000, **ALL_ON)
     ends = {}
     for name, variant in (("auto", 0), ("half-shell", 4096), ("full-shell", 8192)):
         with engine_for(s) as eng:
             eng.set_option("nb_variant", variant)
-            st = eng.minimize(tolerance=0.0, max_iters=120)
-            ends[name] = (st.e_initial, st.e_final, eng.nb_census()["n_cells"])
-    e0, ef, cells = ends["auto"]
-    assert s.n_beads / cells < 60 < s.n_beads / 216          # the run started above the threshold and ended below it
+            st = eng.minimize(tolerance=0.0, max_iters=200)
+            ends[name] = (st.e_initial, st.e_final, eng.nb_census()["n_cells"], eng.get_option("n3_launches"), st.evaluations)
+    e0, ef, cells, n3, evals = ends["auto"]
+    assert s.n_beads / cells < 60                                # the run ended below the threshold ...
+    assert 20 <= n3 < evals - 20                                 # ... having started above it: both kernels ran
+    assert ends["half-shell"][3] >= evals and ends["full-shell"][3] == 0
     for name in ("half-shell", "full-shell"):
         assert abs(ends[name][0] - e0) <= 2e-6 * abs(e0)
-        assert abs(ends[name][1] - ef) <= 2e-2 * abs(e0 - ef)   # 120 iterations from the lattice: chaotic, see DESIGN.md 9
+        assert abs(ends[name][1] - ef) <= 2e-2 * abs(e0 - ef)   # 200 iterations from the lattice: chaotic, see DESIGN.md 9
 
 
 def test_graph_replay_equals_direct_launches_bitwise():
