@@ -1179,3 +1179,9 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
 } MMX_CATCH(h)
 
 } // extern "C"
+
+#ifdef MMX_N3_TIMING
+extern "C" int mmx_debug_n3_times(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_t), sizeof(unsigned long long) * 512 * 20);
+}
+#endif

@@ -200,16 +200,26 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
     const int cap = h->n3_cap;
     const size_t lds = n3_lds_bytes(cap);
+    // the tail of the item queue is taken in shares (k_nb_n3, stage_unit): by default one item per workgroup in two shares
+    // each, then one item per four workgroups in four shares (scripts/n3_tail_ab.py, gw_200k at the lattice / after 400 /
+    // 2000 iterations: 242 / 206 / 178 us without, 220 / 196 / 168 with the first tier, 213 / 190 / 164 with both; twice
+    // or half the items, four or eight shares: within 2 % of that).  For the A/B, nb_variant bits 24-27: items per
+    // workgroup in the first tier (x 1/2), bits 28-29: log2(shares) of it, bit 30: no tail at all
+    const unsigned tcfg = ((unsigned)h->nb_variant >> 24) & 127u;
+    const bool tail = !(tcfg & 64u);
+    const int tail_items = !tail ? 0 : (tcfg & 15u) ? (int)(tcfg & 15u) * grid / 2 : grid;
+    const int tail_sh = !tail ? 0 : (tcfg & 15u) ? (int)((tcfg >> 4) & 3u) : 1;
+    const int tail2_items = tail ? grid / 4 : 0, tail2_sh = tail ? 2 : 0;
 #define N3(EV, GA)                                                                                          \
     do {                                                                                                    \
         if (h->nb_skip_energy)                                                                              \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255);                              \
+                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh); \
         else                                                                                                \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255);                              \
+                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh); \
     } while (0)
     if (P.use_ev && P.use_gauss) N3(true, true);
     else if (P.use_ev) N3(true, false);

@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                  spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st);
 }
 
+#ifdef MMX_N3_TIMING
+__device__ unsigned long long g_n3_t[512 * 20];
+#endif
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
 template <int PMODE, bool EV, bool GAUSS, bool NOENERGY>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
@@ -269,8 +272,13 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           const N3Item *__restrict__ items, MinState *__restrict__ st,
                                                           float *__restrict__ fsort, const int fstride,
                                                           double *__restrict__ part, const int cap,
-                                                          const int diag = 0) {
+                                                          const int diag = 0, const int tail_items = 0,
+                                                          const int tail_sh = 0, const int tail2_items = 0,
+                                                          const int tail2_sh = 0) {
     if (st->phase >= PH_DONE) return;
+#ifdef MMX_N3_TIMING
+    if (threadIdx.x == 0) g_n3_t[blockIdx.x * 20] = wall_clock64();
+#endif
     // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
     // 8 slots are a dummy cluster), two box buffers [cap + 1][2] float4, four id buffers [cap + 8] int
     extern __shared__ __attribute__((aligned(16))) int s_f[];
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ float s_arow[kN3Waves][kCl * 8];
     __shared__ double s_e[2][kN3Waves];
-    __shared__ int s_desc[2][16]; // unit descriptors: a, n, T, wlo, rlo[5], rn[5], id buffer
+    __shared__ int s_desc[2][16]; // unit descriptors: a, n, T, wlo, rlo[5], rn[5], id buffer, share | log2(shares) << 8
     __shared__ N3Ctl ctl;
     // the wave index in a scalar register: hipcc cannot prove threadIdx.x >> 6 uniform and would otherwise keep the
     // scalar i beads in vector registers
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // window -- candidate k of the concatenated runs -> cluster id, box -- and writes its descriptor.  One wave.
     auto stage_unit = [&](int v) {
         const int p = v & 1, ib = v & 3;
-        int a = 0, n = 0, T = 0, wlo = 0, rlo[5], rn[5];
+        int a = 0, n = 0, T = 0, wlo = 0, rlo[5], rn[5], shr = 0;
         bool fetch = true;
         if (v > 0) { // unit v - 1 sits in the other parity
             const int *pd = s_desc[p ^ 1];
@@ -385,6 +393,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             else if (wlo < T) {        // next pass of the same item
                 fetch = false;
                 a = __builtin_amdgcn_readfirstlane(pd[0]);
+                shr = __builtin_amdgcn_readfirstlane(pd[15]);
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     rlo[r] = __builtin_amdgcn_readfirstlane(pd[4 + r]);
@@ -399,7 +408,26 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             // the list is in (roughly) ascending row order; taking it from the far end measured ~5 % faster at 200 000
             // beads (an item's flush targets its own row and the rows above it: descending order keeps the workgroups
             // in flight off each other's target rows); diag & 64: ascending, for the A/B
-            if (!(diag & 64) && q < n_items) q = n_items - 1 - q;
+            // The tail: the `tail_items` items taken last are each taken 2^tail_sh times, as SHARES -- every share sweeps all the
+            // i-clusters of the item against every 2^tail_sh-th candidate cluster of the window (its own LDS window, flushed
+            // like any other) -- so that the work left when the queue runs dry comes in pieces of a quarter of an i-cluster
+            // sweep and spreads over all workgroups: without it the last of ~6 sweeps per wave (~35 us each at 200 000
+            // beads) leaves the waves idle for 17 % of the kernel on average (scripts/n3_tail.py).
+            if (!(diag & 64)) {
+                const int K2 = min(tail2_items, n_items), K1 = min(tail_items, n_items - K2);
+                if (q < n_items - K1 - K2) q = n_items - 1 - q;
+                else {
+                    int r = q - (n_items - K1 - K2);
+                    if (r < (K1 << tail_sh)) {
+                        q = K2 + K1 - 1 - (r >> tail_sh);
+                        shr = (r & ((1 << tail_sh) - 1)) | (tail_sh << 8);
+                    } else {
+                        r -= K1 << tail_sh;
+                        q = r < (K2 << tail2_sh) ? K2 - 1 - (r >> tail2_sh) : n_items;
+                        shr = (r & ((1 << tail2_sh) - 1)) | (tail2_sh << 8);
+                    }
+                }
+            }
             n = 0;
             wlo = 0;
             if (q < n_items) {
@@ -441,7 +469,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         if (lane < 16) {
             int val = 0;
             if (n > 0) {
-                val = lane == 0 ? a : lane == 1 ? n : lane == 2 ? T : lane == 3 ? wlo : lane == 14 ? ib : 0;
+                val = lane == 0 ? a : lane == 1 ? n : lane == 2 ? T : lane == 3 ? wlo : lane == 14 ? ib : lane == 15 ? shr : 0;
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     val = lane == 4 + r ? rlo[r] : val;
@@ -491,7 +519,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             break;
         }
         const int D_a = __builtin_amdgcn_readfirstlane(dd[0]), D_T = __builtin_amdgcn_readfirstlane(dd[2]),
-                  wlo = __builtin_amdgcn_readfirstlane(dd[3]), D_ib = __builtin_amdgcn_readfirstlane(dd[14]);
+                  wlo = __builtin_amdgcn_readfirstlane(dd[3]), D_ib = __builtin_amdgcn_readfirstlane(dd[14]),
+                  D_shr = __builtin_amdgcn_readfirstlane(dd[15]);
+        const int sh = D_shr >> 8, share = D_shr & 255; // this unit sweeps candidates k = share (mod 2^sh) of the window
         const float4 *s_box = reinterpret_cast<const float4 *>(box0 + p * 8 * (cap + 1));
         const int *s_jc = ids0 + D_ib * (cap + 8);
         int *sfx = s_f + p * 3 * fstr, *sfy = sfx + fstr, *sfz = sfy + fstr;
@@ -533,13 +563,13 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 const int own_lc = own_k >= 0 ? own_k : -1;
                 const int k0 = max(own_k, 0);
                 int nlist = 0, rcount = 0, rhead = 0;
-                for (int g = k0 & ~63; g < nwin; g += 128) {
+                for (int g = (k0 >> sh) & ~63; (g << sh) < nwin; g += 128) {
                     // ---- cull: 128 candidate clusters of the window per step (two independent box reads in flight: the LDS
                     // round trip is what a step waits for), boxes from LDS
                     bool ok[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int k = g + 64 * h + lane;
+                        const int k = ((g + 64 * h + lane) << sh) + share;
                         ok[h] = false;
                         if (k >= k0 && k < nwin) {
                             const float4 lo_j = s_box[2 * k], hi_j = s_box[2 * k + 1];
@@ -552,10 +582,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const unsigned long long mask = __ballot(ok[h]);
-                        if (ok[h]) list[nlist + prefix_count(mask)] = (unsigned short)(g + 64 * h + lane);
+                        if (ok[h]) list[nlist + prefix_count(mask)] = (unsigned short)(((g + 64 * h + lane) << sh) + share);
                         nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
                     }
-                    const bool last = g + 128 >= nwin;
+                    const bool last = ((g + 128) << sh) >= nwin;
                     if (nlist < kN3List - 128 && !last) continue;
                     if (diag & 16) { // timing diagnosis only: cull without sweep
                         fx[0] += (float)nlist;
@@ -710,6 +740,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
         }
     }
+#ifdef MMX_N3_TIMING
+    if (lane == 0) g_n3_t[blockIdx.x * 20 + 1 + wave] = wall_clock64();
+#endif
     acc_ev = (double)escale * wave_sum(acc_ev);
     acc_g = wave_sum(acc_g);
     if (lane == 0) {
@@ -726,6 +759,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         }
         part[P_EV * kPartStride + blockIdx.x] = a;
         part[P_GAUSS * kPartStride + blockIdx.x] = b;
+#ifdef MMX_N3_TIMING
+        g_n3_t[blockIdx.x * 20 + 17] = wall_clock64();
+#endif
     }
 }
 
