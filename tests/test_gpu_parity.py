@@ -152,7 +152,7 @@ def test_pair_kernel_choice_follows_size_and_cell_occupancy():
     e0, ef, cells, n3, evals = ends["auto"]
     assert s.n_beads / cells < 60                                # the run ended below the threshold ...
     assert 20 <= n3 < evals - 20                                 # ... having started above it: both kernels ran
-    assert ends["half-shell"][3] >= evals and ends["full-shell"][3] == 0
+    assert ends["half-shell"][3] >= ends["half-shell"][4] and ends["full-shell"][3] == 0
     for name in ("half-shell", "full-shell"):
         assert abs(ends[name][0] - e0) <= 2e-6 * abs(e0)
         assert abs(ends[name][1] - ef) <= 2e-2 * abs(e0 - ef)   # 200 iterations from the lattice: chaotic, see DESIGN.md 9
