@@ -109,8 +109,8 @@ void refresh_params(mmx_handle_s *h) {
 }
 
 // choice of the pair kernel: see use_n3
-constexpr double kN3CrowdedBeadsPerCell = 60.0, kN3MinBeadsPerCell = 20.0;
-constexpr int kN3MinBeadsCrowded = 80000, kN3MinBeads = 150000;
+constexpr double kN3MinBeadsPerCell = 20.0;
+constexpr int kN3MinBeads = 80000;
 
 // The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
 // caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
@@ -120,23 +120,21 @@ bool use_n3(const mmx_handle_s *h) {
     if (h->nb_variant & 8192) return false;
     if (h->nb_variant & 4096) return true;
     if (h->deterministic || (h->nb_variant & 0xffff & ~(4096 | 8192)) != 0) return false;
-    // Which kernel is faster depends on the size of the system and on how crowded the cells are (scripts/kernel_choice.py:
-    // minimizations from the lattice with either kernel forced, iterations/s half shell against full shell):
+    // Which kernel is faster depends on the size of the system (scripts/kernel_choice.py: minimizations from the lattice
+    // with either kernel forced, iterations/s half shell against full shell):
     //   beads      first 200 iterations (150 -> 50 beads per grid cell)    1500-3000 iterations (-> 25 per cell)
-    //   5 000           -13 %                                                  -12 %
-    //   50 000          - 4 %                                                  - 8 %
-    //   80 000          + 1 %                                                  - 5 %
-    //   110 000         + 6 %                                                    0
-    //   140 000         + 5 %                                                  + 1 %
-    //   200 000         + 6 %                                                  + 2 %
-    //   1 000 000       + 6 %                                                  + 6 %
+    //   5 000           - 5 %                                                  -15 %
+    //   30 000          - 1 %                                                  - 5 %
+    //   50 000          - 3 %                                                  -12 %
+    //   80 000          +10 %                                                  + 3 %
+    //   110 000         +16 %                                                  + 6 %
+    //   200 000         +11 %                                                  + 8 %
+    //   1 000 000       + 7 %                                                  + 7 %
     // (the persistent workgroups of the half-shell kernel want several work items each; its path costs one small launch
-    // more.)  The last poll's cell count decides; both kernels compute the same forces to rounding.  Below 20 beads per
-    // cell nothing was measured: the full-shell kernel, which needs no atomics, stays.
-    if (h->last_ncells <= 0) return h->n >= kN3MinBeadsCrowded; // before the first poll: the Hilbert start is crowded
-    const double per_cell = (double)h->n / (double)h->last_ncells;
-    if (per_cell >= kN3CrowdedBeadsPerCell) return h->n >= kN3MinBeadsCrowded;
-    return per_cell >= kN3MinBeadsPerCell && h->n >= kN3MinBeads;
+    // more.)  Below 20 beads per cell nothing was measured: the full-shell kernel, which needs no atomics, stays there;
+    // the last poll's cell count decides.  Both kernels compute the same forces to rounding.
+    if (h->n < kN3MinBeads) return false;
+    return h->last_ncells <= 0 || (double)h->n >= kN3MinBeadsPerCell * (double)h->last_ncells;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
