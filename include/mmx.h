@@ -181,10 +181,10 @@ int mmx_disable_term(mmx_handle h, int32_t term);
 
 /* ---- tunables that are not part of the physics ------------------------------------------------
  * key                 meaning                                                      default
- * "deterministic"     0: half-shell pair kernel (every pair once, reaction through LDS and float
- *                     atomics: results reproducible to rounding, as OpenMM's GPU platforms with
- *                     DeterministicForces=false); 1: full-shell pair kernel with a fixed summation
- *                     order (bitwise reproducible runs, ~15 % slower)                 0
+ * "deterministic"     0: systems of >= 80 000 beads use the half-shell pair kernel (every pair once, reaction
+ *                     through LDS and float atomics: results reproducible to rounding, as OpenMM's GPU
+ *                     platforms with DeterministicForces=false); 1: always the full-shell pair kernel with
+ *                     a fixed summation order (bitwise reproducible runs, ~10 % slower at 200 000 beads)  0
  * "profile"           k>0: HIP-event time the kernel slots of every k-th evaluation of a
  *                     minimization (every k-th launch of a slot elsewhere)            0
  * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them
@@ -198,8 +198,9 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     and halves it again after 128 quiet ones                          0.1
  * "dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_skin_now"
  *                     (get only) statistics of the decomposed run
- * nb_variant bits:    4096 force the half-shell pair kernel, 8192 force the full-shell one (default: chosen per
- *                     state); the other bits select round-1 A/B and diagnosis instances
+ * nb_variant bits:    4096 force the half-shell pair kernel, 8192 force the full-shell one (default: chosen by
+ *                     system size and cell occupancy); bits 24-30 configure the tail shares of the
+ *                     half-shell kernel (A/B); the other bits select round-1 A/B and diagnosis instances
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0
  * "fused_bonded"      1: backbone + loops + confinement in one pass; 0: the three kernels
