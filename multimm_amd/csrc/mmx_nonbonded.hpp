@@ -238,7 +238,7 @@ __global__ __launch_bounds__(192) void k_nb_cells(const FFParams P, const float4
 // chunk lie inside the cutoff while 83 % of them are within the cutoff of SOME home bead, so neither
 // wave-uniform skipping nor per-lane bit-mask compaction pays (both were built and measured, see
 // DESIGN.md).  What pays is making both sides of a tile spatially small: beads are grouped in clusters
-// of 8 consecutive entries of the cell-sorted, Morton-ordered list (k_cell_order writes their padded
+// of 8 consecutive entries of the cell-sorted, Hilbert-ordered list (k_cell_order writes their padded
 // positions `spos4` and bounding boxes).  One wave owns one i-cluster: it tests the candidate
 // j-clusters of the 27-cell stencil box-against-box (lanes = candidate clusters), compacts the
 // survivors with a ballot into an LDS list, keeps its 8 i beads in scalar registers (v_readlane once)

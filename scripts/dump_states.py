@@ -1,0 +1,11 @@
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+from multimm_amd import synthetic_system
+from multimm_amd.engine import engine_for
+eng = engine_for(synthetic_system("gw_200k"))
+done = 0
+for upto in (60, 400, 2000):
+    eng.minimize(tolerance=0.0, max_iters=upto - done); done = upto
+    np.save(f"gpurun_out/pos_{upto}.npy", eng.get_positions().astype(np.float32))
+print("ok")
