@@ -181,10 +181,10 @@ int mmx_disable_term(mmx_handle h, int32_t term);
 
 /* ---- tunables that are not part of the physics ------------------------------------------------
  * key                 meaning                                                      default
- * "deterministic"     0: systems of >= 80 000 beads use the half-shell pair kernel (every pair once, reaction
+ * "deterministic"     0: systems of >= 100 000 beads use the half-shell pair kernel (every pair once, reaction
  *                     through LDS and float atomics: results reproducible to rounding, as OpenMM's GPU
  *                     platforms with DeterministicForces=false); 1: always the full-shell pair kernel with
- *                     a fixed summation order (bitwise reproducible runs, ~10 % slower at 200 000 beads)  0
+ *                     a fixed summation order (bitwise reproducible runs, ~5 % slower at 200 000 beads)   0
  * "profile"           k>0: HIP-event time the kernel slots of every k-th evaluation of a
  *                     minimization (every k-th launch of a slot elsewhere)            0
  * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them

@@ -110,7 +110,7 @@ void refresh_params(mmx_handle_s *h) {
 
 // choice of the pair kernel: see use_n3
 constexpr double kN3MinBeadsPerCell = 20.0;
-constexpr int kN3MinBeads = 80000;
+constexpr int kN3MinBeads = 100000;
 
 // The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
 // caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
@@ -124,11 +124,10 @@ bool use_n3(const mmx_handle_s *h) {
     // with either kernel forced, iterations/s half shell against full shell):
     //   beads      first 200 iterations (150 -> 50 beads per grid cell)    1500-3000 iterations (-> 25 per cell)
     //   5 000           - 5 %                                                  -15 %
-    //   30 000          - 1 %                                                  - 5 %
-    //   50 000          - 3 %                                                  -12 %
-    //   80 000          +10 %                                                  + 3 %
-    //   110 000         +16 %                                                  + 6 %
-    //   200 000         +11 %                                                  + 8 %
+    //   50 000          - 4 %                                                  -12 %
+    //   80 000          + 4 %                                                  - 1 %
+    //   110 000         + 3 %                                                  + 2 %
+    //   200 000         + 5 %                                                  + 4 %
     //   1 000 000       + 7 %                                                  + 7 %
     // (the persistent workgroups of the half-shell kernel want several work items each; its path costs one small launch
     // more.)  Below 20 beads per cell nothing was measured: the full-shell kernel, which needs no atomics, stays there;

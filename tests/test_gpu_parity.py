@@ -136,7 +136,7 @@ def test_half_shell_kernel_dense_cells_and_overlapping_beads():
 
 
 def test_pair_kernel_choice_follows_size_and_cell_occupancy():
-    """Default options (use_n3 in mmx_engine.hpp): systems below 80 000 beads always take the full-shell kernel, larger ones
+    """Default options (use_n3 in mmx_engine.hpp): systems below 100 000 beads always take the full-shell kernel, larger ones
     the half-shell kernel as long as the last poll saw >= 20 beads per grid cell.  Whatever is picked, a minimization ends
     where a run pinned to either kernel ends."""
     with engine_for(synthetic_system("gw_200k", n_beads=30000, **ALL_ON)) as eng:
