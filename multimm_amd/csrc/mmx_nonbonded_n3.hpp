@@ -1,4 +1,4 @@
-// mmx_nonbonded_n3.hpp -- K2 (default): half-shell cluster-pair kernel, Newton's third law through LDS.
+// mmx_nonbonded_n3.hpp -- K2 (default from 100 000 beads): half-shell cluster-pair kernel, Newton's third law through LDS.
 //
 // Same pair physics and the same lean pair loop as k_nb_clusters_j (mmx_nonbonded.hpp; reference: model.py:199 EV
 // power law, model.py:246-250 / 322-328 compartment Gaussians), but every unordered bead pair is evaluated ONCE: the
@@ -29,6 +29,12 @@
 // after next (queue pop, item descriptor, candidate boxes and ids) while the others compute; the flush is done, a chunk
 // at a time, by the waves that wait for that window.  No workgroup barrier in the steady state; every wait is a bounded
 // spin that raises an error (failed evaluation) instead of hanging.
+//
+// The tail.  A wave sweeps ~6 i-clusters per launch at 200 000 beads, ~35 us each, so without care the last sweep leaves
+// most waves idle for a sixth of the kernel.  The items the queue hands out LAST are therefore handed out 2 or 4 times, as
+// SHARES: share c of 2^s sweeps all i-clusters of the item against the candidates k = c (mod 2^s) of the window -- same
+// staging, own LDS window, flushed like any other unit; the i-side sums are atomics anyway and the self tile belongs to
+// exactly one share.  The ticket -> (item, share) map lives in stage_unit; the item list itself is not touched.
 //
 // LDS accumulation is int32 fixed point (2^-13 kJ/mol/nm): ds_add_f32 is serialised on gfx950 (measured,
 // scripts/ubench/lds_atomic.hip: 193 cycles per wave instruction against 4.5-7 for ds_add_u32), and integer sums do
