@@ -283,7 +283,11 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           const int tail2_sh = 0) {
     if (st->phase >= PH_DONE) return;
 #ifdef MMX_N3_TIMING
-    if (threadIdx.x == 0) g_n3_t[blockIdx.x * 20] = wall_clock64();
+    if (threadIdx.x == 0) {
+        g_n3_t[blockIdx.x * 20] = wall_clock64();
+        g_n3_t[blockIdx.x * 20 + 18] = g_n3_t[blockIdx.x * 20 + 19] = 0ull;
+    }
+    __syncthreads();
 #endif
     // dynamic LDS: two force windows [3][cap*8 + 8] int (x | y | z per window slot, fixed point, see kN3Fix; the last
     // 8 slots are a dummy cluster), two box buffers [cap + 1][2] float4, four id buffers [cap + 8] int
@@ -472,6 +476,12 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 box[2 * k + 1] = cl_box[2 * jc + 1];
             }
         }
+#ifdef MMX_N3_TIMING
+        if (lane == 0 && n > 0) {
+            atomicAdd(&g_n3_t[blockIdx.x * 20 + 19], 1ull);
+            if (wlo > 0) atomicAdd(&g_n3_t[blockIdx.x * 20 + 18], 1ull);
+        }
+#endif
         if (lane < 16) {
             int val = 0;
             if (n > 0) {
