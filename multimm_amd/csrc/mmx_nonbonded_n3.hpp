@@ -689,6 +689,21 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 fjz = fmaf(fs, dz, fjz);
                             }
                             const bool self = (jslot >> 3) == own_lc;
+                            const bool big = fmaxf(fmaxf(fabsf(fjx), fabsf(fjy)), fabsf(fjz)) >= fix_lim;
+                            // Nearly every batch holds neither a bead of the i-cluster itself nor a sum too large for the
+                            // fixed-point window: one wave-uniform test takes it past the ~12 operations of both.
+                            if (__builtin_expect(__ballot(self || big) == 0ull, 1)) {
+                                if (!NOENERGY) {
+                                    if (EV) ee += eb;
+                                    if (GAUSS) eg += gb;
+                                }
+                                if (!(diag & 2)) { // reaction on the j beads (sign and unit: at the flush)
+                                    atomicAdd(sfx + jslot, __float2int_rn(fjx * fix_k));
+                                    atomicAdd(sfy + jslot, __float2int_rn(fjy * fix_k));
+                                    atomicAdd(sfz + jslot, __float2int_rn(fjz * fix_k));
+                                }
+                                continue;
+                            }
                             if (!NOENERGY) {
                                 // self tile: both orders of a pair were swept (weight 1/2), and the r = 0 pair -- swept with
                                 // the rest -- goes out again in the batch it came in with (its value, eself, is formed by
@@ -697,19 +712,16 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 if (EV) ee = fmaf(self ? eb - eself : eb, self ? 0.5f : 1.f, ee);
                                 if (GAUSS) eg = fmaf(self ? gb + arow[(jslot & 7) * 8 + lj] : gb, self ? 0.5f : 1.f, eg);
                             }
-                            if (!(diag & 2)) { // reaction on the j beads (sign and unit: at the flush)
-                                const bool big = fmaxf(fmaxf(fabsf(fjx), fabsf(fjy)), fabsf(fjz)) >= fix_lim;
-                                if (__builtin_expect(__ballot(big && !self) != 0ull, 0)) {
-                                    if (big && !self) { // rare (overlapping beads): straight to global memory
-                                        const int gs = s_jc[jslot >> 3] * kCl + (jslot & 7);
-                                        atomicAdd(fsort + gs, -pscale * fjx);
-                                        atomicAdd(fsort + fstride + gs, -pscale * fjy);
-                                        atomicAdd(fsort + 2 * fstride + gs, -pscale * fjz);
-                                    }
+                            if (!(diag & 2)) {
+                                if (big && !self) { // rare (overlapping beads): straight to global memory
+                                    const int gs = s_jc[jslot >> 3] * kCl + (jslot & 7);
+                                    atomicAdd(fsort + gs, -pscale * fjx);
+                                    atomicAdd(fsort + fstride + gs, -pscale * fjy);
+                                    atomicAdd(fsort + 2 * fstride + gs, -pscale * fjz);
                                 }
-                                // lanes of the self tile (and the rare large sums) add into the dummy cluster: no branch
-                                // around the adds, so the j-side FMAs stay in the pair loop instead of keeping all
-                                // eight (fs, d) sets alive behind it
+                                // lanes of the self tile (and the large sums) add into the dummy cluster: no branch around the
+                                // adds, so the j-side FMAs stay in the pair loop instead of keeping all eight (fs, d) sets
+                                // alive behind it
                                 const int tslot = (self || big) ? cap * 8 + (lane & 7) : jslot;
                                 atomicAdd(sfx + tslot, __float2int_rn(fjx * fix_k));
                                 atomicAdd(sfy + tslot, __float2int_rn(fjy * fix_k));

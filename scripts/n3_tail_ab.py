@@ -9,7 +9,7 @@ from multimm_amd.engine import engine_for, K_NONBONDED
 name = sys.argv[1] if len(sys.argv) > 1 else "gw_200k"
 eng = engine_for(synthetic_system(name))
 done = 0
-cfgs = [(0, 0), (64, 0)]
+cfgs = [(0, 0)]
 for upto in (0, 400, 2000):
     if upto > done:
         eng.set_option("nb_variant", 0)
