@@ -271,13 +271,20 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
 #ifdef MMX_N3_TIMING
 __device__ unsigned long long g_n3_t[512 * 20];
 #endif
+// float -> int, rounded to nearest (ties up): ONE operation where __float2int_rn is v_rndne + v_cvt
+__device__ __forceinline__ int cvt_nearest(float v) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
 template <int PMODE, bool EV, bool GAUSS, bool NOENERGY>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
                                                           const float4 *__restrict__ cl_box,
                                                           const N3Item *__restrict__ items, MinState *__restrict__ st,
                                                           float *__restrict__ fsort, const int fstride,
-                                                          double *__restrict__ part, const int cap,
+                                                          double *__restrict__ part, const int cap_arg,
                                                           const int diag = 0, const int tail_items = 0,
                                                           const int tail_sh = 0, const int tail2_items = 0,
                                                           const int tail2_sh = 0) {
@@ -303,7 +310,11 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // scalar i beads in vector registers
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane >> 3, slot = lane & 7;
-    const int fstr = cap * 8 + 8;
+    // the window size is a compile-time constant (the host refuses the kernel when the device cannot give it that much
+    // LDS): window strides become immediate offsets of the LDS instructions
+    constexpr int cap = kN3MaxCap;
+    (void)cap_arg;
+    constexpr int fstr = cap * 8 + 8;
     int *const box0 = s_f + 2 * 3 * fstr;           // box buffers
     int *const ids0 = box0 + 2 * 8 * (cap + 1);     // id buffers
     const int far_cl = P.n_all; // a resident all-padding cluster (8 beads at -1e18)
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         const int sh = D_shr >> 8, share = D_shr & 255; // this unit sweeps candidates k = share (mod 2^sh) of the window
         const float4 *s_box = reinterpret_cast<const float4 *>(box0 + p * 8 * (cap + 1));
         const int *s_jc = ids0 + D_ib * (cap + 8);
-        int *sfx = s_f + p * 3 * fstr, *sfy = sfx + fstr, *sfz = sfy + fstr;
+        int *sfx = s_f + p * 3 * fstr;
         const int nwin = min(D_T, wlo + cap) - wlo;
         // ---- compute: grab i-clusters of the item one at a time
         for (;;) {
@@ -698,9 +709,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                     if (GAUSS) eg += gb;
                                 }
                                 if (!(diag & 2)) { // reaction on the j beads (sign and unit: at the flush)
-                                    atomicAdd(sfx + jslot, __float2int_rn(fjx * fix_k));
-                                    atomicAdd(sfy + jslot, __float2int_rn(fjy * fix_k));
-                                    atomicAdd(sfz + jslot, __float2int_rn(fjz * fix_k));
+                                    atomicAdd(sfx + jslot, cvt_nearest(fjx * fix_k));
+                                    atomicAdd(sfx + fstr + jslot, cvt_nearest(fjy * fix_k));
+                                    atomicAdd(sfx + 2 * fstr + jslot, cvt_nearest(fjz * fix_k));
                                 }
                                 continue;
                             }
@@ -723,9 +734,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 // adds, so the j-side FMAs stay in the pair loop instead of keeping all eight (fs, d) sets
                                 // alive behind it
                                 const int tslot = (self || big) ? cap * 8 + (lane & 7) : jslot;
-                                atomicAdd(sfx + tslot, __float2int_rn(fjx * fix_k));
-                                atomicAdd(sfy + tslot, __float2int_rn(fjy * fix_k));
-                                atomicAdd(sfz + tslot, __float2int_rn(fjz * fix_k));
+                                atomicAdd(sfx + tslot, cvt_nearest(fjx * fix_k));
+                                atomicAdd(sfx + fstr + tslot, cvt_nearest(fjy * fix_k));
+                                atomicAdd(sfx + 2 * fstr + tslot, cvt_nearest(fjz * fix_k));
                             }
                         }
                     }
