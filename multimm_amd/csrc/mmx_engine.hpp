@@ -199,8 +199,8 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     const size_t lds = n3_lds_bytes(cap);
     // the tail of the item queue is taken in shares (k_nb_n3, stage_unit): by default one item per workgroup in two shares
     // each, then one item per four workgroups in four shares (scripts/n3_tail_ab.py, gw_200k at the lattice / after 400 /
-    // 2000 iterations: 242 / 206 / 178 us without, 220 / 196 / 168 with the first tier, 213 / 190 / 164 with both; twice
-    // or half the items, four or eight shares: within 2 % of that).  For the A/B, nb_variant bits 24-27: items per
+    // 2000 iterations, final kernel: 190 / 175 / 157 us without, 182 / 168 / 149 with; half or 1.5 x the items, four
+    // shares in the first tier, no second tier: within 1-2 % of that).  For the A/B, nb_variant bits 24-27: items per
     // workgroup in the first tier (x 1/2), bits 28-29: log2(shares) of it, bit 30: no tail at all
     const unsigned tcfg = ((unsigned)h->nb_variant >> 24) & 127u;
     const bool tail = !(tcfg & 64u);
