@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--profile-every", type=int, default=16,
                     help="HIP-event time every k-th launch of each kernel slot inside the timed region "
                          "(an event pair costs ~10 us of stream time: 16 keeps the perturbation < 1 %%)")
+    ap.add_argument("--dd-timeout", type=float, default=240.0,
+                    help="seconds the extra decomposed leg at N > 1 may take before it is abandoned (the line is printed without it)")
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
                     help="what `value` is at N > 1: 'ensemble' = one gw_200k replica per GPU (config 4, weak scaling, no "
                          "collective; the default, with the gw_1m decomposed run reported beside it as the `dd` object); "
@@ -152,7 +154,7 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
     }
 
 
-def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier) -> dict:
+def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress: dict) -> dict:
     """BASELINE config 5 beside the headline (N > 1): ONE gw_1m system (1 000 000 beads), bead slices owned by the
     ranks, ghost-bead halo exchange + one fp64 all-reduce per evaluation on RCCL, issued by libmmx on its own stream.
     Returns the `dd` object of the JSON line: job iterations/s, the ranks RCCL saw, bytes exchanged per evaluation,
@@ -164,20 +166,24 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier) -> dict:
     from multimm_amd.parallel import broadcast_bytes, reduce_job_stats
     out = {"workload": "gw_1m", "mode": "dd", "ranks": world}
     stage = "setup"
+
+    def at(name):
+        progress["stage"] = name
+        return name
     try:
         system = synthetic_system("gw_1m", seed=0, NB_CUTOFF=args.cutoff)
         out["n_beads"] = system.n_beads
         eng = engine_for(system, device=local_rank, rank=rank, world=world)
         try:
-            stage = "rccl communicator"
+            stage = at("rccl communicator")
             uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128, device=tdev)
             eng.comm_init(uid)
-            stage = "warm-up"
+            stage = at("warm-up")
             if args.warmup > 0:
                 eng.minimize(tolerance=0.0, max_iters=args.warmup)
             b0, x0 = eng.get_option("dd_bytes_sent"), eng.get_option("dd_exchanges")
             r0 = eng.get_option("dd_redecompositions")
-            stage = "timed minimization"
+            stage = at("timed minimization")
             barrier()
             t0 = time.perf_counter()
             st = eng.minimize(tolerance=0.0, max_iters=args.steps)
@@ -197,7 +203,7 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier) -> dict:
             })
         finally:
             eng.close()
-        stage = "single-GPU reference"
+        stage = at("single-GPU reference")
         if rank == 0:
             with engine_for(system, device=local_rank) as e1:
                 if args.warmup > 0:
@@ -387,17 +393,38 @@ def main():
         except Exception as exc:  # noqa: BLE001
             out["truncation"] = {"error": repr(exc)}
     if world > 1 and not dd and not args.no_dd_leg:  # every rank takes part; rank 0 carries the result
-        leg = dd_leg(args, rank, world, local_rank, tdev, barrier)
+        # The RCCL path of the decomposed run has never met more than one rank on hardware: a watchdog
+        # makes sure that a leg which does not come back costs the `dd` object, not the line.
+        import threading
+        progress = {"stage": "setup"}
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(args.dd_timeout):
+                return
+            if rank == 0:
+                out["dd"] = {"workload": "gw_1m", "mode": "dd", "ranks": world,
+                             "error": f"no result after {args.dd_timeout:.0f} s (stage: {progress['stage']}); leg abandoned"}
+                print(json.dumps(out), flush=True)
+            else:
+                time.sleep(3.0)
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        leg = dd_leg(args, rank, world, local_rank, tdev, barrier, progress)
+        finished.set()
         if rank == 0:
             out["dd"] = leg
     if rank == 0:
         if n_gpus == 1 and args.replicas_per_gpu > 1:
             out["replicas_per_gpu"] = replicas_per_gpu_leg(args.workload, args.n_beads, args.cutoff, local_rank,
                                                            args.replicas_per_gpu, args.steps)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        import threading
+        threading.Timer(30.0, lambda: os._exit(0)).start()  # a rank that lost its peers must not keep the launcher waiting
         dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 if __name__ == "__main__":
