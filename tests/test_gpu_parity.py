@@ -346,6 +346,32 @@ def test_full_size_properties_200k():
             e_prev = st.e_final
 
 
+def test_full_size_oracle_parity_200k():
+    """BASELINE config 3 size against the fp64 oracle itself (its OpenMP evaluation of 200 000 beads takes a second): every
+    term on, both cell-list pair kernels, at the lattice start (at-cutoff bands, see E_RTOL_AT_CUTOFF) and on the state the
+    default path reaches after 60 iterations -- the collapse phase, where the half-shell kernel's work items take two window
+    passes and its tail shares are in play."""
+    import dataclasses
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", **ALL_ON)
+    x = s.positions
+    for relaxed in (False, True):
+        if relaxed:
+            with engine_for(s) as eng:
+                eng.minimize(tolerance=0.0, max_iters=60)
+                x = eng.get_positions().astype(np.float64)
+        s2 = dataclasses.replace(s, positions=x)   # (the mass centre of the confinement terms belongs to the system)
+        et_ref, F_ref = Oracle(s2).eval()
+        scale_e, fmax = np.abs(et_ref).sum(), np.abs(F_ref).max()
+        with engine_for(s2) as eng:
+            for variant in (4096, 8192):
+                eng.set_option("nb_variant", variant)
+                et, F = eng.compute()
+                e_rtol, f_rtol = (E_RTOL, F_RTOL) if relaxed else (E_RTOL_AT_CUTOFF, F_RTOL_AT_CUTOFF)
+                assert np.all(np.abs(et - et_ref) <= e_rtol * scale_e + E_ATOL), (relaxed, variant, et, et_ref)
+                assert np.abs(F - F_ref).max() <= f_rtol * fmax + F_ATOL, (relaxed, variant)
+
+
 def test_one_million_beads_runs():
     """BASELINE config 5 size on one GPU: allocation, cell build and kernels at N = 1e6."""
     s = synthetic_system("gw_1m")
