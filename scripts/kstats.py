@@ -1,3 +1,4 @@
+"""Prints the first rows of a rocprofv3 kernel_stats.csv.  usage: kstats.py <csv> [rows=20]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 20]:

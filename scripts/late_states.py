@@ -1,3 +1,5 @@
+"""Where the time of the two pair kernels goes at later states of a gw_200k minimization: diagnosis instances that stop after the
+cluster cull, the j stream, the per-bead cull (nb_variant bits; results are wrong, only the timing counts).  usage: late_states.py"""
 import sys
 sys.path.insert(0, '.')
 from multimm_amd import synthetic_system

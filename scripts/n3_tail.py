@@ -1,3 +1,5 @@
+"""Idle tail of the half-shell kernel: per-workgroup and per-wave exit times from a -DMMX_N3_TIMING build of libmmx.so (loaded through
+MMX_LIB), units and later passes per launch.  usage: MMX_LIB=<timing build> n3_tail.py [nb_variant bits 24-30 = tail configuration]"""
 import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,3 +1,5 @@
+"""gw_1m: full-shell kernel with and without the XCD-slab mapping, half-shell kernel with items taken in descending / ascending order.
+usage: xcd_1m.py"""
 import sys
 sys.path.insert(0, '.')
 from multimm_amd import synthetic_system
