@@ -335,7 +335,6 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
     int *list = s_list[wave];
     float4 *ring = s_ring[wave];
     const float *arow = s_arow[wave];
-    const unsigned long long lt = (1ull << lane) - 1ull;
     // spos4 holds the beads' positions as they are (nm, bit for bit): the pair terms see the state without any rounding of
     // their own.  (Round 1 worked in lengths scaled by sqrt(log2(e) / (2 r_comp^2)), which saves the multiply in front
     // of v_exp -- 1 of 27 operations per pair, ~2 % of the kernel -- and costs one rounding of every coordinate at its
