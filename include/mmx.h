@@ -73,6 +73,9 @@ enum {
 #define MMX_MIN_LS_MAX_STEP (-4)
 #define MMX_MIN_LS_MAX_LINESEARCH (-5)
 #define MMX_MIN_NAN (-6)
+#define MMX_MIN_KERNEL (-7) /* a force kernel reported that it could not do its work (e.g. the half-shell pair kernel's
+                               work-unit protocol timed out): the evaluation was void, nothing was decided on it;
+                               mmx_minimize / mmx_compute / mmx_md_step return MMX_ERR_STATE */
 
 typedef struct mmx_handle_s *mmx_handle;
 
@@ -209,6 +212,8 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     in the cell-build slot); 0: its own launch ("confine" slot)     1
  * "order_fallbacks"   (get only) cells of the last call that were too large for the in-LDS sort and
  *                     kept arrival order: 0 means the summation order was bitwise reproducible
+ * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
+ *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE     0
  */
 int mmx_set_option(mmx_handle h, const char *key, double value);
 int mmx_get_option(mmx_handle h, const char *key, double *value);

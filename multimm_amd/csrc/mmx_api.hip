@@ -588,6 +588,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
         h->dd_skin = h->dd_skin_cur = (float)value;
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
+    else if (k == "inject_fault") h->inject_fault = (int)value;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -602,6 +603,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "use_graph") *value = h->use_graph;
+    else if (k == "inject_fault") *value = h->inject_fault;
     else if (k == "n3_launches") *value = (double)h->n3_launches;   // read-only: how often the half-shell kernel ran
     else if (k == "dd_halo") *value = h->dd_halo;
     else if (k == "dd_skin") *value = h->dd_skin;
@@ -628,6 +630,7 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) try {
     if ((rc = pull_state(h))) return rc;
     HIPCHK(h, hipGetLastError());
     prof_collect(h, nullptr);
+    if ((rc = kernel_error_rc(h))) return rc;
     if (energy_terms_out)
         for (int t = 0; t < MMX_N_TERMS; ++t) energy_terms_out[t] = h->st_host->eterms[t];
     if (forces_out) {
@@ -773,6 +776,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     for (int k = 0; k < MMX_N_KERNELS; ++k) local.kernel_launches[k] = h->launches[k];
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (out) *out = local;
+    if (s.status == MMX_MIN_KERNEL || s.kernel_error) return kernel_error_rc(h);
     if (s.status == MMX_MIN_NAN) return fail(h, MMX_ERR_NAN, "non-finite energy during minimization");
     return MMX_OK;
 } MMX_CATCH(h)
@@ -912,6 +916,10 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         if (h->dd_rc != MMX_OK) return h->dd_rc;
         if ((s + 1) % poll_every == 0) { // bound the queue depth; learn the cluster count
             if ((rc = pull_state(h))) return rc;
+            if ((rc = kernel_error_rc(h))) {
+                h->md_forces_valid = false;
+                return rc;
+            }
             if (h->st_host->sums[12] > 0.5) { // all-reduced: every rank sees it
                 h->md_forces_valid = false;
                 return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two "
@@ -932,6 +940,10 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     hipLaunchKernelGGL(k_md_kinetic_fold, dim3(1), dim3(256), 0, h->stream, gk, h->ke_part, h->ke_out);
     if (has_comm(h)) coll_allreduce(h, h->ke_out, 1);
     if ((rc = pull_state(h))) return rc;
+    if ((rc = kernel_error_rc(h))) {
+        h->md_forces_valid = false;
+        return rc;
+    }
     if (h->st_host->sums[12] > 0.5) {
         h->md_forces_valid = false;
         return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two re-decompositions");

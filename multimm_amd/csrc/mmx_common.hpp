@@ -78,6 +78,10 @@ struct FormParams {
     int chb_form;           // 1 gaussian, 2 saturating
 };
 
+// MinState::kernel_error bits
+enum KernelError { KERR_N3_SPIN = 1,   // k_nb_n3: a wave waited for a unit / flush that never came (protocol bug)
+                   KERR_N3_ITEMS = 2 }; // k_nb_n3's item list is too short for this cell build
+
 // Device-resident minimizer state; mirrored to pinned host memory when polled.
 struct MinState {
     int phase;
@@ -95,6 +99,9 @@ struct MinState {
     int n3_queue;        // ... and the head of their queue (persistent workgroups pull from it)
     int dd_stale;        // decomposed runs: an owned bead has moved more than half the skin since the ghost lists were built
     int halt_phase;      // phase to return to after PH_HALT
+    int kernel_error;    // a force kernel could not do its work (KERR_*): the evaluation is void, the controller ends the
+                         // call with status MMX_MIN_KERNEL instead of deciding on partial sums
+    int dd_overflow;     // decomposed runs: a ghost list built on the stream outgrew its message (capacity known to the host)
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;
@@ -160,6 +167,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Orders LDS traffic between the WAVES of a workgroup around a flag in LDS that other waves poll: release before the
+// flag is raised, acquire after it has been seen.  Workgroup scope, LDS only ("local": global loads and atomics in
+// flight are not waited for) -- on gfx950 an s_waitcnt lgkmcnt(0), the same instruction the wavefront-scope fence
+// emits, so the stronger scope costs nothing; what it adds is the guarantee the protocol relies on.
+__device__ __forceinline__ void wg_lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void wg_lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
 // Block-wide sum of one double per thread; result valid on thread 0.  Fixed order => deterministic.
 template <int BLOCK>

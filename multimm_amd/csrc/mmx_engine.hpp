@@ -207,16 +207,17 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     const int tail_items = !tail ? 0 : (tcfg & 15u) ? (int)(tcfg & 15u) * grid / 2 : grid;
     const int tail_sh = !tail ? 0 : (tcfg & 15u) ? (int)((tcfg >> 4) & 3u) : 1;
     const int tail2_items = tail ? grid / 4 : 0, tail2_sh = tail ? 2 : 0;
+    const int spin = (h->inject_fault & 1) ? 0 : kN3SpinLimit; // option "inject_fault" bit 0: every wait of the kernel fails
 #define N3(EV, GA)                                                                                          \
     do {                                                                                                    \
         if (h->nb_skip_energy)                                                                              \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh); \
+                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh, spin); \
         else                                                                                                \
             hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
                                h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh); \
+                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh, spin); \
     } while (0)
     if (P.use_ev && P.use_gauss) N3(true, true);
     else if (P.use_ev) N3(true, false);
@@ -640,12 +641,12 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   h->n3_max_items, h->st);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   h->n3_max_items, h->st);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
@@ -869,6 +870,20 @@ int pull_state(mmx_handle_s *h) {
                                          : "loopback collective timed out: every rank of the group must make the same "
                                            "call from its own thread");
     return MMX_OK;
+}
+
+// After a poll: did a force kernel of the evaluations just read back report that it could not do its work?  Such an
+// evaluation is void -- partial force sums are finite, so nothing else would notice -- and the call ends in
+// MMX_ERR_STATE.  (Decomposed runs: the controller spreads the flag of any rank through the all-reduce.)
+int kernel_error_rc(mmx_handle_s *h) {
+    const int ke = h->st_host->kernel_error;
+    if (!ke) return MMX_OK;
+    std::string what;
+    if (ke & KERR_N3_SPIN) what += " k_nb_n3: a wave waited for a work unit or a window flush that never came;";
+    if (ke & KERR_N3_ITEMS) what += " k_nb_n3: the work-item list is too short for this cell build;";
+    if ((ke & 0xff) == 0) what += " reported by another rank;";
+    return fail(h, MMX_ERR_STATE, "a force kernel could not do its work, the evaluation is void:" + what +
+                                  " forces and energies of this call must not be used");
 }
 
 int ensure_allpairs_scratch(mmx_handle_s *h) {

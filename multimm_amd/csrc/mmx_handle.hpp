@@ -232,6 +232,7 @@ struct mmx_handle_s {
     // hipGraph of consecutive minimizer evaluations (captured per mmx_minimize call, see graph_capture).  OFF by default:
     // on ROCm 7.2 / MI355X replaying loses to launch-by-launch submission at every size measured
     int use_graph = 0, graph_evals = 2; // evaluations per graph (even: the cell grid ping-pongs)
+    int inject_fault = 0; // tests only: bit 0 = every wait of k_nb_n3 times out at once, bit 1 = its item list holds one item
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool capturing = false;

@@ -99,7 +99,9 @@ __device__ __forceinline__ void rows_finish(const double (&acc)[3], double *s_ou
 // Line-search controller, run by ONE thread after every evaluation on the folded (and, in a multi-GPU
 // run, all-reduced) slot sums: exactly liblbfgs' line_search_backtracking with
 // LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE.  Every rank executes it on identical inputs.
-__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums) {
+// kerr: a force kernel of this evaluation reported that it could not do its work (MinState::kernel_error; multi-GPU: of
+// any rank, through the all-reduce): the sums are partial, nothing may be decided on them.
+__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums, const bool kerr) {
     double f = 0.0;
     for (int t = 0; t < 9; ++t) {
         st->eterms[t] = sums[t];
@@ -108,6 +110,16 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     st->ftrial = f;
     const double dg = sums[P_GD], gg = sums[P_GG], xx = sums[P_XX];
     const int phase = st->phase;
+    if (kerr) {
+        st->kernel_error |= 0x100; // (a rank without a failure of its own learns of it here)
+        st->accepted = 0;
+        st->store_hist = 0;
+        if (phase != PH_IDLE) {
+            st->status = -7; // MMX_MIN_KERNEL
+            st->phase = PH_DONE;
+        }
+        return;
+    }
     if (phase == PH_IDLE) return; // plain mmx_compute()
 
     const double ftol = 1e-4, wolfe = 0.9, min_step = 1e-20, max_step = 1e20;
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const doub
     double sums[P_NSLOTS];
 #pragma unroll
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
-    controller_decide(st, sums);
+    controller_decide(st, sums, st->kernel_error != 0);
 }
 
 // Minimizer, single GPU: energies + k_history rows folded together, line-search decision, and on acceptance the
@@ -423,12 +435,23 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
 #pragma unroll
         for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
         dots_from_rows(sums, s_rows);
-        controller_decide(st, sums);
+        controller_decide(st, sums, st->kernel_error != 0);
         s_accepted = st->accepted;
         if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
     }
     __syncthreads();
     if (s_accepted && threadIdx.x < MMX_NBASIS * MMX_NBASIS) st->gram[threadIdx.x] = s_G[threadIdx.x];
+}
+
+// Entries 0..15 of the all-reduced array of a decomposed run: the P_NSLOTS slot sums, then the flags every rank must see
+// alike -- 12: some rank's ghost lists are out of date or outgrew their message (k_dd_displacement, k_dd_build_lists),
+// 13: some rank's force kernel failed (MinState::kernel_error).
+constexpr int kSumStale = 12, kSumKernelError = 13;
+__device__ __forceinline__ double flag_or_sum(const MinState *__restrict__ st, const double *s_out, int t) {
+    if (t < P_NSLOTS) return s_out[t];
+    if (t == kSumStale) return (st->dd_stale || st->dd_overflow) ? 1.0 : 0.0;
+    if (t == kSumKernelError) return st->kernel_error ? 1.0 : 0.0;
+    return 0.0;
 }
 
 // Multi-GPU: fold -> st->sums (+ st->rowsum) -> ncclAllReduce (fp64 sum, in place) -> decide on every rank.
@@ -443,13 +466,13 @@ __global__ __launch_bounds__(1024) void k_reduce_slots(const CtlArgs A, const do
     __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
     slot_counts(A, s_n);
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : (threadIdx.x == 12 && st->dd_stale) ? 1.0 : 0.0;
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = flag_or_sum(st, s_out, threadIdx.x);
 }
 __global__ void k_controller_decide(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
     double sums[P_NSLOTS];
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
-    controller_decide(st, sums);
+    controller_decide(st, sums, st->sums[kSumKernelError] > 0.5);
 }
 __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
                                                      const double *__restrict__ rows, MinState *__restrict__ st) {
@@ -468,12 +491,12 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
     rows_finish<MMX_NROWSUM>(acc, s_rows);
     // slot 12 of the all-reduced array: "some rank's ghost lists are out of date" (see k_dd_displacement)
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = threadIdx.x < P_NSLOTS ? s_out[threadIdx.x] : (threadIdx.x == 12 && st->dd_stale) ? 1.0 : 0.0;
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = flag_or_sum(st, s_out, threadIdx.x);
     if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
-    if (st->sums[12] > 0.5) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
+    if (st->sums[kSumKernelError] <= 0.5 && st->sums[kSumStale] > 0.5) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
         st->halt_phase = st->phase;
         st->phase = PH_HALT;
         st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
@@ -484,7 +507,7 @@ __global__ void k_decide_reduced(MinState *__restrict__ st) {
     double sums[P_NSLOTS];
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
     dots_from_rows(sums, st->rowsum);
-    controller_decide(st, sums);
+    controller_decide(st, sums, st->sums[kSumKernelError] > 0.5);
     if (st->accepted) coef_decide(st, st->rowsum, st->gram, ysl);
 }
 

@@ -88,7 +88,8 @@ struct N3Ctl {
     int fl_next[2], fl_done[2], fl_total[2], fl_nwin[2], fl_ids[2];
     int error;
 };
-constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gives up (a bug, not a state of the data)
+constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gives up (a bug, not a state of the data);
+                                      // the kernel takes the limit as an argument so that a test can inject the failure
 
 // ---- item builder ---------------------------------------------------------------------------------------------
 // One wave per row of the cell grid, lanes = cells of the row.  A cell of >= kN3Dense clusters is cut into equal runs
@@ -195,7 +196,7 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         if (lane == 0) first = atomicAdd(&st->n3_items, total);
         first = __builtin_amdgcn_readfirstlane(first);
         if (first + total > max_items) { // cannot happen (the list has room for a run per cell plus one per 16 clusters)
-            if (lane == 0) st->nan_seen = 1; // surfaces as a failed evaluation
+            if (lane == 0) atomicOr(&st->kernel_error, (int)KERR_N3_ITEMS); // the controller voids the evaluation
             continue;
         }
         // pass 2: emit
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                                           double *__restrict__ part, const int cap_arg,
                                                           const int diag = 0, const int tail_items = 0,
                                                           const int tail_sh = 0, const int tail2_items = 0,
-                                                          const int tail2_sh = 0) {
+                                                          const int tail2_sh = 0, const int spin_limit = kN3SpinLimit) {
     if (st->phase >= PH_DONE) return;
 #ifdef MMX_N3_TIMING
     if (threadIdx.x == 0) {
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // atomic wave instructions.  Zeroes what it flushes; whoever hands in the last token declares unit + 2 ready.
     auto help_flush = [&](int p, int unit) {
         if (vepoch[p] != unit) return;
+        wg_lds_acquire(); // the job description and the window sums of every wave that left the unit
         const int total = ctl.fl_total[p];
         int c = total;
         if (lane == 0 && *(volatile int *)&ctl.fl_next[p] < total) c = atomicAdd(&ctl.fl_next[p], 1);
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             }
         }
         if (c == 0 && lane < 8) wx[cap * 8 + lane] = wy[cap * 8 + lane] = wz[cap * 8 + lane] = 0; // the dummy cluster
-        wave_lds_sync();
+        wg_lds_release(); // the zeroed chunk, before the token that may declare the window ready
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == total) vready[p] = unit + 2;
     };
     // Decides what unit `v` is (the next pass of the item of unit v - 1, or the next item of the queue), stages its
@@ -505,7 +508,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             }
             s_desc[p][lane] = val;
         }
-        wave_lds_sync();
+        wg_lds_release(); // descriptor, ids and boxes, before the caller raises `ready` (or hands in its flush token)
+        __builtin_amdgcn_wave_barrier();
     };
 
     // ---- unit pipeline.  No workgroup barrier: a wave that runs out of i-clusters of unit v moves on to unit v + 1
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         for (int spins = 0; vready[p] < v; ++spins) {
             help_flush(p, v - 2);
             __builtin_amdgcn_s_sleep(2);
-            if (spins > kN3SpinLimit || *(volatile int *)&ctl.error) {
+            if (spins >= spin_limit || *(volatile int *)&ctl.error) {
                 failed = true;
                 break;
             }
@@ -531,15 +535,16 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         if (failed) {
             if (lane == 0) {
                 ctl.error = 1;
-                st->nan_seen = 1; // surfaces as a failed evaluation
+                atomicOr(&st->kernel_error, (int)KERR_N3_SPIN); // the controller voids the evaluation (MMX_MIN_KERNEL)
             }
             break;
         }
-        wave_lds_sync();
+        wg_lds_acquire(); // what the stager / the flushers wrote before they raised `ready`
+        __builtin_amdgcn_wave_barrier();
         const int *dd = s_desc[p];
         const int D_n = __builtin_amdgcn_readfirstlane(dd[1]);
         if (D_n == 0) { // the queue is dry; unit v - 1 may still need its window flushed
-            for (int spins = 0; v > 0 && vready[p ^ 1] < v + 1 && spins < kN3SpinLimit && !*(volatile int *)&ctl.error; ++spins) {
+            for (int spins = 0; v > 0 && vready[p ^ 1] < v + 1 && spins < spin_limit && !*(volatile int *)&ctl.error; ++spins) {
                 help_flush(p ^ 1, v - 1);
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -759,7 +764,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             }
         }
         // ---- out of i-clusters: leave the unit; the last wave to do so opens the flush and stages unit v + 2
-        wave_lds_sync();
+        wg_lds_release(); // this wave's adds into the window, before it is counted out
+        __builtin_amdgcn_wave_barrier();
         int d = 0;
         if (lane == 0) d = atomicAdd(&ctl.done[p], 1);
         d = __builtin_amdgcn_readfirstlane(d);
@@ -773,7 +779,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 ctl.fl_next[p] = 0;
                 ctl.fl_done[p] = 0;
             }
-            wave_lds_sync();
+            wg_lds_release(); // the job description, before the epoch that opens it
+            __builtin_amdgcn_wave_barrier();
             if (lane == 0) vepoch[p] = v; // the job is open
             stage_unit(v + 2);
             if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
