@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no launcher around it (WORLD_SIZE unset) the command starts its own N rank processes -- one per GPU, a
+`python -m torch.distributed.run` child started BEFORE anything touches the GPU -- and passes their one JSON line through;
+under a launcher (the driver's torchrun line) it is one of the ranks.  stdout carries the JSON line and nothing else
+(what libraries print -- RCCL's version banner, Gloo's connection notes -- is sent to stderr).
+
 One "step" is one accepted L-BFGS iteration (liblbfgs "progress" call) of the on-device minimizer
 over a synthetic Hilbert-curve-initialised bead system.  N = 1: BASELINE config 3 (gw_200k: 200 000
 beads, GW preset = EV + compartment blocks + container + lamina + bonds + angles + loops).  N > 1:
@@ -52,10 +57,14 @@ def parse_args():
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg; 0 disables")
     ap.add_argument("--profile-every", type=int, default=16,
-                    help="HIP-event time every k-th launch of each kernel slot inside the timed region "
+                    help="HIP-event time every kernel slot of every k-th evaluation inside the timed region "
                          "(an event pair costs ~10 us of stream time: 16 keeps the perturbation < 1 %%)")
+    ap.add_argument("--profile-nb-every", type=int, default=0,
+                    help="HIP-event time the pair kernel alone in every k-th evaluation (one event pair); 0 = adaptive: "
+                         "often enough for at least 8 samples in the timed region (2 for the driver's 20-step command)")
     ap.add_argument("--dd-timeout", type=float, default=240.0,
-                    help="seconds the extra decomposed leg at N > 1 may take before it is abandoned (the line is printed without it)")
+                    help="seconds the extra decomposed leg at N > 1 may take before it is abandoned: the line is printed "
+                         "with the stage it was in and the process exits with code 3")
     ap.add_argument("--mode", choices=("ensemble", "dd"), default="ensemble",
                     help="what `value` is at N > 1: 'ensemble' = one gw_200k replica per GPU (config 4, weak scaling, no "
                          "collective; the default, with the gw_1m decomposed run reported beside it as the `dd` object); "
@@ -221,8 +230,61 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
     return out
 
 
+_JSON_FD = None
+
+
+def emit(obj: dict) -> None:
+    """The one JSON line, on the process's ORIGINAL stdout (fd 1 itself points at stderr by now, see main)."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
+def spawn_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: start N rank processes as ONE child (torch.distributed.run, which starts
+    the ranks) before this process has made any GPU call -- it never makes one --, hand their JSON line through and
+    return their exit code.  With fewer GPUs visible than ranks (a rehearsal on a one-GPU box) the ranks share devices:
+    torch.distributed then runs on gloo (RCCL refuses two ranks on one device), the line says so, and its numbers are
+    not a scaling measurement."""
+    import socket
+    import subprocess
+    import torch  # device_count() does not initialise the GPU
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus:
+        env.setdefault("MMX_DIST_BACKEND", "gloo")
+        env["MMX_BENCH_REHEARSAL"] = f"{args.gpus} ranks share {ndev} GPU(s): launch-path rehearsal, not a scaling measurement"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if line is not None or proc.returncode else 5
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    # stdout is for the JSON line alone: whatever libraries write to fd 1 (RCCL's version banner, Gloo's connection
+    # notes) goes to stderr from here on
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -271,6 +333,9 @@ def main():
     if args.warmup > 0:
         eng.minimize(tolerance=0.0, max_iters=args.warmup)
     eng.set_option("profile", args.profile_every)
+    # the pair kernel alone is sampled more often (one event pair): at least 8 samples whatever --steps is
+    nb_every = args.profile_nb_every or max(1, min(args.profile_every, args.steps // 8))
+    eng.set_option("profile_nb", nb_every)
     n3_before = eng.get_option("n3_launches")
     barrier()
     t0 = time.perf_counter()
@@ -310,12 +375,16 @@ def main():
             n3_share = (eng.get_option("n3_launches") - n3_before) / max(st.kernel_launches[K_NONBONDED], 1)
             kname = ("k_nb_allpairs" if args.cutoff <= 0 else "k_nb_n3" if n3_share > 0.99 else "k_nb_clusters_j" if n3_share < 0.01
                      else f"k_nb_n3 ({100 * n3_share:.0f} % of the launches: the dense phase), then k_nb_clusters_j")
-            roofline = {"bound": "hbm", "kernel": kname,
+            # what bounds the kernel: VALU issue of the pair arithmetic + culls, and latency (4 waves per SIMD, a third of
+            # the wave cycles waiting: DESIGN.md 5c) -- not HBM.  achieved/peak/frac are the HBM view the metric asks for
+            # (algorithmic bytes / launch time against 8 TB/s); valu_view prices the same launch against the fp32 peak.
+            roofline = {"bound": "valu+latency", "kernel": kname,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc pass (profiles/nb_traffic.json)"
                         if traffic is not None and args.nb_traffic_bytes is None else "command line" if traffic is not None else None,
                         "launch_us": nb_us, "samples": int(st.kernel_samples[K_NONBONDED]),
-                        "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md section 5): see valu_view"}
+                        "note": "achieved/peak/frac = HBM view (32 B/bead algorithmic bytes over the launch time); the kernel "
+                                "itself is bound by VALU issue and latency, see valu_view and its wait counters"}
             if census:
                 directed = census["pairs_within_cutoff"]     # the census walks every bead's full shell
                 pairs = directed / 2.0                        # unique pairs: what the physics needs evaluated
@@ -359,7 +428,8 @@ def main():
                 "workload": f"{system.name}: {n} beads, Hilbert-curve start, "
                             f"{'GW preset (EV+COB+container+lamina+bonds+angles+loops)' if 'gw' in args.workload else 'EV+bonds+angles+loops'}, "
                             f"{system.n_loops} loops, pair cutoff {args.cutoff} nm"
-                            + ("; ONE system, bead slices owned by the GPUs, pos4 all-gather + fp64 all-reduce on RCCL"
+                            + ("; ONE system, bead slices owned by the GPUs, ghost-bead halo exchange (ncclSend/ncclRecv of the "
+                               "beads the peers' need-maps ask for) + one fp64 all-reduce per evaluation on RCCL"
                                if dd else "; one independent replica per GPU (seeds 0..N-1), no collective"
                                if world > 1 else ""),
                 "n_beads": n, "cutoff_nm": args.cutoff, "replicas": 1 if dd else world, "mode": args.mode if world > 1 else "single",
@@ -373,6 +443,8 @@ def main():
             "kernel_algorithmic_GBps": kernel_gbs,
             "roofline": roofline,
         }
+        if os.environ.get("MMX_BENCH_REHEARSAL"):
+            out["rehearsal"] = os.environ["MMX_BENCH_REHEARSAL"]
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
     eng.close()
     if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0 and args.cutoff > 0:
@@ -405,10 +477,10 @@ def main():
             if rank == 0:
                 out["dd"] = {"workload": "gw_1m", "mode": "dd", "ranks": world,
                              "error": f"no result after {args.dd_timeout:.0f} s (stage: {progress['stage']}); leg abandoned"}
-                print(json.dumps(out), flush=True)
+                emit(out)
             else:
                 time.sleep(3.0)
-            os._exit(0)
+            os._exit(3)  # a hang of a process that holds the GPU is a failure, with the line as its post-mortem
         threading.Thread(target=watchdog, daemon=True).start()
         leg = dd_leg(args, rank, world, local_rank, tdev, barrier, progress)
         finished.set()
@@ -418,12 +490,13 @@ def main():
         if n_gpus == 1 and args.replicas_per_gpu > 1:
             out["replicas_per_gpu"] = replicas_per_gpu_leg(args.workload, args.n_beads, args.cutoff, local_rank,
                                                            args.replicas_per_gpu, args.steps)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         import threading
-        threading.Timer(30.0, lambda: os._exit(0)).start()  # a rank that lost its peers must not keep the launcher waiting
+        threading.Timer(60.0, lambda: os._exit(4)).start()  # a rank that lost its peers must not keep the launcher waiting
         dist.barrier()
         dist.destroy_process_group()
+        sys.stderr.flush()
         os._exit(0)
 
 

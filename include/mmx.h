@@ -109,10 +109,11 @@ int mmx_abi_version(void);
  * One process and one handle per GPU.  Rank r of `world` owns the contiguous bead range
  * [r*slice, min(N, (r+1)*slice)), slice = ceil(N/world): forces, energies and the L-BFGS state of those
  * beads live on its GPU.  Every setter still takes the arrays of the WHOLE system.  Per evaluation the
- * ranks all-gather their position slices (ghost beads for pair, bond, angle and loop terms) and
- * all-reduce once: 57 doubles in the minimizer (energies, the three Gram rows an accepted step would change, g.d,
- * x.x), 16 in a plain evaluation -- RCCL, issued on the handle's stream, no host round trip.  Without a communicator a multi-rank
- * handle still evaluates its owned beads against the positions last set by the host (unit tests). */
+ * ranks exchange ghost beads (what lies within the cutoff of a peer's owned beads, by the peers' need-maps; backbone
+ * neighbours and loop partners across slice ends) with ncclSend/ncclRecv and all-reduce once: 59 doubles in the
+ * minimizer (energies, the three Gram rows an accepted step would change, g.d, x.x, two flags), 16 in a plain
+ * evaluation -- RCCL, issued on the handle's stream, no host round trip (csrc/mmx_dd.hpp).  Without a communicator a
+ * multi-rank handle still evaluates its owned beads against the positions last set by the host (unit tests). */
 int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out);
 int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world);
 /* rank 0: 128-byte ncclUniqueId to hand to every rank (e.g. by torch.distributed broadcast). */
@@ -190,17 +191,26 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     a fixed summation order (bitwise reproducible runs, ~5 % slower at 200 000 beads)   0
  * "profile"           k>0: HIP-event time the kernel slots of every k-th evaluation of a
  *                     minimization (every k-th launch of a slot elsewhere)            0
+ * "profile_nb"        k>0 (with "profile" > 0): also time the pair-kernel slot alone in every k-th
+ *                     evaluation of a minimization (one event pair: more samples of the dominant kernel) 0
  * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them
  *                     per graph, even) instead of launching them one by one; same bits; slower on
  *                     ROCm 7.2 at every size measured, kept for A/B     0
- * "dd_halo"           decomposed runs with a communicator: 1 = ghost-bead halo exchange (lists rebuilt at
- *                     re-decomposition, ncclSend/ncclRecv of the listed beads per evaluation);
- *                     0 = all-gather of every position per evaluation (round-1 path, A/B)  1
- * "dd_skin"           nm; the ghost lists hold while no bead has moved more than half of it; the
- *                     minimizer doubles it (up to 1.6) when lists go stale within 8 evaluations
- *                     and halves it again after 128 quiet ones                          0.1
- * "dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_skin_now"
- *                     (get only) statistics of the decomposed run
+ * "dd_halo"           decomposed runs with a communicator: 1 = ghost-bead halo exchange (ghosts chosen by the
+ *                     peers' need-maps -- coarse-cell occupancy grown by the cutoff --, ncclSend/ncclRecv of the
+ *                     listed beads per evaluation); 0 = all-gather of every position per evaluation (round-1 path,
+ *                     A/B; also what a run with chromosomal blocks uses: that term has no cutoff)  1
+ * "dd_rebuild_every"  K: the ghost lists are rebuilt, on the stream, before every K-th evaluation.  1: before each
+ *                     one -- exact lists, no skin, one 32 KB all-gather more per evaluation; K > 1: the lists reach
+ *                     cutoff + dd_skin and hold while no bead has moved more than dd_skin / 2 (checked on the
+ *                     device; a violation voids the evaluation, which is repeated with fresh lists)          1
+ * "dd_skin"           nm, K > 1 only; doubled (up to 0.8) for the rest of a call whenever a list went stale   0.2
+ * "dd_ghosts", "dd_ghost_slots", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_sync_rebuilds",
+ * "dd_halts", "dd_capacity_updates", "dd_skin_now"
+ *                     (get only) statistics of the decomposed run: ghosts listed for this rank / slots of its
+ *                     incoming messages (capacity) at the last poll; halo exchanges; bytes this rank put on the
+ *                     wire in them; list rebuilds (all / host-synchronous); evaluations voided and repeated;
+ *                     polls that resized a message
  * nb_variant bits:    4096 force the half-shell pair kernel, 8192 force the full-shell one (default: chosen by
  *                     system size and cell occupancy); bits 24-30 configure the tail shares of the
  *                     half-shell kernel (A/B); the other bits select round-1 A/B and diagnosis instances
@@ -213,7 +223,9 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "order_fallbacks"   (get only) cells of the last call that were too large for the in-LDS sort and
  *                     kept arrival order: 0 means the summation order was bitwise reproducible
  * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
- *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE     0
+ *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE;
+ *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a
+ *                     ghost list exercises the halt-and-repeat protocol                                          0
  */
 int mmx_set_option(mmx_handle h, const char *key, double value);
 int mmx_get_option(mmx_handle h, const char *key, double *value);

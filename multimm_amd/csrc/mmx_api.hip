@@ -74,6 +74,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->perm, (size_t)h->n_all));
         if (h->world > 1) HIPCHK(h, dalloc(&h->xg, (size_t)3 * h->n_all));
         HIPCHK(h, dalloc(&h->count, (size_t)h->maxcells + 1));
+        if (h->world > 1) HIPCHK(h, dalloc(&h->count_own, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->rank_in_cell, (size_t)h->n_all));
         HIPCHK(h, dalloc(&h->start, (size_t)h->maxcells + 1));
         HIPCHK(h, dalloc(&h->istart, (size_t)h->maxcells + 1));
@@ -93,9 +94,9 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             }
             HIPCHK(h, hipMemcpy(h->spos4 + (size_t)h->n_all * 8, farc, sizeof(farc), hipMemcpyHostToDevice));
         }
-        // half-shell pair kernel: force per cluster slot (single-domain handles only) and its LDS window.  Above 64 KB of
-        // LDS per workgroup the runtime wants to be told; a device that refuses keeps the full-shell kernel.
-        if (h->world == 1) {
+        // half-shell pair kernel: force per cluster slot and its LDS window.  Above 64 KB of LDS per workgroup the runtime
+        // wants to be told; a device that refuses keeps the full-shell kernel.
+        {
             h->fstride = (h->n_all + 1) * 8;
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
             h->n3_cap = n3_configure(kN3MaxCap);
@@ -224,8 +225,10 @@ int mmx_destroy(mmx_handle h) try {
     for (void *p : {(void *)h->v, (void *)h->xlo, (void *)h->ke_part, (void *)h->ke_out, (void *)h->formp, (void *)h->lbox[0],
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
-                    (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref})
+                    (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own})
         if (p) (void)hipFree(p);
+    if (h->dd_cnt_host) (void)hipHostFree(h->dd_cnt_host);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
                     h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
@@ -577,6 +580,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     const std::string k(key);
     if (k == "deterministic") h->deterministic = value != 0.0;
     else if (k == "profile") h->profile = (int)value;
+    else if (k == "profile_nb") h->profile_nb = std::max(0, (int)value);
     else if (k == "poll_interval") h->poll_interval = std::max(1, (int)value);
     else if (k == "nb_variant") h->nb_variant = (int)value;
     else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
@@ -586,6 +590,11 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "dd_skin") {
         if (!(value > 0.0)) return fail(h, MMX_ERR_BAD_ARG, "dd_skin must be positive");
         h->dd_skin = h->dd_skin_cur = (float)value;
+    }
+    else if (k == "dd_rebuild_every") {
+        if (!(value >= 1.0)) return fail(h, MMX_ERR_BAD_ARG, "dd_rebuild_every must be >= 1");
+        h->dd_every = (int)value;
+        h->dd_lists_valid = false;
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else if (k == "inject_fault") h->inject_fault = (int)value;
@@ -598,6 +607,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     const std::string k(key);
     if (k == "deterministic") *value = h->deterministic;
     else if (k == "profile") *value = h->profile;
+    else if (k == "profile_nb") *value = h->profile_nb;
     else if (k == "poll_interval") *value = h->poll_interval;
     else if (k == "nb_variant") *value = h->nb_variant;
     else if (k == "fused_bonded") *value = h->fused_bonded;
@@ -608,7 +618,18 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_halo") *value = h->dd_halo;
     else if (k == "dd_skin") *value = h->dd_skin;
     else if (k == "dd_skin_now") *value = h->dd_skin_cur;
-    else if (k == "dd_ghosts") *value = h->dd_nghost;                       // read-only statistics of a decomposed run
+    else if (k == "dd_rebuild_every") *value = h->dd_every;
+    else if (k == "dd_halts") *value = (double)h->dd_halts;
+    else if (k == "dd_capacity_updates") *value = (double)h->dd_cap_updates;
+    else if (k == "dd_sync_rebuilds") *value = (double)h->dd_sync_rebuilds;
+    else if (k == "dd_ghost_slots") *value = h->dd_nghost;
+    else if (k == "dd_ghosts") { // read-only statistics of a decomposed run: ghosts listed for this rank at the last poll
+        double g = 0.0;
+        if (h->dd_cnt_host)
+            for (int q = 0; q < h->world; ++q)
+                if (q != h->rank) g += h->dd_cnt_host[(size_t)h->world * q + h->rank];
+        *value = g;
+    }
     else if (k == "dd_redecompositions") *value = (double)h->dd_redecompositions;
     else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
     else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
@@ -678,14 +699,17 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->Y, 0, sizeof(float) * nv * MMX_M, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
-    h->dd_skin_cur = std::max(h->dd_skin_cur, h->dd_skin);
-    h->dd_last_rebuild_eval = 0;
+    h->dd_skin_cur = h->dd_skin;
+    h->dd_slack_div = 8;
+    // every exit from here on goes through leave(): per-evaluation profiling back to per-slot sampling, graph dropped
+    auto leave = [&](int code) {
+        h->prof_eval = -1;
+        graph_drop(h);
+        return code;
+    };
     h->prof_eval = 1; // the first evaluation is a profiling sample when profiling is on
     enqueue_eval(h, PACK_PLAIN, FOLD_MIN);
-    if ((rc = pull_state(h))) {
-        h->prof_eval = -1;
-        return rc;
-    }
+    if ((rc = pull_state(h))) return leave(rc);
     local.e_initial = h->st_host->fx;
     // Trial evaluations: pairs of them are replayed from a hipGraph (single-GPU runs; option use_graph), except the
     // every profile-th evaluation, which goes out launch by launch with HIP events around every kernel slot.
@@ -701,49 +725,37 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             have_graph = graph_capture(h);
         }
         for (int b = 0; b < batch;) {
-            const bool s0 = h->profile > 0 && eval_no % h->profile == 0, s1 = h->profile > 0 && (eval_no + 1) % h->profile == 0;
+            const bool s0 = h->profile > 0 && eval_no % h->profile == 0;
             bool sampled = false; // a profiling sample inside the span a replay would cover?
             for (int k = 0; k < h->graph_evals; ++k) sampled = sampled || (h->profile > 0 && (eval_no + k) % h->profile == 0);
-            (void)s1;
             if (have_graph && !sampled && b + h->graph_evals <= batch && (h->build_idx & 1) == h->gkey_parity && graph_replay(h)) {
                 b += h->graph_evals;
                 eval_no += h->graph_evals;
                 continue;
             }
-            h->prof_eval = s0 ? 1 : 0;
-            enqueue_eval(h, PACK_MOVE, FOLD_MIN);
+            h->prof_eval = s0 ? 1 : (h->profile > 0 && h->profile_nb > 0 && eval_no % h->profile_nb == 0) ? 2 : 0;
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN, dd_schedule(h));
+            if (h->dd_rc != MMX_OK) return leave(h->dd_rc);
             ++b;
             ++eval_no;
         }
-        if ((rc = pull_state(h))) {
-            h->prof_eval = -1;
-            graph_drop(h);
-            return rc;
-        }
+        if ((rc = pull_state(h))) return leave(rc);
         while (h->st_host->phase == PH_HALT) {
-            // decomposed run: an evaluation found the ghost lists out of date and decided nothing.  New lists at the
-            // trial point (the pack of the repeated evaluation writes it again), then the evaluation itself.
+            // decomposed run: an evaluation found a ghost list out of date (a bead beyond half the skin, dd_every > 1) or
+            // longer than its message, and decided nothing.  New lists and capacities at the trial point (the pack of the
+            // repeated evaluation writes it again), then the evaluation itself.
+            h->dd_halts++;
+            // (both policies read the all-reduced flags: every rank must arrive at the same capacities and the same skin)
+            if (h->st_host->sums[kSumOverflow] > 0.5) h->dd_slack_div = std::max(2, h->dd_slack_div / 2); // lists grow faster than assumed
+            if (h->st_host->sums[kSumStale] > 0.5) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f); // the skin did not last dd_every evaluations
             h->st_host->phase = h->st_host->halt_phase;
             h->st_host->dd_stale = 0;
-            // early in a minimization beads move fast: a skin that lasted fewer than 8 evaluations is doubled (more
-            // ghosts per exchange, fewer host round trips); the poll loop below halves it again when things calm down
-            if (h->st_host->evals - h->dd_last_rebuild_eval < 8) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 1.6f);
-            h->dd_last_rebuild_eval = h->st_host->evals;
-            if ((rc = push_state(h))) return rc;
+            h->st_host->dd_overflow = 0;
+            if ((rc = push_state(h))) return leave(rc);
             h->prof_eval = 0;
-            enqueue_eval(h, PACK_MOVE, FOLD_MIN, true);
-            if (h->dd_rc != MMX_OK) return h->dd_rc;
-            if ((rc = pull_state(h))) return rc;
-        }
-        if (use_halo(h) && h->dd_skin_cur > h->dd_skin && h->st_host->evals - h->dd_last_rebuild_eval >= 128 &&
-            h->st_host->phase != PH_DONE) {
-            // 128 evaluations without a stale list: try half the skin (the lists are rebuilt by the next evaluation)
-            h->dd_skin_cur = std::max(h->dd_skin, 0.5f * h->dd_skin_cur);
-            h->dd_last_rebuild_eval = h->st_host->evals;
-            h->prof_eval = 0;
-            enqueue_eval(h, PACK_MOVE, FOLD_MIN, true);
-            if (h->dd_rc != MMX_OK) return h->dd_rc;
-            if ((rc = pull_state(h))) return rc;
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN, 1);
+            if (h->dd_rc != MMX_OK) return leave(h->dd_rc);
+            if ((rc = pull_state(h))) return leave(rc);
         }
         if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
     }
@@ -907,9 +919,9 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         // aMD reads the potential energy of the current positions at every step
         const bool report = h->md_kind == MD_AMD || s + 1 == n_steps || (s + 1) % poll_every == 0;
         h->nb_skip_energy = !report;
-        // decomposed runs: new ghost lists at the first step of a call that has none and after every poll (a bead moves
-        // ~1e-5 nm per step: the skin outlasts the poll interval by orders of magnitude; checked below all the same)
-        const bool redecomp = use_halo(h) && (!h->dd_lists_valid || (s > 0 && s % poll_every == 0));
+        // decomposed runs: a call that has no ghost lists builds them synchronously at its first step; afterwards they are
+        // rebuilt on the stream like the minimizer's (every dd_rebuild_every-th step; checked at the polls all the same)
+        const int redecomp = !use_halo(h) ? 0 : !h->dd_lists_valid ? 1 : dd_schedule(h);
         enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE, redecomp);
         h->nb_skip_energy = false;
         h->md_step++;
@@ -920,10 +932,12 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
                 h->md_forces_valid = false;
                 return rc;
             }
-            if (h->st_host->sums[12] > 0.5) { // all-reduced: every rank sees it
+            if (h->st_host->sums[kSumStale] > 0.5 || h->st_host->sums[kSumOverflow] > 0.5) { // all-reduced: every rank sees it
                 h->md_forces_valid = false;
-                return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two "
-                                              "re-decompositions: step too large for the decomposed run");
+                h->dd_lists_valid = false;
+                return fail(h, MMX_ERR_STATE, "a ghost list of the decomposed run went out of date during MD (a bead moved more "
+                                              "than half of dd_skin between two rebuilds, or a list outgrew its message): "
+                                              "the steps since the last poll are void; call again (the lists are rebuilt)");
             }
             const double f = h->st_host->ftrial;
             if (!(f - f == 0.0)) {
@@ -944,9 +958,11 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         h->md_forces_valid = false;
         return rc;
     }
-    if (h->st_host->sums[12] > 0.5) {
+    if (h->st_host->sums[kSumStale] > 0.5 || h->st_host->sums[kSumOverflow] > 0.5) {
         h->md_forces_valid = false;
-        return fail(h, MMX_ERR_STATE, "a bead moved more than half the ghost skin (dd_skin) between two re-decompositions");
+        h->dd_lists_valid = false;
+        return fail(h, MMX_ERR_STATE, "a ghost list of the decomposed run went out of date during MD: the last steps are void; "
+                                      "call again (the lists are rebuilt)");
     }
     double ke = 0.0;
     HIPCHK(h, hipMemcpy(&ke, h->ke_out, sizeof(double), hipMemcpyDeviceToHost));

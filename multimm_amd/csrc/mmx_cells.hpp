@@ -8,9 +8,13 @@ namespace mmx {
 // Slot of a bead inside its cell: group the lanes of the wave by cell with ballots only (no memory traffic inside
 // the loop), then let the first lane of every group issue its atomicAdd in ONE instruction -- one round trip per
 // wave instead of one per distinct cell (Hilbert-ordered beads: ~3 distinct cells per wave).  Whole wave must call.
-__device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count) {
+// count_own (decomposed runs): the cell's OWNED beads are counted separately -- they and the ghosts of a cell form
+// separate clusters (cell_scan_block, emit_clusters).
+__device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count,
+                                          int *__restrict__ count_own = nullptr, bool owned = true) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long own_lanes = count_own ? __ballot(todo && owned) : 0ull;
     unsigned long long pending = __ballot(todo), mine = 0ull;
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
@@ -21,7 +25,10 @@ __device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restri
     }
     const int first = todo ? __ffsll((long long)mine) - 1 : lane;
     int base = 0;
-    if (todo && lane == first) base = atomicAdd(&count[c], __popcll(mine));
+    if (todo && lane == first) {
+        base = atomicAdd(&count[c], __popcll(mine));
+        if (count_own && (mine & own_lanes)) atomicAdd(&count_own[c], __popcll(mine & own_lanes));
+    }
     base = __shfl(base, first, 64);
     if (todo) rank[i] = base + __popcll(mine & lt);
 }
@@ -209,15 +216,15 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
                                                     const float4 *__restrict__ pos4,
                                                     const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                     int *__restrict__ rank, int *__restrict__ count,
-                                                    const MinState *__restrict__ st) {
+                                                    const MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
     if (st->phase >= PH_DONE) return;
     const GridParams G = *grid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool todo = i < n_all;
     int c = 0;
+    const bool owned = (unsigned)(i - own_lo) < (unsigned)n_own;
     if (todo) {
         const float4 p = pos4[i];
-        const bool owned = (unsigned)(i - own_lo) < (unsigned)n_own;
         if (!owned) {
             // ghost candidate (multi-GPU): kept only when strictly inside the (cutoff-expanded) grid
             const float fx = (p.x - G.ox) * G.inv_h, fy = (p.y - G.oy) * G.inv_h, fz = (p.z - G.oz) * G.inv_h;
@@ -231,8 +238,11 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
         }
         cell_of[i] = todo ? c : -1;
     }
-    cell_rank(todo, c, i, rank, count);
+    cell_rank(todo, c, i, rank, count, count_own, owned);
 }
+
+// Clusters of a cell of k beads, ko of them owned: owned beads and ghosts never share a cluster (single-domain runs: ko = k).
+__device__ __forceinline__ int cell_clusters(int k, int ko) { return ((ko + 7) >> 3) + ((k - ko + 7) >> 3); }
 
 // Single-block exclusive scan of the cell populations (bead offsets) and of the per-cell chunk
 // counts (work-item offsets); publishes the item count and the grid of the next build.
@@ -245,13 +255,14 @@ struct ScanArgs {
     int *start, *istart, *cstart, *biglist;
     const GridParams *grid;
     GridParams *grid_next;
+    const int *count_own; // decomposed runs: owned beads per cell (nullptr: every bead is owned)
 };
 template <int CHUNK>
 __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__restrict__ st) {
     const float *__restrict__ bbox_part = a.bbox_part;
     const int nblk = a.nblk, maxcells = a.maxcells;
     const float hmin = a.hmin;
-    const int *__restrict__ count = a.count;
+    const int *__restrict__ count = a.count, *__restrict__ count_own = a.count_own;
     int *__restrict__ start = a.start, *__restrict__ istart = a.istart, *__restrict__ cstart = a.cstart,
                       *__restrict__ biglist = a.biglist;
     const GridParams *__restrict__ grid = a.grid;
@@ -269,7 +280,7 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
         const int k = count[c];
         sa += k;
         sb += (k + CHUNK - 1) / CHUNK;
-        sc += (k + 7) >> 3;
+        sc += cell_clusters(k, count_own ? count_own[c] : k);
         sd += k > 64 ? 1 : 0;
         mx = max(mx, k);
     }
@@ -334,7 +345,7 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
         if (k > 64) biglist[rd++] = c; // cells the order kernel sorts with a whole block, one per block
         ra += k;
         rb += (k + CHUNK - 1) / CHUNK;
-        rcl += (k + 7) >> 3;
+        rcl += cell_clusters(k, count_own ? count_own[c] : k);
     }
     if (t == 1023) {
         start[G.ncells] = tot_a;
@@ -436,25 +447,31 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
 // bitwise reproducible) and is counted in st->order_fallbacks.
 
 // padded cluster positions + boxes of one sorted cell; `nthr` cooperating threads, thread index `tid`
-__device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, const int *__restrict__ perm,
+// `no`: owned beads of the cell (they come first in the sorted order: order_key); the ghosts start a new cluster, so that
+// a cluster is all-owned or all-ghost (the half-shell kernel weights energies and drops reactions per cluster).
+__device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int cb, const int *__restrict__ perm,
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, int own_lo, int n_own,
                                               const unsigned long long *keys = nullptr) {
-    const int ncl = (cnt + 7) >> 3;
+    const int o8 = ((no + 7) >> 3) << 3; // slots of the owned clusters
+    const int ncl = cell_clusters(cnt, no);
     for (int e = tid; e < ncl * 8; e += nthr) {
         float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
         int nown = 0;
-        if (e < cnt) {
+        const int src = e < o8 ? (e < no ? e : -1) : (e - o8 < cnt - no ? no + (e - o8) : -1); // place in the sorted cell
+        const bool real = src >= 0;
+        if (real) {
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
-            const int b = keys ? (int)(unsigned)(keys[e] & 0xffffffffull) : perm[s + e];
+            const int b = keys ? (int)(unsigned)(keys[src] & 0xffffffffull) : perm[s + src];
             p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
             nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
         }
         spos4[(size_t)cb * 8 + e] = p;
         const float big = 3.0e38f;
-        float lx = e < cnt ? p.x : big, ly = e < cnt ? p.y : big, lz = e < cnt ? p.z : big;
-        float hx = e < cnt ? p.x : -big, hy = e < cnt ? p.y : -big, hz = e < cnt ? p.z : -big;
+        float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
+        float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
+        int nreal = real ? 1 : 0;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
             lx = fminf(lx, __shfl_xor(lx, o, 64));
@@ -464,12 +481,13 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int cb, con
             hy = fmaxf(hy, __shfl_xor(hy, o, 64));
             hz = fmaxf(hz, __shfl_xor(hz, o, 64));
             nown += __shfl_xor(nown, o, 64);
+            nreal += __shfl_xor(nreal, o, 64);
         }
         if ((e & 7) == 0) { // lo.w = cell id, hi.w = (owned beads << 8) | beads of the cluster
             // one 32-byte record per cluster: {lo, hi} interleaved in cl_lo (cl_hi is unused: both halves of a box are
             // then fetched by two back-to-back 16-byte loads from one address)
             cl_lo[2 * (cb + (e >> 3))] = make_float4(lx, ly, lz, __int_as_float(c));
-            cl_lo[2 * (cb + (e >> 3)) + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | min(8, cnt - e)));
+            cl_lo[2 * (cb + (e >> 3)) + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | nreal));
         }
     }
 }
@@ -560,7 +578,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  float4 *__restrict__ cl_hi, int own_lo, int n_own,
                                                  const unsigned long long *__restrict__ okeys,
                                                  const int *__restrict__ biglist,
-                                                 MinState *__restrict__ st) {
+                                                 MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
@@ -577,7 +595,11 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
     for (int c = (bid - nB) * 4 + wave; bid >= nB && c < ncells; c += (nblk - nB) * 4) {
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt > 64) continue;
-        if (lane == 0) count[c] = 0;
+        const int no = count_own ? count_own[c] : cnt;
+        if (lane == 0) {
+            count[c] = 0;
+            if (count_own) count_own[c] = 0;
+        }
         if (cnt == 0) continue;
         if (lane == 0) items[istart[c]] = make_int2(c, 0);
         if (cnt > 1) {
@@ -595,7 +617,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -604,7 +626,12 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         const int c = biglist[bi];
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt <= 64) continue; // (cannot happen; block-uniform)
-        if (threadIdx.x == 0) count[c] = 0;
+        const int no = count_own ? count_own[c] : cnt;
+        __syncthreads(); // every thread has read count_own[c]
+        if (threadIdx.x == 0) {
+            count[c] = 0;
+            if (count_own) count_own[c] = 0;
+        }
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
         for (int k = threadIdx.x; k < nchunk; k += 256) items[ib + k] = make_int2(c, k);
         if (cnt <= 1024) { // keys in registers, <= 3 exchanges through LDS
@@ -615,7 +642,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf);
+            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -665,7 +692,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         }
         else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
         // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
     }
 }
 
@@ -679,10 +706,10 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
                                                     const int *__restrict__ biglist,
-                                                    MinState *__restrict__ st) {
+                                                    MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st);
+                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own);
 }
 
 } // namespace mmx

@@ -3,30 +3,54 @@
 // Rank r owns the bead slice [own_lo, own_lo + n_own) -- the Hilbert start makes index slices spatially compact -- and
 // needs, per evaluation, the positions of (a) every foreign bead within the pair cutoff of its owned beads, (b) the two
 // backbone neighbours beyond each slice end and (c) the loop partners of its owned beads.  Instead of gathering every
-// position on every rank, each owner SENDS what the others need:
+// position on every rank, each owner SENDS what the others need, and WHAT they need is decided by geometry:
 //
-//   re-decomposition (host-synchronous; at the start of a call, and whenever an evaluation finds the lists stale):
-//     all-gather of the positions and of the ranks' owned bounding boxes; every rank lists, per destination q, its
-//     owned beads that lie inside q's box grown by cutoff + skin, plus the static partners of (b) and (c); the
-//     world x world matrix of list lengths is all-gathered and read by the host: these are the message sizes.
-//   every evaluation: k_dd_pack gathers the listed beads' float4 {x, y, z, id|label} into one send buffer per
-//     destination; grouped ncclSend/ncclRecv of exactly the listed entries; k_dd_unpack scatters what arrived into
-//     pos4 by the id each entry carries and writes the ghost id list that the cell build bins next to the owned beads.
-//     No position of a bead outside the halo is touched, sent or binned.
-//   validity: the lists hold for as long as no bead has moved more than skin / 2 since they were built
-//     (k_dd_displacement, every evaluation, on the owned beads -- every bead is owned by someone).  The flag rides in
-//     the evaluation's one all-reduce; when it is up, k_decide_reduced decides nothing and halts (PH_HALT), the host
-//     re-decomposes at the trial point and repeats the evaluation.
+//   need-maps.  Space is cut into a coarse grid of 64^3 cells of edge >= reach / 2 (reach = cutoff + skin; one 64-bit
+//     word per (z, y) row, x = the bit: 32 KB per rank).  A rank marks the cells its owned beads sit in
+//     (k_dd_occupancy), grows the set by ceil(reach / edge) <= 2 cells in every direction (k_dd_dilate: "I need every
+//     bead of these cells") and the ranks all-gather their maps.  Owned bead i then goes to rank q iff the bit of
+//     its cell is set in q's map, or it is a static partner of q ((b), (c): one bit per rank and bead).  A map follows
+//     the SHAPE of a slice -- a concave blob of the collapsed globule as well as a brick of the lattice start; round 2
+//     tested against the slice's bounding box and sent a third of everybody else.  Cell indices wrap (& 63): a bead
+//     outside the grid of the last synchronous rebuild aliases into it, which can only add ghosts, never lose one.
+//   lists on the stream.  k_dd_build_lists appends bead ids to one list per destination (wave-aggregated atomics).
+//     The whole rebuild -- occupancy, dilation, all-gather of the maps, lists -- is enqueued on the handle's stream with
+//     no host round trip; by default it runs before EVERY evaluation ("dd_rebuild_every" = 1), so the lists are exact
+//     for the positions they are used with and there is no skin at all.  With a rebuild every K > 1 evaluations the
+//     lists hold while no bead has moved more than skin / 2 (k_dd_displacement).
+//   messages of host-known capacity.  ncclSend / ncclRecv need their sizes on the host, the lists are sized on the
+//     device: a message carries `cap` entries (the length of the list at the last synchronous rebuild + 1/8 + 512),
+//     entries beyond the list are padding (bead id -1).  Every all-gather of the maps also carries the senders' current
+//     list lengths, so each poll of the host sees the world x world matrix of lengths and both ends of a message
+//     re-derive its capacity from the same numbers before a list outgrows it.
+//   when it still goes wrong -- a list longer than its message (dd_overflow), or a bead beyond skin / 2 (dd_stale, K > 1)
+//     -- the flag rides in the evaluation's one all-reduce, k_decide_reduced decides nothing and halts (PH_HALT) on
+//     every rank, the host rebuilds synchronously at the trial point (fresh capacities) and repeats the evaluation.
+//   every evaluation: k_dd_pack gathers the listed beads' float4 {x, y, z, id|label}; grouped ncclSend/ncclRecv, one
+//     message per pair of ranks that share any; k_dd_unpack scatters what arrived into pos4 by the id each entry
+//     carries and writes the ghost id list that the cell build bins next to the owned beads.  No position of a bead
+//     outside the halo is touched, sent or binned; nothing but 6 floats per rank is ever all-gathered from everybody.
 #pragma once
 #include "mmx_cells.hpp"
 #include "mmx_common.hpp"
 
 namespace mmx {
 
-constexpr int kDDMaxWorld = 64; // static partner masks are one bit per rank
+constexpr int kDDMaxWorld = 64;                          // static partner masks are one bit per rank
+constexpr int kDDGridN = 64;                             // coarse cells per axis (x = the bit of a 64-bit word)
+constexpr int kDDWords = kDDGridN * kDDGridN;            // words of a need-map: [z][y]
+constexpr int kDDPayload = kDDWords + kDDMaxWorld / 2;   // ... + the rank's send-list lengths (kDDMaxWorld ints)
 
 struct DDOffsets {
-    int off[kDDMaxWorld + 1]; // prefix of the per-source ghost counts
+    int off[kDDMaxWorld + 1]; // prefix of the per-source message capacities
+};
+struct DDCaps {
+    int cap[kDDMaxWorld]; // entries per message (to / from rank q)
+};
+// Coarse grid of the need-maps (device; written by k_dd_grid at a synchronous rebuild, read by the rebuilds on the stream)
+struct DDGrid {
+    float ox, oy, oz, inv_edge, edge;
+    int radius; // cells a map is grown by: ceil(reach / edge)
 };
 
 // owned bounding box of this rank from k_pack's per-block boxes -> out6 = {lo x y z, hi x y z}; one block
@@ -57,60 +81,158 @@ __global__ __launch_bounds__(256) void k_dd_bbox(const float *__restrict__ bbox_
     }
 }
 
-// Send lists: owned bead i goes to rank q when it is a static partner of q (backbone neighbour beyond a slice end, loop
-// partner) or lies inside q's owned box grown by `reach` = cutoff + skin.  Lanes of a wave that go to the same rank
-// share one atomic; the order inside a list is arbitrary (the receiver's cell build sorts ghosts by position and id).
-__global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, int rank, int world,
-                                                        const float *__restrict__ x, const float *__restrict__ boxes,
-                                                        float reach, const unsigned long long *__restrict__ static_mask,
-                                                        int *__restrict__ send_ids, int slice, int *__restrict__ send_cnt) {
+// Coarse grid from the all-gathered owned boxes: every rank computes the same numbers from the same input.  The grid
+// spans the whole system with two cells of margin; its edge is reach / 2 unless the system is larger than 60 such cells.
+__global__ void k_dd_grid(const float *__restrict__ boxes, int world, float reach, DDGrid *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int q = 0; q < world; ++q) {
+        const float *b = boxes + 6 * q;
+        if (!(b[0] <= b[3]) || !(b[1] <= b[4]) || !(b[2] <= b[5])) continue; // a rank without (finite) beads
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], b[k]);
+            hi[k] = fmaxf(hi[k], b[k + 3]);
+        }
+    }
+    float ext = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.f;
+        ext = fmaxf(ext, hi[k] - lo[k]);
+    }
+    DDGrid G;
+    G.edge = fmaxf(0.5f * reach, ext * (1.f / (float)(kDDGridN - 4)));
+    if (!(G.edge > 1e-6f) || !(G.edge < 1e30f)) G.edge = 1.f;
+    G.inv_edge = 1.f / G.edge;
+    G.radius = max(1, (int)ceilf(reach * G.inv_edge - 1e-4f));
+    G.ox = lo[0] - 2.f * G.edge;
+    G.oy = lo[1] - 2.f * G.edge;
+    G.oz = lo[2] - 2.f * G.edge;
+    *out = G;
+}
+
+// coarse cell of a position: word index (z, y) and x bit; indices wrap, so any finite position has a cell
+__device__ __forceinline__ void dd_cell(const DDGrid &G, float px, float py, float pz, int &word, int &bit) {
+    const int cx = (int)floorf((px - G.ox) * G.inv_edge) & (kDDGridN - 1);
+    const int cy = (int)floorf((py - G.oy) * G.inv_edge) & (kDDGridN - 1);
+    const int cz = (int)floorf((pz - G.oz) * G.inv_edge) & (kDDGridN - 1);
+    word = cz * kDDGridN + cy;
+    bit = cx;
+}
+
+// occ |= the coarse cells of the owned beads.  Consecutive beads mostly share a cell: lanes of a wave with the same cell
+// issue one atomic.
+__global__ __launch_bounds__(256) void k_dd_occupancy(int n_own, const float *__restrict__ x, const DDGrid *__restrict__ grid,
+                                                      unsigned long long *__restrict__ occ, const MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    const DDGrid G = *grid;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n_own;
-    float px = 0.f, py = 0.f, pz = 0.f;
+    int word = 0, bit = 0;
+    if (act) dd_cell(G, x[3 * i], x[3 * i + 1], x[3 * i + 2], word, bit);
+    const int key = word * kDDGridN + bit;
+    unsigned long long pending = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(act && key == k0);
+        if (lane == leader) atomicOr(&occ[word], 1ull << bit);
+        pending &= ~same;
+    }
+}
+
+// need = occ grown by `radius` cells in every direction (indices wrap) -> this rank's part of the payload; the last
+// block appends the lengths of the send lists in use (built by the previous rebuild) for the capacity bookkeeping of
+// the host.  17 blocks of 256 threads.
+__global__ __launch_bounds__(256) void k_dd_dilate(const unsigned long long *__restrict__ occ, const DDGrid *__restrict__ grid,
+                                                   unsigned long long *__restrict__ payload, const int *__restrict__ send_cnt,
+                                                   int world, const MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= kDDWords) {
+        const int q = t - kDDWords;
+        if (q < kDDMaxWorld) reinterpret_cast<int *>(payload + kDDWords)[q] = q < world ? send_cnt[q] : 0;
+        return;
+    }
+    const int R = grid->radius;
+    const int z = t / kDDGridN, y = t % kDDGridN;
+    unsigned long long acc = 0ull;
+    for (int dz = -R; dz <= R; ++dz)
+        for (int dy = -R; dy <= R; ++dy)
+            acc |= occ[((z + dz) & (kDDGridN - 1)) * kDDGridN + ((y + dy) & (kDDGridN - 1))];
+    unsigned long long out = acc;
+    for (int r = 1; r <= R; ++r) out |= (acc << r) | (acc >> (64 - r)) | (acc >> r) | (acc << (64 - r));
+    payload[t] = out;
+}
+
+// Send lists: owned bead i goes to rank q when it is a static partner of q (backbone neighbour beyond a slice end, loop
+// partner) or its coarse cell is set in q's need-map.  Lanes of a wave that go to the same rank share one atomic; the
+// order inside a list is arbitrary (the receiver's cell build sorts ghosts by position and id).  A list that would
+// outgrow its message raises st->dd_overflow and stops growing (the evaluation will be repeated).
+__global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, int rank, int world,
+                                                        const float *__restrict__ x, const DDGrid *__restrict__ grid,
+                                                        const unsigned long long *__restrict__ maps /* [world][kDDPayload] */,
+                                                        const unsigned long long *__restrict__ static_mask,
+                                                        int *__restrict__ send_ids, int slice, int *__restrict__ send_cnt,
+                                                        const DDCaps caps, MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    const DDGrid G = *grid;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < n_own;
+    int word = 0, bit = 0;
     unsigned long long sm = 0ull;
     if (act) {
-        px = x[3 * i];
-        py = x[3 * i + 1];
-        pz = x[3 * i + 2];
+        dd_cell(G, x[3 * i], x[3 * i + 1], x[3 * i + 2], word, bit);
         if (static_mask) sm = static_mask[i];
     }
     const int lane = threadIdx.x & 63;
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
-        const float *b = boxes + 6 * q;
-        const bool need = act && (((sm >> q) & 1ull) || (px >= b[0] - reach && px <= b[3] + reach && py >= b[1] - reach &&
-                                                            py <= b[4] + reach && pz >= b[2] - reach && pz <= b[5] + reach));
+        const bool need = act && ((((sm >> q) | (maps[(size_t)q * kDDPayload + word] >> bit)) & 1ull) != 0ull);
         const unsigned long long m = __ballot(need);
         if (m == 0ull) continue;
         const int leader = __ffsll((long long)m) - 1;
         int base = 0;
         if (lane == leader) base = atomicAdd(&send_cnt[q], __popcll(m));
         base = __shfl(base, leader, 64);
+        if (base + __popcll(m) > caps.cap[q]) { // wave-uniform
+            if (lane == leader) st->dd_overflow = 1;
+            continue;
+        }
         if (need) send_ids[(size_t)q * slice + base + __popcll(m & ((1ull << lane) - 1ull))] = own_lo + i;
     }
 }
 
-// sendbuf[q][k] = pos4[send_ids[q][k]]; grid (blocks, world)
-__global__ __launch_bounds__(256) void k_dd_pack(const int *__restrict__ send_ids, const int *__restrict__ send_cnt, int slice,
-                                                 const float4 *__restrict__ pos4, float4 *__restrict__ sendbuf,
-                                                 const MinState *__restrict__ st) {
-    if (st->phase >= PH_DONE) return;
-    const int q = blockIdx.y, n = send_cnt[q];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
-        sendbuf[(size_t)q * slice + k] = pos4[send_ids[(size_t)q * slice + k]];
+// cntmat[r][q] = length of rank r's send list for q as carried by the last all-gather of the maps; one block
+__global__ void k_dd_gather_counts(const unsigned long long *__restrict__ maps, int world, int *__restrict__ cntmat) {
+    for (int t = threadIdx.x; t < world * world; t += blockDim.x)
+        cntmat[t] = reinterpret_cast<const int *>(maps + (size_t)(t / world) * kDDPayload + kDDWords)[t % world];
 }
 
-// What arrived from rank q (recvbuf[q][0 .. cnt_q)) goes to pos4 by the bead id it carries; ghost_ids lists the ids in
-// arrival order for the cell build.  grid (blocks, world)
+// sendbuf[q][k] = pos4[send_ids[q][k]] for the entries of the list, padding (bead id -1) up to the message's capacity;
+// grid (blocks, world)
+__global__ __launch_bounds__(256) void k_dd_pack(const int *__restrict__ send_ids, const int *__restrict__ send_cnt, int slice,
+                                                 const float4 *__restrict__ pos4, float4 *__restrict__ sendbuf,
+                                                 const DDCaps caps, const MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    const int q = blockIdx.y, cap = caps.cap[q], n = min(send_cnt[q], cap);
+    const float4 pad = make_float4(3e18f, 3e18f, 3e18f, __int_as_float(-8 + 2));
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cap; k += gridDim.x * 256)
+        sendbuf[(size_t)q * slice + k] = k < n ? pos4[send_ids[(size_t)q * slice + k]] : pad;
+}
+
+// What arrived from rank q (recvbuf[q][0 .. cap_q)) goes to pos4 by the bead id it carries; ghost_ids lists the ids in
+// arrival order for the cell build (-1: padding).  grid (blocks, world)
 __global__ __launch_bounds__(256) void k_dd_unpack(const float4 *__restrict__ recvbuf, const DDOffsets O, int slice,
-                                                   float4 *__restrict__ pos4, int *__restrict__ ghost_ids,
+                                                   float4 *__restrict__ pos4, int *__restrict__ ghost_ids, int n_all,
                                                    const MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
     const int q = blockIdx.y, n = O.off[q + 1] - O.off[q];
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
         const float4 p = recvbuf[(size_t)q * slice + k];
-        const int id = __float_as_int(p.w) >> 3;
-        pos4[id] = p;
+        int id = __float_as_int(p.w) >> 3;
+        if ((unsigned)id >= (unsigned)n_all) id = -1;
+        if (id >= 0) pos4[id] = p;
         ghost_ids[O.off[q] + k] = id;
     }
 }
@@ -134,7 +256,7 @@ __global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, in
                                                        const float4 *__restrict__ pos4,
                                                        const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                        int *__restrict__ rank, int *__restrict__ count,
-                                                       const MinState *__restrict__ st) {
+                                                       int *__restrict__ count_own, const MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
     const GridParams G = *grid;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -143,6 +265,10 @@ __global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, in
     if (todo) {
         const bool owned = t < n_own;
         bead = owned ? own_lo + t : ghost_ids[t - n_own];
+        todo = bead >= 0; // padding of a message
+    }
+    if (todo) {
+        const bool owned = t < n_own;
         const float4 p = pos4[bead];
         if (!owned) {
             const float fx = (p.x - G.ox) * G.inv_h, fy = (p.y - G.oy) * G.inv_h, fz = (p.z - G.oz) * G.inv_h;
@@ -153,7 +279,7 @@ __global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, in
                 cell_coord(p.x, G.ox, G.inv_h, G.nx);
         cell_of[bead] = todo ? c : -1;
     }
-    cell_rank(todo, c, bead, rank, count);
+    cell_rank(todo, c, bead, rank, count, count_own, t < n_own);
 }
 
 // Bead ids and sort keys into the cells' slices, for the owned beads and the listed ghosts (twin of k_cell_fill).
@@ -167,6 +293,7 @@ __global__ __launch_bounds__(256) void k_cell_fill_dd(int n_own, int own_lo, int
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_own + n_ghost) return;
     const int i = t < n_own ? own_lo + t : ghost_ids[t - n_own];
+    if (i < 0) return;
     const int c = cell_of[i];
     if (c < 0) return;
     const GridParams G = *grid;

@@ -112,11 +112,19 @@ void refresh_params(mmx_handle_s *h) {
 constexpr double kN3MinBeadsPerCell = 20.0;
 constexpr int kN3MinBeads = 100000;
 
-// The half-shell kernel (k_nb_n3) runs when the lean pair loop applies, the handle owns the whole system and the
-// caller did not ask for bitwise reproducibility.  nb_variant bit 4096 forces it on (deterministic or not), bit 8192
-// forces it off (A/B timing).
+// Beads in this handle's cell list: its owned beads and, on a decomposed rank, the ghost slots of its halo.
+int local_beads(const mmx_handle_s *h) {
+    if (h->world == 1 && h->n_own == h->n) return h->n;
+    const bool comm = h->comm != nullptr || h->lcomm != nullptr;
+    return comm && h->dd_halo && h->dd_lists_valid ? h->n_own + h->dd_nghost : h->n_all;
+}
+
+// The half-shell kernel (k_nb_n3) runs when the lean pair loop applies and the caller did not ask for bitwise
+// reproducibility -- on single-domain handles and on the ranks of a decomposed run alike (there with its DD instance:
+// ghosts in clusters of their own, ghost-ghost pairs culled).  nb_variant bit 4096 forces it on (deterministic or
+// not), bit 8192 forces it off (A/B timing).
 bool use_n3(const mmx_handle_s *h) {
-    if (!h->nb_lean || h->n3_cap <= 0 || !h->fsort || !h->n3_items || h->world > 1 || h->n_own != h->n) return false;
+    if (!h->nb_lean || h->n3_cap <= 0 || !h->fsort || !h->n3_items) return false;
     if (h->nb_variant & 8192) return false;
     if (h->nb_variant & 4096) return true;
     if (h->deterministic || (h->nb_variant & 0xffff & ~(4096 | 8192)) != 0) return false;
@@ -132,8 +140,9 @@ bool use_n3(const mmx_handle_s *h) {
     // (the persistent workgroups of the half-shell kernel want several work items each; its path costs one small launch
     // more.)  Below 20 beads per cell nothing was measured: the full-shell kernel, which needs no atomics, stays there;
     // the last poll's cell count decides.  Both kernels compute the same forces to rounding.
-    if (h->n < kN3MinBeads) return false;
-    return h->last_ncells <= 0 || (double)h->n >= kN3MinBeadsPerCell * (double)h->last_ncells;
+    const int nl = local_beads(h);
+    if (nl < kN3MinBeads) return false;
+    return h->last_ncells <= 0 || (double)nl >= kN3MinBeadsPerCell * (double)h->last_ncells;
 }
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
@@ -144,7 +153,8 @@ bool prof_begin(mmx_handle_s *h, int slot, EventPair &ep) {
     if (h->profile <= 0 || h->capturing) return false;
     // minimizer: whole evaluations are sampled (every profile-th one; the others may be graph replays); elsewhere
     // every profile-th launch of the slot
-    if (h->prof_eval >= 0 ? !h->prof_eval : (h->launches[slot] - 1) % h->profile != 0) return false;
+    if (h->prof_eval >= 0 ? !(h->prof_eval == 1 || (h->prof_eval == 2 && slot == MMX_K_NONBONDED))
+                          : (h->launches[slot] - 1) % h->profile != 0) return false;
     if (h->ev_pool.empty()) return false;
     ep = h->ev_pool.back();
     h->ev_pool.pop_back();
@@ -176,8 +186,10 @@ int n3_configure(int want) {
     const int bytes = (int)n3_lds_bytes(want);
     bool ok = true;
 #define N3ATTR(PM, EV, GA, NE)                                                                              \
-    ok = ok && hipFuncSetAttribute((const void *)k_nb_n3<PM, EV, GA, NE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                   bytes) == hipSuccess
+    ok = ok && hipFuncSetAttribute((const void *)k_nb_n3<PM, EV, GA, NE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   bytes) == hipSuccess &&                                                  \
+         hipFuncSetAttribute((const void *)k_nb_n3<PM, EV, GA, NE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                             bytes) == hipSuccess
 #define N3ATTR_PM(PM)                                                                                       \
     N3ATTR(PM, true, true, false); N3ATTR(PM, true, true, true); N3ATTR(PM, true, false, false);            \
     N3ATTR(PM, true, false, true); N3ATTR(PM, false, true, false); N3ATTR(PM, false, true, true)
@@ -208,36 +220,42 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     const int tail_sh = !tail ? 0 : (tcfg & 15u) ? (int)((tcfg >> 4) & 3u) : 1;
     const int tail2_items = tail ? grid / 4 : 0, tail2_sh = tail ? 2 : 0;
     const int spin = (h->inject_fault & 1) ? 0 : kN3SpinLimit; // option "inject_fault" bit 0: every wait of the kernel fails
+    const bool dd = h->world > 1 || h->n_own != h->n; // the cell list holds ghosts: the DD instance
+#define N3L(EV, GA, NE, DDI)                                                                                \
+    hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, NE, DDI>), dim3(grid), dim3(kN3Threads), lds, h->stream, P,  \
+                       h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,               \
+                       cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh, spin)
 #define N3(EV, GA)                                                                                          \
     do {                                                                                                    \
-        if (h->nb_skip_energy)                                                                              \
-            hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, true>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
-                               h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh, spin); \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, false>), dim3(grid), dim3(kN3Threads), lds, h->stream, P, \
-                               h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,       \
-                               cap, (h->nb_variant >> 16) & 255, tail_items, tail_sh, tail2_items, tail2_sh, spin); \
+        if (h->nb_skip_energy) {                                                                            \
+            if (dd) N3L(EV, GA, true, true);                                                                \
+            else N3L(EV, GA, true, false);                                                                  \
+        } else {                                                                                            \
+            if (dd) N3L(EV, GA, false, true);                                                               \
+            else N3L(EV, GA, false, false);                                                                 \
+        }                                                                                                   \
     } while (0)
     if (P.use_ev && P.use_gauss) N3(true, true);
     else if (P.use_ev) N3(true, false);
     else N3(false, true);
 #undef N3
+#undef N3L
 }
 
 // What has to follow the half-shell kernel: forces from cluster-slot order into the gradient (outside the "nonbonded"
 // timing bracket of enqueue_eval, so that the slot's HIP-event time is the pair kernel's own, as rocprofv3 reports it).
 void launch_nb_finish(mmx_handle_s *h) {
-    if (!use_n3(h)) return;
+    if (!h->n3_build) return;
     const int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     const int gu = std::max(64, std::min((cl * 8 + 255) / 256, 2048));
-    hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->spos4, h->fsort, h->fstride, h->g, h->st);
+    hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->spos4, h->fsort, h->fstride, h->g, h->st,
+                       h->own_lo, h->n_own);
 }
 
 template <int PMODE>
 void launch_nb_cells_p(mmx_handle_s *h, int grid) {
     const FFParams &P = h->P;
-    if (use_n3(h)) {
+    if (h->n3_build) { // the kernel the last cell build prepared for (its work items exist): not re-decided here
         h->n3_launches++;
         launch_nb_n3_p<PMODE>(h, grid);
         return;
@@ -306,7 +324,7 @@ void launch_nb_allpairs_p(mmx_handle_s *h, int tiles_per_slice) {
 }
 
 int nb_grid(const mmx_handle_s *h) {
-    if (use_n3(h)) return n3_grid(h);
+    if (h->n3_build) return n3_grid(h);
     if (h->nb_variant == 1) { // v1: one block per {cell, 64-bead chunk}
         int items = h->last_items > 0 ? h->last_items : (h->n + kChunk - 1) / kChunk + 1024;
         int g = items + items / 4 + 64;
@@ -416,7 +434,11 @@ void coll_allreduce(mmx_handle_s *h, double *buf, int count) {
 }
 
 // ---- ghost-bead halo (mmx_dd.hpp) -------------------------------------------------------------------------------
-bool use_halo(const mmx_handle_s *h) { return h->dd_halo && has_comm(h) && h->world > 1; }
+// The chromosomal-block term reads EVERY bead of the owned beads' chromosomes, with no cutoff (k_chb): there is no halo
+// for it.  A decomposed run with that term keeps the all-gather of every position per evaluation.
+bool use_halo(const mmx_handle_s *h) {
+    return h->dd_halo && has_comm(h) && h->world > 1 && !(h->P.use_chb && h->chrom_of);
+}
 
 // In-place all-gather of `bytes` per rank at buf + rank * bytes; `peer(q)` = the same buffer of rank q's handle
 // (loopback communicator only).
@@ -437,17 +459,17 @@ void coll_allgather_small(mmx_handle_s *h, void *buf, size_t bytes, Peer peer) {
     }
 }
 
-// The halo exchange of one evaluation: exactly the listed entries, one message per pair of ranks that share any.
+// The halo exchange of one evaluation: one message of host-known capacity per pair of ranks that share any ghost.
 void coll_halo_exchange(mmx_handle_s *h) {
     const size_t S = (size_t)h->slice;
     if (h->comm) {
         rccl_check(h, g_rccl.GroupStart(), "ncclGroupStart");
         for (int q = 0; q < h->world; ++q) {
             if (q == h->rank) continue;
-            if (h->dd_scnt[q] > 0)
-                rccl_check(h, g_rccl.Send(h->dd_sendbuf + q * S, (size_t)h->dd_scnt[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclSend");
-            if (h->dd_rcnt[q] > 0)
-                rccl_check(h, g_rccl.Recv(h->dd_recvbuf + q * S, (size_t)h->dd_rcnt[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclRecv");
+            if (h->dd_scap.cap[q] > 0)
+                rccl_check(h, g_rccl.Send(h->dd_sendbuf + q * S, (size_t)h->dd_scap.cap[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclSend");
+            if (h->dd_rcap.cap[q] > 0)
+                rccl_check(h, g_rccl.Recv(h->dd_recvbuf + q * S, (size_t)h->dd_rcap.cap[q] * 4, ncclFloat, q, h->comm, h->stream), "ncclRecv");
         }
         rccl_check(h, g_rccl.GroupEnd(), "ncclGroupEnd");
     } else if (h->lcomm && !h->coll_failed) {
@@ -455,23 +477,28 @@ void coll_halo_exchange(mmx_handle_s *h) {
         int p;
         if (!local_begin(h, p)) { h->coll_failed = true; return; }
         for (int q = 0; q < L.world; ++q)
-            if (q != h->rank && h->dd_rcnt[q] > 0) // what rank q packed for me
+            if (q != h->rank && h->dd_rcap.cap[q] > 0) // what rank q packed for me
                 (void)hipMemcpyAsync(h->dd_recvbuf + q * S, L.h[q]->dd_sendbuf + (size_t)h->rank * S,
-                                     sizeof(float4) * (size_t)h->dd_rcnt[q], hipMemcpyDeviceToDevice, h->stream);
+                                     sizeof(float4) * (size_t)h->dd_rcap.cap[q], hipMemcpyDeviceToDevice, h->stream);
         if (!local_end(h, p)) h->coll_failed = true;
     }
     h->dd_exchanges++;
-    for (int q = 0; q < h->world; ++q) h->dd_bytes_sent += (long long)h->dd_scnt[q] * 16;
+    for (int q = 0; q < h->world; ++q) h->dd_bytes_sent += (long long)h->dd_scap.cap[q] * 16;
 }
 
 int dd_alloc(mmx_handle_s *h) {
     if (h->dd_boxes) return MMX_OK;
     const size_t W = (size_t)h->world, S = (size_t)h->slice;
     HIPCHK(h, dalloc(&h->dd_boxes, W * 6));
+    HIPCHK(h, dalloc(&h->dd_grid, (size_t)1));
+    HIPCHK(h, dalloc(&h->dd_occ, (size_t)kDDWords));
+    HIPCHK(h, dalloc(&h->dd_maps, W * kDDPayload));
     HIPCHK(h, dalloc(&h->dd_static, (size_t)std::max(h->n_own, 1)));
     HIPCHK(h, dalloc(&h->dd_send_ids, W * S));
     HIPCHK(h, dalloc(&h->dd_send_cnt, W));
     HIPCHK(h, dalloc(&h->dd_cntmat, W * W));
+    HIPCHK(h, hipHostMalloc((void **)&h->dd_cnt_host, sizeof(int) * W * W, hipHostMallocDefault));
+    std::memset(h->dd_cnt_host, 0, sizeof(int) * W * W);
     HIPCHK(h, dalloc(&h->dd_ghost_ids, W * S));
     HIPCHK(h, dalloc(&h->dd_sendbuf, W * S));
     HIPCHK(h, dalloc(&h->dd_recvbuf, W * S));
@@ -499,40 +526,101 @@ int dd_upload_static(mmx_handle_s *h) {
     return MMX_OK;
 }
 
-// Re-decomposition.  pos4 of the owned beads and bbox_part must be current (a pack has just run on the stream).
-// Synchronises with the host (the message sizes of the following halo exchanges come back from the device).
-int dd_redecompose(mmx_handle_s *h) {
-    const int gb = (h->n_own + 255) / 256;
-    const size_t W = (size_t)h->world;
-    hipLaunchKernelGGL(k_dd_bbox, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, h->dd_boxes + 6 * h->rank);
-    coll_allgather_pos4(h); // every position, once: what the lists are built from
-    coll_allgather_small(h, h->dd_boxes, 6 * sizeof(float), [](mmx_handle_s *o) { return (void *)o->dd_boxes; });
-    HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
-    const float reach = hmin_of(h) / 1.001f + h->dd_skin_cur;
-    hipLaunchKernelGGL(k_dd_build_lists, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world,
-                       h->x, h->dd_boxes, reach, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt);
-    HIPCHK(h, hipMemcpyAsync(h->dd_cntmat + W * h->rank, h->dd_send_cnt, sizeof(int) * W, hipMemcpyDeviceToDevice, h->stream));
-    coll_allgather_small(h, h->dd_cntmat, W * sizeof(int), [](mmx_handle_s *o) { return (void *)o->dd_cntmat; });
-    std::vector<int> mat(W * W);
-    HIPCHK(h, hipMemcpyAsync(mat.data(), h->dd_cntmat, sizeof(int) * W * W, hipMemcpyDeviceToHost, h->stream));
-    // the lists start a new life: reference positions, stale flag, cells of beads that are no longer ghosts
-    HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->st->dd_stale, 0, sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->cell_of, 0xff, sizeof(int) * (size_t)h->n_all, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+// Capacity of a message for a list of `cnt` entries: room for cnt / dd_slack_div + 512 more before the list outgrows
+// it (1/8 by default; 1/4, 1/2 after a list did outgrow its message in this call: the collapse phase of a minimization
+// adds 10-20 % of ghosts between two polls).
+int dd_capacity(const mmx_handle_s *h, int cnt) {
+    if (h->inject_fault & 4) return std::max(cnt, 0); // tests: no slack at all -- any growth of a list halts the evaluation
+    return cnt <= 0 ? 0 : std::min(h->slice, cnt + cnt / h->dd_slack_div + 512);
+}
+
+// Message capacities from the world x world matrix of list lengths (row = sender).  `fresh`: every capacity is set from
+// the length (a synchronous rebuild: the lists are these very ones); otherwise only where a list has come within 1/16
+// of its capacity or shrunk to under half of it.  Both ends of a message evaluate the same rule on the same numbers.
+bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
+    const int W = h->world;
+    bool changed = false;
+    auto upd = [&](int &cap, int cnt) {
+        int want = cap;
+        if (fresh || cnt + cnt / (2 * h->dd_slack_div) > cap || (cap > 2048 && dd_capacity(h, cnt) < cap / 2)) want = dd_capacity(h, cnt);
+        if (!fresh && cap == 0 && cnt > 0) want = dd_capacity(h, cnt);
+        if (want != cap) {
+            cap = want;
+            changed = true;
+        }
+    };
+    for (int q = 0; q < W; ++q) {
+        if (q == h->rank) {
+            h->dd_scap.cap[q] = h->dd_rcap.cap[q] = 0;
+            continue;
+        }
+        upd(h->dd_scap.cap[q], mat[W * h->rank + q]);
+        upd(h->dd_rcap.cap[q], mat[W * q + h->rank]);
+    }
     h->dd_nghost = 0;
     h->dd_off.off[0] = 0;
-    for (int q = 0; q < h->world; ++q) {
-        h->dd_scnt[q] = q == h->rank ? 0 : mat[W * h->rank + q];
-        h->dd_rcnt[q] = q == h->rank ? 0 : mat[W * q + h->rank];
-        if (h->dd_scnt[q] > h->slice || h->dd_rcnt[q] > h->slice) return fail(h, MMX_ERR_STATE, "ghost list longer than a slice");
-        h->dd_nghost += h->dd_rcnt[q];
+    for (int q = 0; q < W; ++q) {
+        h->dd_nghost += h->dd_rcap.cap[q];
         h->dd_off.off[q + 1] = h->dd_nghost;
     }
-    h->dd_lists_valid = true;
+    return changed;
+}
+
+// Rebuild of the ghost lists from the owned positions as they are (a pack has just run on the stream: x, pos4 of the
+// owned beads and bbox_part are current).  On the stream, no host round trip: need-map of the owned beads, all-gather of
+// the maps (32 KB per rank), one send list per destination -- checked against the capacity of its message.
+// `sync` (start of every API call, repeat of a halted evaluation): before that the coarse grid is laid over the
+// all-gathered owned boxes, the lists are unbounded, and afterwards the matrix of list lengths is all-gathered and read
+// by the host: fresh capacities.
+int dd_rebuild(mmx_handle_s *h, bool sync) {
+    const int gb = std::max((h->n_own + 255) / 256, 1);
+    const size_t W = (size_t)h->world;
+    const float reach = hmin_of(h) / 1.001f + (h->dd_every > 1 ? h->dd_skin_cur : 0.f);
+    if (sync) {
+        hipLaunchKernelGGL(k_dd_bbox, dim3(1), dim3(256), 0, h->stream, h->bbox_part, (h->n_own + 255) / 256,
+                           h->dd_boxes + 6 * h->rank);
+        coll_allgather_small(h, h->dd_boxes, 6 * sizeof(float), [](mmx_handle_s *o) { return (void *)o->dd_boxes; });
+        hipLaunchKernelGGL(k_dd_grid, dim3(1), dim3(64), 0, h->stream, h->dd_boxes, h->world, reach, h->dd_grid);
+    }
+    HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
+    hipLaunchKernelGGL(k_dd_occupancy, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
+    hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
+                       h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
+    coll_allgather_small(h, h->dd_maps, sizeof(unsigned long long) * kDDPayload,
+                         [](mmx_handle_s *o) { return (void *)o->dd_maps; });
+    if (!sync) // the lengths of the lists in use until now, of every rank: what the next poll sizes the messages by
+        hipLaunchKernelGGL(k_dd_gather_counts, dim3(1), dim3(256), 0, h->stream, h->dd_maps, h->world, h->dd_cntmat);
+    HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
+    DDCaps caps = h->dd_scap;
+    if (sync)
+        for (int q = 0; q < h->world; ++q) caps.cap[q] = h->slice;
+    hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world, h->x,
+                       h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st);
+    if (h->dd_every > 1) { // the lists start a new life: reference positions of the displacement test
+        HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(&h->st->dd_stale, 0, sizeof(int), h->stream));
+    }
+    h->dd_since = 0;
     h->dd_redecompositions++;
+    if (!sync) return MMX_OK;
+    HIPCHK(h, hipMemcpyAsync(h->dd_cntmat + W * h->rank, h->dd_send_cnt, sizeof(int) * W, hipMemcpyDeviceToDevice, h->stream));
+    coll_allgather_small(h, h->dd_cntmat, W * sizeof(int), [](mmx_handle_s *o) { return (void *)o->dd_cntmat; });
+    HIPCHK(h, hipMemcpyAsync(h->dd_cnt_host, h->dd_cntmat, sizeof(int) * W * W, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->st->dd_stale, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->st->dd_overflow, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->cell_of, 0xff, sizeof(int) * (size_t)h->n_all, h->stream)); // beads that are no longer ghosts
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+    (void)dd_set_capacities(h, h->dd_cnt_host, true);
+    h->dd_lists_valid = true;
+    h->dd_sync_rebuilds++;
     return MMX_OK;
+}
+
+// Which rebuild the next evaluation of a running call gets: 2 = on the stream (every dd_every-th evaluation), 0 = none.
+int dd_schedule(mmx_handle_s *h) {
+    if (!use_halo(h) || !h->dd_lists_valid) return 0;
+    return ++h->dd_since >= h->dd_every ? 2 : 0;
 }
 
 void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
@@ -540,7 +628,8 @@ void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
 // Pack (+ trial move / integrator step), then the cell build.  With `bonded` set, the bonded terms of the evaluation
 // -- which only need pos4 -- are enqueued with it: inside the launch of the cell scan ("overlap_bonded", default), or
 // right behind the pack.
-void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr, bool redecomp = false) {
+// redecomp (decomposed runs with a halo): 0 = the ghost lists stay, 1 = synchronous rebuild, 2 = rebuild on the stream.
+void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded = nullptr, int redecomp = 0) {
     const int gb = (h->n_own + 255) / 256;  // blocks over owned beads (k_pack, bbox partials)
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
@@ -581,22 +670,24 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
     if (redecomp && use_halo(h)) { // fresh ghost lists from the positions the pack has just written
-        const int rc = dd_redecompose(h);
+        const int rc = dd_rebuild(h, redecomp == 1);
         if (rc != MMX_OK && h->dd_rc == MMX_OK) h->dd_rc = rc;
     }
     const bool halo = use_halo(h) && h->dd_lists_valid;
     if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
-        const float half = 0.5f * h->dd_skin_cur;
-        hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
-                           half * half, h->st);
+        if (h->dd_every > 1 && !redecomp) { // lists older than this evaluation: still within the skin?
+            const float half = 0.5f * h->dd_skin_cur;
+            hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
+                               half * half, h->st);
+        }
         int mx = 1;
-        for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scnt[q], h->dd_rcnt[q]));
+        for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scap.cap[q], h->dd_rcap.cap[q]));
         const dim3 gq(std::min((mx + 255) / 256, 256), h->world);
         hipLaunchKernelGGL(k_dd_pack, gq, dim3(256), 0, h->stream, h->dd_send_ids, h->dd_send_cnt, h->slice, h->pos4,
-                           h->dd_sendbuf, h->st);
+                           h->dd_sendbuf, h->dd_scap, h->st);
         coll_halo_exchange(h);
         hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
-                           h->dd_ghost_ids, h->st);
+                           h->dd_ghost_ids, h->n_all, h->st);
     } else if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
         coll_allgather_pos4(h);
     const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
@@ -610,11 +701,14 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         const int gl = (h->n_own + h->dd_nghost + 255) / 256; // owned beads + listed ghosts
         if (halo)
             hipLaunchKernelGGL(k_cell_count_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo,
-                               h->dd_nghost, h->dd_ghost_ids, h->pos4, cur, h->cell_of, h->rank_in_cell, h->count, h->st);
+                               h->dd_nghost, h->dd_ghost_ids, h->pos4, cur, h->cell_of, h->rank_in_cell, h->count,
+                               h->count_own, h->st);
         else if (!fuse_count)
             hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
-                               cur, h->cell_of, h->rank_in_cell, h->count, h->st);
-        const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next};
+                               cur, h->cell_of, h->rank_in_cell, h->count, h->st, h->count_own);
+        // (count_own: decomposed handles only -- a cell's owned beads and its ghosts form separate clusters)
+        const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next,
+                          h->count_own};
         if (in_scan) { // block 0 scans, the others are the bonded pass (four virtual 256-thread blocks each)
             const int nvb = grid_beads(h->n_own);
             const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
@@ -636,25 +730,26 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         // of the half-shell pair kernel are built by extra workgroups of the same launch (k_order_items)
         const bool small_cells = h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
         const int go = small_cells ? 2048 : 1024;
-        if (use_n3(h)) {
+        h->n3_build = use_n3(h); // latched per build: the pair kernel that follows must be the one whose work items exist
+        if (h->n3_build) {
             if (small_cells)
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st, h->count_own);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st);
+                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st, h->count_own);
         h->gcur = cur;
         h->build_idx++;
     }
@@ -724,7 +819,7 @@ enum { FOLD_NONE = 0, // nothing (MD steps whose energies nobody reads)
        FOLD_MIN };    // minimizer: history pass, then energies + line search + direction coefficients
 
 // One full energy+gradient evaluation: pack/move, [bonded terms || cell build], pair kernel, fold.
-void enqueue_eval(mmx_handle_s *h, int mode, int fold, bool redecomp = false) {
+void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
     EventPair ep{};
     CtlArgs A{};
     bool on = prof_begin(h, MMX_K_CELL_BUILD, ep);
@@ -815,6 +910,7 @@ bool graph_capture(mmx_handle_s *h) {
     const int idx0 = h->build_idx;
     GridParams *const gcur0 = h->gcur;
     int64_t saved[MMX_N_KERNELS];
+    const long long n3_saved = h->n3_launches;
     for (int k = 0; k < MMX_N_KERNELS; ++k) saved[k] = h->launches[k];
     if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -828,6 +924,8 @@ bool graph_capture(mmx_handle_s *h) {
         h->glaunches[k] = h->launches[k] - saved[k];
         h->launches[k] = saved[k];
     }
+    h->gn3_launches = h->n3_launches - n3_saved;
+    h->n3_launches = n3_saved;
     h->build_idx = idx0;
     h->gcur = gcur0;
     if (e != hipSuccess || !h->graph || hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -846,6 +944,7 @@ bool graph_replay(mmx_handle_s *h) {
     h->build_idx += h->graph_evals;
     h->gcur = h->grid + ((h->build_idx - 1) & 1);
     for (int k = 0; k < MMX_N_KERNELS; ++k) h->launches[k] += h->glaunches[k];
+    h->n3_launches += h->gn3_launches;
     return true;
 }
 
@@ -855,7 +954,13 @@ int push_state(mmx_handle_s *h) {
 }
 int pull_state(mmx_handle_s *h) {
     HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
+    const bool halo = use_halo(h) && h->dd_lists_valid && h->dd_cnt_host;
+    if (halo)
+        HIPCHK(h, hipMemcpyAsync(h->dd_cnt_host, h->dd_cntmat, sizeof(int) * (size_t)h->world * h->world,
+                                 hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // decomposed runs: messages follow the lists (every rank sees the same matrix at the same poll: same capacities)
+    if (halo && !h->coll_failed && dd_set_capacities(h, h->dd_cnt_host, false)) h->dd_cap_updates++;
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
     if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
     if (h->st_host->max_per_cell > 0) h->last_max_per_cell = h->st_host->max_per_cell;
@@ -906,7 +1011,7 @@ int ensure_allpairs_scratch(mmx_handle_s *h) {
 // First build of a call: learn the work-item count so the pair kernel's grid is sized to it.
 int prime_items(mmx_handle_s *h) {
     if (!has_nb(h) || all_pairs(h)) return MMX_OK;
-    enqueue_build(h, PACK_PLAIN, true, nullptr, true); // decomposed runs: the ghost lists of this call are built here
+    enqueue_build(h, PACK_PLAIN, true, nullptr, 1); // decomposed runs: the ghost lists of this call are built here
     if (h->dd_rc != MMX_OK) return h->dd_rc;
     return pull_state(h);
 }

@@ -144,17 +144,25 @@ struct mmx_handle_s {
     double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
     // ghost-bead halo of a decomposed run with a communicator (mmx_dd.hpp); dd_halo = 0 keeps the all-gather of every position
     int dd_halo = 1;
-    float dd_skin = 0.1f;                       // nm: the lists hold while no bead has moved more than half of it (base value)
-    float dd_skin_cur = 0.1f;                   // ... as adapted by the minimizer: doubled when lists go stale within 8
-                                                // evaluations, halved again after 128 quiet ones
-    int dd_last_rebuild_eval = 0;
-    float *dd_boxes = nullptr;                  // [world][6] owned bounding boxes (all-gathered at re-decomposition)
+    int dd_every = 1;                           // ghost lists are rebuilt (on the stream) before every dd_every-th evaluation;
+                                                // 1: before each one -- lists exact for the positions they serve, no skin
+    int dd_since = 0;                           // evaluations enqueued since the last rebuild
+    float dd_skin = 0.2f;                       // nm (dd_every > 1): the lists hold while no bead has moved more than half of it
+    float dd_skin_cur = 0.2f;                   // ... as adapted by the minimizer: doubled (up to 0.8) when a list went stale
+    float *dd_boxes = nullptr;                  // [world][6] owned bounding boxes (all-gathered at a synchronous rebuild)
+    DDGrid *dd_grid = nullptr;                  // coarse grid of the need-maps (device)
+    unsigned long long *dd_occ = nullptr;       // [kDDWords] coarse cells of the owned beads
+    unsigned long long *dd_maps = nullptr;      // [world][kDDPayload] all-gathered need-maps + send-list lengths
     unsigned long long *dd_static = nullptr;    // [n_own] ranks that always need this bead (backbone / loop partners)
     std::vector<unsigned long long> dd_loop_mask; // host: the loop-partner part of it (mmx_set_loops)
     int *dd_send_ids = nullptr, *dd_send_cnt = nullptr, *dd_cntmat = nullptr, *dd_ghost_ids = nullptr;
+    int *dd_cnt_host = nullptr;                 // pinned [world][world]: list lengths as of the last poll
     float4 *dd_sendbuf = nullptr, *dd_recvbuf = nullptr; // [world][slice]
-    float *dd_xref = nullptr;                   // [3 n_own] owned positions when the lists were built
-    int dd_scnt[kDDMaxWorld]{}, dd_rcnt[kDDMaxWorld]{}, dd_nghost = 0;
+    float *dd_xref = nullptr;                   // [3 n_own] owned positions when the lists were built (dd_every > 1)
+    DDCaps dd_scap{}, dd_rcap{};                // entries per message to / from rank q (host-known: ncclSend/ncclRecv sizes)
+    int dd_nghost = 0;                          // sum of dd_rcap: ghost slots binned per evaluation (padding included)
+    int dd_slack_div = 8;                       // a message has room for 1 / dd_slack_div more entries than its list had
+    long long dd_halts = 0, dd_cap_updates = 0, dd_sync_rebuilds = 0; // statistics
     DDOffsets dd_off{};
     bool dd_lists_valid = false, dd_static_dirty = true;
     int dd_rc = 0;                              // first error of a re-decomposition inside a launch sequence
@@ -172,6 +180,7 @@ struct mmx_handle_s {
     float *cf_w = nullptr;
     int *chrom_of = nullptr, *chrom_lo = nullptr, *chrom_hi = nullptr; // chromosomal blocks: id per bead, range per id
     // cells
+    int *count_own = nullptr; // decomposed handles: owned beads per cell (a cell's ghosts form clusters of their own)
     int *cell_of = nullptr, *count = nullptr, *rank_in_cell = nullptr, *start = nullptr, *istart = nullptr,
         *perm = nullptr;
     int2 *items = nullptr;
@@ -184,6 +193,8 @@ struct mmx_handle_s {
     float4 *spos4 = nullptr, *cl_lo = nullptr, *cl_hi = nullptr; // padded cell-sorted positions, cluster boxes
     int last_clusters = -1;
     long long n3_launches = 0;                   // launches of the half-shell kernel since the handle was created (option n3_launches)
+    long long gn3_launches = 0;                  // ... per replay of the captured graph
+    bool n3_build = false;                       // the last enqueued cell build prepared the half-shell kernel's work items
     int last_ncells = -1;                        // cells of the grid at the last poll (picks the pair kernel, see use_n3)
     float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
     int fstride = 0;
@@ -238,7 +249,9 @@ struct mmx_handle_s {
     bool capturing = false;
     int gkey_parity = 0;
     int64_t glaunches[MMX_N_KERNELS]{};
-    int prof_eval = -1; // minimizer: 1 / 0 = this evaluation is / is not a profiling sample; -1 = per-slot sampling
+    int prof_eval = -1; // minimizer: 1 / 0 = this evaluation is / is not a profiling sample, 2 = its pair kernel alone is;
+                        // -1 = per-slot sampling
+    int profile_nb = 0; // minimizer: every profile_nb-th evaluation samples the pair-kernel slot alone (one event pair)
     // profiling
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};

@@ -444,13 +444,15 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
 }
 
 // Entries 0..15 of the all-reduced array of a decomposed run: the P_NSLOTS slot sums, then the flags every rank must see
-// alike -- 12: some rank's ghost lists are out of date or outgrew their message (k_dd_displacement, k_dd_build_lists),
-// 13: some rank's force kernel failed (MinState::kernel_error).
-constexpr int kSumStale = 12, kSumKernelError = 13;
+// alike (the host's policies read them from the all-reduced array too, never from a rank's own flag) -- 12: ranks on
+// which a bead has moved beyond half the skin since the ghost lists were built (k_dd_displacement), 13: ranks whose force
+// kernel failed (MinState::kernel_error), 14: ranks with a ghost list longer than its message (k_dd_build_lists).
+constexpr int kSumStale = 12, kSumKernelError = 13, kSumOverflow = 14;
 __device__ __forceinline__ double flag_or_sum(const MinState *__restrict__ st, const double *s_out, int t) {
     if (t < P_NSLOTS) return s_out[t];
-    if (t == kSumStale) return (st->dd_stale || st->dd_overflow) ? 1.0 : 0.0;
+    if (t == kSumStale) return st->dd_stale ? 1.0 : 0.0;
     if (t == kSumKernelError) return st->kernel_error ? 1.0 : 0.0;
+    if (t == kSumOverflow) return st->dd_overflow ? 1.0 : 0.0;
     return 0.0;
 }
 
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
-    if (st->sums[kSumKernelError] <= 0.5 && st->sums[kSumStale] > 0.5) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
+    if (st->sums[kSumKernelError] <= 0.5 && (st->sums[kSumStale] > 0.5 || st->sums[kSumOverflow] > 0.5)) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
         st->halt_phase = st->phase;
         st->phase = PH_HALT;
         st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      const unsigned long long *__restrict__ okeys,
                                                      const int *__restrict__ biglist,
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
-                                                     MinState *__restrict__ st) {
+                                                     MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st);
+                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own);
 }
 
 #ifdef MMX_N3_TIMING
@@ -280,7 +280,14 @@ __device__ __forceinline__ int cvt_nearest(float v) {
 }
 
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
-template <int PMODE, bool EV, bool GAUSS, bool NOENERGY>
+//
+// DD (decomposed runs: the cell list holds this rank's owned beads AND its ghosts, in separate clusters -- emit_clusters):
+// every pair with at least one owned bead is still evaluated once, by the cluster with the lower id, whichever side owns
+// what; pairs of two ghosts are not evaluated at all (an all-ghost i-cluster culls all-ghost candidates).  Forces that
+// land on ghost slots -- the i side of a ghost cluster, the reaction on a ghost j bead -- are dropped by
+// k_nb_n3_unsort: the ghost's owner computes them itself.  Energies are weighted 1/2 (own_i + own_j): each rank books
+// half of every cross-rank pair, all of every pair it owns both beads of.
+template <int PMODE, bool EV, bool GAUSS, bool NOENERGY, bool DD = false>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
                                                           const float4 *__restrict__ cl_box,
                                                           const N3Item *__restrict__ items, MinState *__restrict__ st,
@@ -566,6 +573,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (gi >= D_n) break;
             const int icl = D_a + gi;
             const float4 lo_i = cl_box[2 * icl], hi_i = cl_box[2 * icl + 1];
+            // decomposed runs: is this a cluster of owned beads or of ghosts (never both)
+            const bool i_own = !DD || __builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w) >> 8) != 0;
             float4 pv = spos4[(size_t)icl * kCl + slot];
             const int own_w = __float_as_int(pv.w);
             if (own_w < 0) { // padding slots: far away on the i side (they are j entries at +1e18 too)
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
                             const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
                             ok[h] = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
+                            if (DD) ok[h] = ok[h] && (i_own || (__float_as_int(hi_j.w) >> 8) != 0); // never ghosts against ghosts
                         }
                     }
 #pragma unroll
@@ -649,7 +659,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             const bool okb = fmaf(bx, bx, fmaf(by, by, bz * bz)) < rc2;
                             const unsigned long long mb = __ballot(okb);
                             if (okb) {
-                                q.w = __int_as_float((((lq << 3) | slot) << 3) | (__float_as_int(q.w) & 7));
+                                int wj = (((lq << 3) | slot) << 3) | (__float_as_int(q.w) & 7);
+                                if (DD) wj |= ((unsigned)((__float_as_int(q.w) >> 3) - P.own_lo) < (unsigned)P.n_own) ? 1 << 15 : 0;
+                                q.w = __int_as_float(wj);
                                 ring[(rhead + rcount + prefix_count(mb)) & 127] = q;
                             }
                             rcount += __builtin_amdgcn_readfirstlane(__popcll(mb));
@@ -666,7 +678,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             rcount -= took;
                             const int wq = __float_as_int(q.w);
                             const int lj = wq & 7;
-                            const int jslot = wq >> 3;
+                            const int jslot = DD ? (wq >> 3) & 0xfff : wq >> 3; // (window slots: < 2^12)
+                            // energy weight of this lane's pairs: half per owned side
+                            const float wl = DD ? 0.5f * ((i_own ? 1.f : 0.f) + (float)((wq >> 15) & 1)) : 1.f;
                             float fjx = 0.f, fjy = 0.f, fjz = 0.f, eb = 0.f, gb = 0.f;
                             if (diag & 4) { // timing diagnosis only: no pair arithmetic
                                 fx[0] += q.x;
@@ -710,8 +724,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             // fixed-point window: one wave-uniform test takes it past the ~12 operations of both.
                             if (__builtin_expect(__ballot(self || big) == 0ull, 1)) {
                                 if (!NOENERGY) {
-                                    if (EV) ee += eb;
-                                    if (GAUSS) eg += gb;
+                                    if (EV) ee = DD ? fmaf(eb, wl, ee) : ee + eb;
+                                    if (GAUSS) eg = DD ? fmaf(gb, wl, eg) : eg + gb;
                                 }
                                 if (!(diag & 2)) { // reaction on the j beads (sign and unit: at the flush)
                                     atomicAdd(sfx + jslot, cvt_nearest(fjx * fix_k));
@@ -725,8 +739,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 // the rest -- goes out again in the batch it came in with (its value, eself, is formed by
                                 // the very operations of the loop: what is left of it is the rounding of the up to 7 small
                                 // terms that shared an accumulator with it, ~1e-4 kJ/mol per bead, random in sign)
-                                if (EV) ee = fmaf(self ? eb - eself : eb, self ? 0.5f : 1.f, ee);
-                                if (GAUSS) eg = fmaf(self ? gb + arow[(jslot & 7) * 8 + lj] : gb, self ? 0.5f : 1.f, eg);
+                                if (EV) ee = fmaf(self ? eb - eself : eb, (self ? 0.5f : 1.f) * wl, ee);
+                                if (GAUSS) eg = fmaf(self ? gb + arow[(jslot & 7) * 8 + lj] : gb, (self ? 0.5f : 1.f) * wl, eg);
                             }
                             if (!(diag & 2)) {
                                 if (big && !self) { // rare (overlapping beads): straight to global memory
@@ -753,7 +767,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             // step halves the values a lane carries (lane bit k picks which half it keeps summing), so the 8 sums of a
             // component cost ~27 operations instead of 8 full wave reductions (56)
             const float ofx = fold8(fx, lane) * pscale, ofy = fold8(fy, lane) * pscale, ofz = fold8(fz, lane) * pscale;
-            if (lane < kCl && own_w >= 0 && !(diag & 8)) {
+            if (lane < kCl && own_w >= 0 && i_own && !(diag & 8)) {
                 atomicAdd(fsort + icl * kCl + lane, ofx);
                 atomicAdd(fsort + fstride + icl * kCl + lane, ofy);
                 atomicAdd(fsort + 2 * fstride + icl * kCl + lane, ofz);
@@ -813,9 +827,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 
 // g[bead] -= fsort[slot] for every real bead of the cluster list, fsort back to zero for the next evaluation, and the
 // item queue rewound (the pair kernel may be launched again on the same cell build: mmx_time_kernel).
+// Decomposed runs: g holds the owned beads only; what landed on a ghost's slot is dropped (its owner computes it).
 __global__ __launch_bounds__(256) void k_nb_n3_unsort(const float4 *__restrict__ spos4, float *__restrict__ fsort,
                                                       const int fstride, float *__restrict__ g,
-                                                      MinState *__restrict__ st) {
+                                                      MinState *__restrict__ st, const int own_lo, const int n_own) {
     if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->n3_queue = 0;
     const int nsl = st->n_clusters * kCl;
@@ -825,8 +840,8 @@ __global__ __launch_bounds__(256) void k_nb_n3_unsort(const float4 *__restrict__
         fsort[i] = 0.f;
         fsort[fstride + i] = 0.f;
         fsort[2 * fstride + i] = 0.f;
-        if (bead >= 0) {
-            float *gb = g + 3 * (size_t)bead; // the bonded terms wrote the gradient first
+        if ((unsigned)(bead - own_lo) < (unsigned)n_own) {
+            float *gb = g + 3 * (size_t)(bead - own_lo); // the bonded terms wrote the gradient first
             gb[0] -= fx;
             gb[1] -= fy;
             gb[2] -= fz;
