@@ -222,6 +222,9 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     in the cell-build slot); 0: its own launch ("confine" slot)     1
  * "order_fallbacks"   (get only) cells of the last call that were too large for the in-LDS sort and
  *                     kept arrival order: 0 means the summation order was bitwise reproducible
+ * "dd_freeze"         measurement only (scripts/dd_projection.py): 1 = a rank of a decomposed run issues no collective any
+ *                     more -- ghost lists and the ghost positions last received stay, sums are not all-reduced -- so
+ *                     that mmx_time_kernel can time ONE rank's kernels on exactly the beads it holds in the run   0
  * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
  *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE;
  *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a

@@ -598,6 +598,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else if (k == "inject_fault") h->inject_fault = (int)value;
+    else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -667,6 +668,9 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) try {
 int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) try {
     if (!h || max_iters < 0 || !(tolerance >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad minimize arguments");
     h->md_forces_valid = false;
+    // A minimization from the lattice adds 10-25 % of ghosts within its first ten iterations: decomposed runs start
+    // with roomier messages (1/4) and short intervals between the polls that resize them (4, 8, 16, ... evaluations)
+    h->dd_slack_div = 4;
     int rc = prepare(h);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -700,7 +704,6 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
     h->dd_skin_cur = h->dd_skin;
-    h->dd_slack_div = 8;
     // every exit from here on goes through leave(): per-evaluation profiling back to per-slot sampling, graph dropped
     auto leave = [&](int code) {
         h->prof_eval = -1;
@@ -717,8 +720,10 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     bool have_graph = false;
     GraphKey gkey{};
     long long eval_no = 1;
+    int ramp = use_halo(h) ? 4 : h->poll_interval, quiet_polls = 0;
     while (h->st_host->phase != PH_DONE) {
-        int batch = h->poll_interval;
+        int batch = std::min(h->poll_interval, ramp);
+        ramp = std::min(2 * ramp, std::max(h->poll_interval, 1));
         if (max_iters > 0) batch = std::max(1, std::min(batch, max_iters - h->st_host->iters));
         if (graphs && (!have_graph || !(gkey == graph_key(h)))) {
             gkey = graph_key(h);
@@ -740,6 +745,11 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             ++eval_no;
         }
         if ((rc = pull_state(h))) return leave(rc);
+        if (h->st_host->phase == PH_HALT) quiet_polls = 0;
+        else if (++quiet_polls >= 8 && h->dd_slack_div < 8) { // the lists have settled: tighter messages again
+            h->dd_slack_div *= 2;
+            quiet_polls = 0;
+        }
         while (h->st_host->phase == PH_HALT) {
             // decomposed run: an evaluation found a ghost list out of date (a bead beyond half the skin, dd_every > 1) or
             // longer than its message, and decided nothing.  New lists and capacities at the trial point (the pack of the

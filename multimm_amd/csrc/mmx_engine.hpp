@@ -669,12 +669,16 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
-    if (redecomp && use_halo(h)) { // fresh ghost lists from the positions the pack has just written
+    // dd_frozen (measurement: scripts/dd_projection.py): no collective is issued -- the ghost lists and the ghost positions
+    // last received stay, so one rank's kernels can be timed alone on exactly the beads it holds in a real run
+    if (redecomp && use_halo(h) && !h->dd_frozen) { // fresh ghost lists from the positions the pack has just written
         const int rc = dd_rebuild(h, redecomp == 1);
         if (rc != MMX_OK && h->dd_rc == MMX_OK) h->dd_rc = rc;
     }
     const bool halo = use_halo(h) && h->dd_lists_valid;
-    if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
+    if (halo && h->dd_frozen) {
+        // nothing to exchange: the ghosts of the last exchange are binned again
+    } else if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
         if (h->dd_every > 1 && !redecomp) { // lists older than this evaluation: still within the skin?
             const float half = 0.5f * h->dd_skin_cur;
             hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
@@ -688,7 +692,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         coll_halo_exchange(h);
         hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
                            h->dd_ghost_ids, h->n_all, h->st);
-    } else if (has_comm(h)) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
+    } else if (has_comm(h) && !h->dd_frozen) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
         coll_allgather_pos4(h);
     const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
     if (bonded && !in_scan) enqueue_bonded(h, *bonded, false);
@@ -864,8 +868,9 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
         prof_end(h, on, ep);
     }
     on = prof_begin(h, MMX_K_REDUCE, ep);
+    const bool solo = !has_comm(h) || h->dd_frozen; // no all-reduce: this handle's sums are all there is
     if (fold == FOLD_MIN) {
-        if (!has_comm(h)) {
+        if (solo) {
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
         } else { // energies, Gram rows, g.d, x.x of all ranks: ONE fp64 all-reduce of 57 doubles per evaluation
             hipLaunchKernelGGL(k_reduce_all, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
@@ -873,7 +878,7 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
             hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
         }
         // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
-    } else if (!has_comm(h)) {
+    } else if (solo) {
         hipLaunchKernelGGL(k_controller, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);
     } else { // energies of all ranks: one fp64 all-reduce of 16 doubles
         hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, h->st);

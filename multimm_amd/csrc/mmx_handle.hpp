@@ -161,6 +161,7 @@ struct mmx_handle_s {
     float *dd_xref = nullptr;                   // [3 n_own] owned positions when the lists were built (dd_every > 1)
     DDCaps dd_scap{}, dd_rcap{};                // entries per message to / from rank q (host-known: ncclSend/ncclRecv sizes)
     int dd_nghost = 0;                          // sum of dd_rcap: ghost slots binned per evaluation (padding included)
+    bool dd_frozen = false;                     // measurement only (option dd_freeze): no collectives, ghosts as last received
     int dd_slack_div = 8;                       // a message has room for 1 / dd_slack_div more entries than its list had
     long long dd_halts = 0, dd_cap_updates = 0, dd_sync_rebuilds = 0; // statistics
     DDOffsets dd_off{};
