@@ -82,47 +82,51 @@ __device__ __forceinline__ float angle_forces(F3 pi, F3 pj, F3 pk, float th0, fl
 }
 
 // K3.  flags[i] bit0: bond (i,i+1) present, bit1: angle (i,i+1,i+2) present.
-// Per-bead gather of the <= 2 bonds and <= 3 angles bead i takes part in; (gx,gy,gz) receive dE/dx_i, the bead
-// books the energy of the bond / angle it starts.  Neighbours i-2..i+2 may belong to other ranks: pos4 holds all.
-__device__ __forceinline__ void backbone_bead(const FFParams &P, const float4 *__restrict__ pos4,
-                                              const uint8_t *__restrict__ flags, int i, double &eb, double &ea,
-                                              float &gx, float &gy, float &gz) {
+// Every bond and every angle is evaluated ONCE, by the thread of the bead that starts it (round 2: the thread of bead i
+// re-evaluated all it takes part in -- 2 bonds, 3 angles with their atan2 and cross products -- and the kernel ran at a
+// quarter of the bandwidth the other per-bead kernels reach).  The other beads of a term get their share from that
+// thread through wave shuffles: a wave is a TILE of 62 consecutive beads preceded by the two beads before them (lanes
+// 0 and 1: they evaluate the terms they start, for the hand-over only, and write nothing).  No LDS, no barrier, no
+// atomics; fixed order of the five fp32 additions per bead, so results are bitwise reproducible.
+constexpr int kBBTile = 62; // beads written per wave
+
+// For the bead of this lane (global index i; `valid`: it exists): dE/dx_i of the backbone terms into (gx,gy,gz);
+// energies of the bond / angle the bead STARTS into eb / ea when `book` (output lanes).  Whole waves must call.
+__device__ __forceinline__ void backbone_lane(const FFParams &P, const float4 *__restrict__ pos4,
+                                              const uint8_t *__restrict__ flags, const int i, const bool valid,
+                                              const bool book, double &eb, double &ea, float &gx, float &gy, float &gz) {
     const int n = P.n;
-    const int f0 = flags[i];
-    const int fm1 = i >= 1 ? flags[i - 1] : 0;
-    const int fm2 = i >= 2 ? flags[i - 2] : 0;
-    const F3 p0 = f3(pos4[i]);
-    F3 pm1 = p0, pm2 = p0, pp1 = p0, pp2 = p0;
-    if (i >= 1) pm1 = f3(pos4[i - 1]);
-    if (i >= 2) pm2 = f3(pos4[i - 2]);
-    if (i + 1 < n) pp1 = f3(pos4[i + 1]);
-    if (i + 2 < n) pp2 = f3(pos4[i + 2]);
-    if (P.use_bond) {
-        if (fm1 & 1) (void)bond_grad(p0, pm1, P.bond_r0, P.bond_k, gx, gy, gz);
-        if (f0 & 1) eb += (double)bond_grad(p0, pp1, P.bond_r0, P.bond_k, gx, gy, gz);
-    }
-    if (P.use_angle) {
-        F3 fi, fk;
-        if (fm2 & 2) { // angle (i-2,i-1,i): this bead is the k end
-            (void)angle_forces(pm2, pm1, p0, P.ang_th0, P.ang_k, fi, fk);
-            gx -= fk.x;
-            gy -= fk.y;
-            gz -= fk.z;
+    float bx = 0.f, by = 0.f, bz = 0.f;       // gradient on i of bond (i, i+1); bead i+1 gets the opposite
+    F3 fi = {0.f, 0.f, 0.f}, fk = {0.f, 0.f, 0.f}; // forces of angle (i, i+1, i+2) on its two end beads
+    if (valid) {
+        const int f0 = flags[i];
+        const F3 p0 = f3(pos4[i]);
+        F3 p1 = p0, p2 = p0;
+        if (i + 1 < n) p1 = f3(pos4[i + 1]);
+        if (i + 2 < n) p2 = f3(pos4[i + 2]);
+        if (P.use_bond && (f0 & 1)) {
+            const float e = bond_grad(p0, p1, P.bond_r0, P.bond_k, bx, by, bz);
+            if (book) eb += (double)e;
         }
-        if (fm1 & 2) { // angle (i-1,i,i+1): this bead is the middle
-            (void)angle_forces(pm1, p0, pp1, P.ang_th0, P.ang_k, fi, fk);
-            gx += fi.x + fk.x;
-            gy += fi.y + fk.y;
-            gz += fi.z + fk.z;
-        }
-        if (f0 & 2) { // angle (i,i+1,i+2): this bead is the i end; it also owns the energy
-            ea += (double)angle_forces(p0, pp1, pp2, P.ang_th0, P.ang_k, fi, fk);
-            gx -= fi.x;
-            gy -= fi.y;
-            gz -= fi.z;
+        if (P.use_angle && (f0 & 2)) {
+            const float e = angle_forces(p0, p1, p2, P.ang_th0, P.ang_k, fi, fk);
+            if (book) ea += (double)e;
         }
     }
+    // what the two beads behind a term's first bead receive: from lane - 1 the bond's reaction and the angle's middle
+    // share, from lane - 2 the angle's far-end force
+    const float b1x = __shfl_up(bx, 1, 64), b1y = __shfl_up(by, 1, 64), b1z = __shfl_up(bz, 1, 64);
+    const float m1x = __shfl_up(fi.x + fk.x, 1, 64), m1y = __shfl_up(fi.y + fk.y, 1, 64), m1z = __shfl_up(fi.z + fk.z, 1, 64);
+    const float k2x = __shfl_up(fk.x, 2, 64), k2y = __shfl_up(fk.y, 2, 64), k2z = __shfl_up(fk.z, 2, 64);
+    // same order as ever: bond (i-1,i), bond (i,i+1), angle ending here, angle centred here, angle starting here
+    gx = (((gx - b1x) + bx) - k2x + m1x) - fi.x;
+    gy = (((gy - b1y) + by) - k2y + m1y) - fi.y;
+    gz = (((gz - b1z) + bz) - k2z + m1z) - fi.z;
 }
+
+// Tiles of a launch of `nwaves` waves over n_own owned beads: wave `gw` takes tiles gw, gw + nwaves, ...; lane l of tile t
+// stands for owned bead t * kBBTile + l - 2 (lanes 0, 1: the hand-over beads, possibly of another rank or non-existent).
+__device__ __forceinline__ int bb_tiles(int n_own) { return (n_own + kBBTile - 1) / kBBTile; }
 
 // Algorithmic traffic: read 12 B position + 1 B flag, read-modify-write 12 B gradient = 25 B/bead (+12 RMW read).
 __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4 *__restrict__ pos4,
@@ -131,12 +135,17 @@ __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4
     if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double eb = 0.0, ea = 0.0;
-    for (int li = blockIdx.x * 256 + threadIdx.x; li < P.n_own; li += gridDim.x * 256) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int t = gw; t < bb_tiles(P.n_own); t += nw) {
+        const int li = t * kBBTile + lane - 2, i = P.own_lo + li;
+        const bool out = lane >= 2 && li < P.n_own;
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        backbone_bead(P, pos4, flags, P.own_lo + li, eb, ea, gx, gy, gz);
-        g[3 * li] += gx;
-        g[3 * li + 1] += gy;
-        g[3 * li + 2] += gz;
+        backbone_lane(P, pos4, flags, i, i >= 0 && i < P.n && li < P.n_own, out, eb, ea, gx, gy, gz);
+        if (out) {
+            g[3 * li] += gx;
+            g[3 * li + 1] += gy;
+            g[3 * li + 2] += gz;
+        }
     }
     const double sb = block_sum<256>(eb, s_w);
     const double sa = block_sum<256>(ea, s_w);
@@ -292,17 +301,22 @@ __device__ __forceinline__ void bonded_fused_block(const FFParams &P, const floa
     const bool bb = flags != nullptr && (P.use_bond | P.use_angle);
     const bool any = P.use_container | P.use_lamina | P.use_central;
     const int tv = threadIdx.x & 255;
-    for (int li = vb < nvb ? vb * 256 + tv : P.n_own; li < P.n_own; li += nvb * 256) {
+    // the waves of the virtual blocks walk tiles of kBBTile beads (backbone_lane); lanes 0 and 1 of a tile only hand over
+    const int lane = threadIdx.x & 63, gw = vb * 4 + (tv >> 6), nw = nvb * 4;
+    for (int t = vb < nvb ? gw : bb_tiles(P.n_own); t < bb_tiles(P.n_own); t += nw) {
+        const int li = t * kBBTile + lane - 2;
         const int i = P.own_lo + li;
-        const float4 p = pos4[i];
+        const bool out = lane >= 2 && li < P.n_own;
         float gx = 0.f, gy = 0.f, gz = 0.f; // first writer of the gradient: the pair kernels add to it afterwards
         if (bb) {
             float tx = 0.f, ty = 0.f, tz = 0.f;
-            backbone_bead(P, pos4, flags, i, eb, ea, tx, ty, tz);
+            backbone_lane(P, pos4, flags, i, i >= 0 && i < P.n && li < P.n_own, out, eb, ea, tx, ty, tz);
             gx += tx;
             gy += ty;
             gz += tz;
         }
+        if (!out) continue;
+        const float4 p = pos4[i];
         if (lstart) {
             const int q0 = lstart[li], q1 = lstart[li + 1];
             if (q1 > q0) {
@@ -322,7 +336,7 @@ __device__ __forceinline__ void bonded_fused_block(const FFParams &P, const floa
     }
     const double v[6] = {eb, ea, elp, ec, el, ef};
     const int slot[6] = {P_BOND, P_ANGLE, P_LOOP, P_CONT, P_LAM, P_CENT};
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const double w = wave_sum(v[k]);
