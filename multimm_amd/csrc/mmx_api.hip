@@ -99,6 +99,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         {
             h->fstride = (h->n_all + 1) * 8;
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
+            HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
             h->n3_cap = n3_configure(kN3MaxCap);
             // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16
             h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 16 + 64;
@@ -226,7 +227,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own})
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead})
         if (p) (void)hipFree(p);
     if (h->dd_cnt_host) (void)hipHostFree(h->dd_cnt_host);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,

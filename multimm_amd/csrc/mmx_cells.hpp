@@ -453,12 +453,12 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, int own_lo, int n_own,
-                                              const unsigned long long *keys = nullptr) {
+                                              const unsigned long long *keys = nullptr, int *__restrict__ sbead = nullptr) {
     const int o8 = ((no + 7) >> 3) << 3; // slots of the owned clusters
     const int ncl = cell_clusters(cnt, no);
     for (int e = tid; e < ncl * 8; e += nthr) {
         float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8)); // padding: far away, bead id -1
-        int nown = 0;
+        int nown = 0, bead = -1;
         const int src = e < o8 ? (e < no ? e : -1) : (e - o8 < cnt - no ? no + (e - o8) : -1); // place in the sorted cell
         const bool real = src >= 0;
         if (real) {
@@ -466,8 +466,10 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
             const int b = keys ? (int)(unsigned)(keys[src] & 0xffffffffull) : perm[s + src];
             p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
             nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
+            bead = b;
         }
         spos4[(size_t)cb * 8 + e] = p;
+        if (sbead) sbead[(size_t)cb * 8 + e] = bead; // slot -> bead (k_nb_n3_unsort reads 4 bytes per slot, not a float4)
         const float big = 3.0e38f;
         float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
         float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
@@ -578,7 +580,8 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  float4 *__restrict__ cl_hi, int own_lo, int n_own,
                                                  const unsigned long long *__restrict__ okeys,
                                                  const int *__restrict__ biglist,
-                                                 MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
+                                                 MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
+                                                 int *__restrict__ sbead = nullptr) {
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
@@ -617,7 +620,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own, nullptr, sbead);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -642,7 +645,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf);
+            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf, sbead);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -692,7 +695,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         }
         else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
         // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, nullptr, sbead);
     }
 }
 

@@ -248,7 +248,7 @@ void launch_nb_finish(mmx_handle_s *h) {
     if (!h->n3_build) return;
     const int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     const int gu = std::max(64, std::min((cl * 8 + 255) / 256, 2048));
-    hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->spos4, h->fsort, h->fstride, h->g, h->st,
+    hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->sbead, h->fsort, h->fstride, h->g, h->st,
                        h->own_lo, h->n_own);
 }
 
@@ -740,12 +740,12 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
-                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own);
+                                   (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,

@@ -197,6 +197,7 @@ struct mmx_handle_s {
     long long gn3_launches = 0;                  // ... per replay of the captured graph
     bool n3_build = false;                       // the last enqueued cell build prepared the half-shell kernel's work items
     int last_ncells = -1;                        // cells of the grid at the last poll (picks the pair kernel, see use_n3)
+    int *sbead = nullptr;                        // half-shell kernel: bead id per cluster slot (-1: padding), written with spos4
     float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
     int fstride = 0;
     bool nb_lean = false;                        // the lean pair loop applies (default forms, one cutoff): refresh_params

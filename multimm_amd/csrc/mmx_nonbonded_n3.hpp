@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      const unsigned long long *__restrict__ okeys,
                                                      const int *__restrict__ biglist,
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
-                                                     MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
+                                                     MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
+                                                     int *__restrict__ sbead = nullptr) {
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own);
+                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own, sbead);
 }
 
 #ifdef MMX_N3_TIMING
@@ -828,14 +829,14 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 // g[bead] -= fsort[slot] for every real bead of the cluster list, fsort back to zero for the next evaluation, and the
 // item queue rewound (the pair kernel may be launched again on the same cell build: mmx_time_kernel).
 // Decomposed runs: g holds the owned beads only; what landed on a ghost's slot is dropped (its owner computes it).
-__global__ __launch_bounds__(256) void k_nb_n3_unsort(const float4 *__restrict__ spos4, float *__restrict__ fsort,
+__global__ __launch_bounds__(256) void k_nb_n3_unsort(const int *__restrict__ sbead, float *__restrict__ fsort,
                                                       const int fstride, float *__restrict__ g,
                                                       MinState *__restrict__ st, const int own_lo, const int n_own) {
     if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->n3_queue = 0;
     const int nsl = st->n_clusters * kCl;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nsl; i += gridDim.x * 256) {
-        const int bead = __float_as_int(spos4[i].w) >> 3;
+        const int bead = sbead[i];
         const float fx = fsort[i], fy = fsort[fstride + i], fz = fsort[2 * fstride + i];
         fsort[i] = 0.f;
         fsort[fstride + i] = 0.f;

@@ -19,6 +19,7 @@ for w in chr1_50k gw_200k gw_1m; do
 done
 echo "converge done"
 timeout -k 10 400 python3 scripts/dd_projection.py > $OUT/dd_projection.txt 2>&1
+timeout -k 10 400 python3 scripts/dd_halo_stats.py gw_1m 150 1500 8,4,2 > $OUT/dd_halo_stats.txt 2>&1
 echo "dd done"
 python3 - <<PY
 import json, glob, os
@@ -28,6 +29,6 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
     except Exception as e:
         print(os.path.basename(f), "unreadable", e); continue
     print(os.path.basename(f), d["config"].get("n_beads"), round(d["value"], 1), d["unit"], round(d["ms_per_step"], 4), "ms",
-          {k: round(v, 1) for k, v in d.get("kernel_us_mean", {}).items()}, "cpu", d.get("cpu_baseline", {}).get("value"))
+          {k: round(v, 1) for k, v in d.get("kernel_us_mean", {}).items()}, "cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
-cat $OUT/md.txt $OUT/converge.txt; tail -15 $OUT/dd_projection.txt
+cat $OUT/md.txt $OUT/converge.txt; grep "^world\|beads, relaxed" $OUT/dd_projection.txt; cat $OUT/dd_halo_stats.txt
