@@ -253,7 +253,7 @@ int mmx_destroy(mmx_handle h) try {
 
 int mmx_set_positions(mmx_handle h, const float *xyz) try {
     if (!h || !xyz) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     HIPCHK(h, hipSetDevice(h->device));
     for (size_t i = 0; i < (size_t)3 * h->n; ++i)
         if (!std::isfinite(xyz[i])) return fail(h, MMX_ERR_BAD_ARG, "non-finite position");
@@ -302,7 +302,7 @@ int mmx_get_positions(mmx_handle h, float *xyz) try {
 
 int mmx_set_labels(mmx_handle h, const int8_t *s) try {
     if (!h || !s) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     for (int i = 0; i < h->n; ++i)
         if (s[i] < -2 || s[i] > 2) return fail(h, MMX_ERR_BAD_ARG, "label outside {-2..2}");
     HIPCHK(h, hipSetDevice(h->device));
@@ -314,7 +314,7 @@ int mmx_set_labels(mmx_handle h, const int8_t *s) try {
 int mmx_set_backbone_masks(mmx_handle h, const uint8_t *flags, float bond_r0, float bond_k, float angle_theta0,
                            float angle_k, int32_t use_bond, int32_t use_angle) try {
     if (!h || !flags) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     const int n = h->n;
     for (int i = 0; i < n; ++i) {
         if ((flags[i] & 1) && i + 1 >= n) return fail(h, MMX_ERR_BAD_ARG, "bond flag on the last bead");
@@ -356,7 +356,7 @@ int mmx_set_backbone(mmx_handle h, const int32_t *chr_ends, int32_t n_ends, floa
 
 int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float *r0, int32_t n_loops, float k_loop) try {
     if (!h || n_loops < 0 || (n_loops > 0 && (!m || !n || !r0))) return fail(h, MMX_ERR_BAD_ARG, "bad loop arrays");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     HIPCHK(h, hipSetDevice(h->device));
     for (int l = 0; l < n_loops; ++l) {
         if (m[l] < 0 || m[l] >= h->n || n[l] < 0 || n[l] >= h->n || m[l] == n[l])
@@ -430,7 +430,7 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
 
 int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) try {
     if (!h) return MMX_ERR_BAD_ARG;
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     if (!(sigma > 0.f) || !(r_small >= 0.f) || !std::isfinite(eps) || !std::isfinite(power) || !(power > 0.f))
         return fail(h, MMX_ERR_BAD_ARG, "bad excluded-volume parameters (sigma > 0, r_small >= 0, power > 0)");
     // eps == 0 is a term that contributes nothing: it is left out (the pair kernels factor eps out of the pair loop)
@@ -445,7 +445,7 @@ int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small,
 
 int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, float cutoff_nm) try {
     if (!h || !E || !(rc > 0.f)) return fail(h, MMX_ERR_BAD_ARG, "bad compartment parameters");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     auto idx = [](int si, int sj) { return (si + 2) * 5 + (sj + 2); };
     if (mode == MMX_COMP_COB) { // model.py:246-250: A = {1,2}, B = {-1,-2}
         std::memset(h->tab_cob, 0, sizeof(h->tab_cob));
@@ -472,7 +472,7 @@ int mmx_set_compartments(mmx_handle h, int32_t mode, const float *E, float rc, f
 
 int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float centre[3]) try {
     if (!h || !centre) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     h->P.use_container = 1;
     h->P.sc_C = C;
     h->P.sc_R1 = R1;
@@ -485,7 +485,7 @@ int mmx_set_container(mmx_handle h, float C, float R1, float R2, const float cen
 
 int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre[3]) try {
     if (!h || !centre || !(R2 != R1)) return fail(h, MMX_ERR_BAD_ARG, "bad lamina parameters");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     h->P.use_lamina = 1;
     h->P.ibl_B = B;
     h->P.ibl_R1 = R1;
@@ -498,7 +498,7 @@ int mmx_set_lamina(mmx_handle h, float B, float R1, float R2, const float centre
 
 int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], const float *w) try {
     if (!h || !centre || !w) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->cf_w) HIPCHK(h, dalloc(&h->cf_w, (size_t)h->n));
     HIPCHK(h, hipMemcpy(h->cf_w, w, sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice));
@@ -513,7 +513,7 @@ int mmx_set_central(mmx_handle h, float G, float R1, const float centre[3], cons
 
 int mmx_set_chromosomal_blocks(mmx_handle h, float k_C, float dE, const int32_t *chrom) try {
     if (!h || !chrom) return fail(h, MMX_ERR_BAD_ARG, "null argument");
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     if ((h->n + 255) / 256 > kPartStride) return fail(h, MMX_ERR_BAD_ARG, "too many beads for the chromosomal-block kernel");
     HIPCHK(h, hipSetDevice(h->device));
     // chromosome ids must form contiguous runs; remap them to 0..K-1 in order of appearance
@@ -559,7 +559,7 @@ int mmx_set_functional_form(mmx_handle h, int32_t selector, int32_t form) try {
 
 int mmx_disable_term(mmx_handle h, int32_t term) try {
     if (!h) return MMX_ERR_BAD_ARG;
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = h->grid_ready = false; // cached forces (MD) and the cell grid of the last build are stale now
     switch (term) {
     case MMX_T_EV: h->P.use_ev = 0; break;
     case MMX_T_GAUSS: h->has_cob = h->has_scb = false; h->P.use_gauss = 0; break;
@@ -577,7 +577,7 @@ int mmx_disable_term(mmx_handle h, int32_t term) try {
 
 int mmx_set_option(mmx_handle h, const char *key, double value) try {
     if (!h || !key) return MMX_ERR_BAD_ARG;
-    h->md_forces_valid = false; // forces cached for the MD integrator are stale now
+    h->md_forces_valid = false; // forces cached for the MD integrator are stale now (no option changes the cell grid)
     const std::string k(key);
     if (k == "deterministic") h->deterministic = value != 0.0;
     else if (k == "profile") h->profile = (int)value;
@@ -679,24 +679,23 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     std::memset(&local, 0, sizeof(local));
     for (int k = 0; k < MMX_N_KERNELS; ++k) h->launches[k] = 0;
 
-    // epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2))  (OpenMM LocalEnergyMinimizer)
-    std::vector<float> hx((size_t)3 * h->n);
-    if ((rc = mmx_get_positions(h, hx.data()))) return rc; // whole system (multi-GPU: every rank sees the same)
-    double nrm = 0.0;
-    for (float v : hx) nrm += (double)v * (double)v;
-    nrm /= (double)h->n;
-    nrm = nrm < 1.0 ? 1.0 : std::sqrt(nrm);
-
-    std::memset(h->st_host, 0, sizeof(MinState));
-    h->st_host->phase = PH_IDLE;
-    if ((rc = push_state(h))) return rc;
-    if ((rc = prime_items(h))) return rc;
+    // A build before the first evaluation (one launch sequence + one host round trip) teaches the host the cluster and
+    // item counts of this state and, on a decomposed run, builds the ghost lists.  A single-domain handle that has
+    // built cells since anything about the system last changed skips it: the grid of its last build is a valid (if
+    // slightly stale) grid for these positions -- k_cell_count's clamping argument -- and the counts are known.
+    if (!h->grid_ready || h->world > 1 || h->n_own != h->n || h->last_clusters <= 0) {
+        std::memset(h->st_host, 0, sizeof(MinState));
+        h->st_host->phase = PH_IDLE;
+        if ((rc = push_state(h))) return rc;
+        if ((rc = prime_items(h))) return rc;
+    }
 
     std::memset(h->st_host, 0, sizeof(MinState));
     h->st_host->phase = PH_INIT;
     h->st_host->k = 1;
     h->st_host->max_iters = max_iters;
-    h->st_host->epsilon = tolerance / nrm;
+    h->st_host->tolerance = tolerance; // epsilon = tolerance / max(1, rms |x_i|): formed on the device (controller_decide)
+    h->st_host->n_total = (double)h->n;
     h->st_host->n_items = h->last_items > 0 ? h->last_items : 0;
     if ((rc = push_state(h))) return rc;
     const size_t nv = (size_t)h->n4 * 4;
@@ -713,8 +712,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     };
     h->prof_eval = 1; // the first evaluation is a profiling sample when profiling is on
     enqueue_eval(h, PACK_PLAIN, FOLD_MIN);
-    if ((rc = pull_state(h))) return leave(rc);
-    local.e_initial = h->st_host->fx;
+    // (no poll here: the trial evaluations go out behind it at once; MinState::f0 keeps the initial energy)
     // Trial evaluations: pairs of them are replayed from a hipGraph (single-GPU runs; option use_graph), except the
     // every profile-th evaluation, which goes out launch by launch with HIP events around every kernel slot.
     const bool graphs = h->use_graph && !has_comm(h) && h->world == 1;
@@ -791,6 +789,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     local.evaluations = s.evals;
     local.status = s.status;
     local.n_beads = h->n;
+    local.e_initial = s.f0;
     local.e_final = s.fx;
     local.gnorm_final = s.gnorm;
     local.xnorm_final = s.xnorm;

@@ -105,6 +105,9 @@ struct MinState {
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;
+    double tolerance; // minimizer: epsilon = tolerance / max(1, rms |x_i|) is formed on the device from the first evaluation's x.x
+    double n_total;   // ... beads of the whole system
+    double f0;        // energy of the first evaluation of the call
     double gnorm, xnorm;
     double cell_edge;
     double eterms[9];       // per-term energies of the last evaluation

@@ -756,6 +756,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                                h->own_lo, h->n_own, h->okeys, h->biglist, h->st, h->count_own);
         h->gcur = cur;
         h->build_idx++;
+        h->grid_ready = true;
     }
 }
 

@@ -207,6 +207,7 @@ struct mmx_handle_s {
     GridParams *grid = nullptr;  // [2]: grid of this build / of the next one (ping-pong)
     GridParams *gcur = nullptr;  // grid the last enqueued build used (what the pair kernel reads)
     int build_idx = 0;
+    bool grid_ready = false;     // grid[build_idx & 1] was computed by a build of this system as it is now (no setter since)
     float *bbox_part = nullptr;  // [6][ceil(n/256)] per-block bounding boxes of k_pack
     int maxcells = 262144;
     int max_items = 0;

@@ -136,8 +136,14 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
             return;
         }
         st->fx = f;
+        st->f0 = f;
         for (int t = 0; t < 9; ++t) st->eterms_acc[t] = sums[t];
         double xn = sqrt(xx);
+        // OpenMM LocalEnergyMinimizer: epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2)) of the starting positions
+        // (x.x of this very evaluation: no copy of the positions to the host, no all-gather on a decomposed run)
+        double rms = sqrt(xx / st->n_total);
+        if (rms < 1.0) rms = 1.0;
+        st->epsilon = st->tolerance / rms;
         if (xn < 1.0) xn = 1.0;
         st->xnorm = xn;
         st->gnorm = sqrt(gg);
