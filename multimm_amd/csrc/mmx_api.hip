@@ -754,12 +754,24 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             // longer than its message, and decided nothing.  New lists and capacities at the trial point (the pack of the
             // repeated evaluation writes it again), then the evaluation itself.
             h->dd_halts++;
-            // (both policies read the all-reduced flags: every rank must arrive at the same capacities and the same skin)
-            if (h->st_host->sums[kSumOverflow] > 0.5) h->dd_slack_div = std::max(2, h->dd_slack_div / 2); // lists grow faster than assumed
-            if (h->st_host->sums[kSumStale] > 0.5) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f); // the skin did not last dd_every evaluations
+            if (std::getenv("MMX_DD_DEBUG")) { // which list outgrew which message
+                std::vector<int> cnt(h->world);
+                (void)hipMemcpy(cnt.data(), h->dd_send_cnt, sizeof(int) * h->world, hipMemcpyDeviceToHost);
+                std::string line = "[dd] rank " + std::to_string(h->rank) + " halt at eval " + std::to_string(h->st_host->evals) +
+                                   " reason=" + std::to_string(h->st_host->halt_reason) + " slack_div=" + std::to_string(h->dd_slack_div) + ":";
+                for (int q = 0; q < h->world; ++q)
+                    if (q != h->rank) line += " " + std::to_string(cnt[q]) + "/" + std::to_string(h->dd_scap.cap[q]);
+                std::fprintf(stderr, "%s\n", line.c_str());
+            }
+            // (both policies read the reason k_decide_reduced recorded from the ALL-REDUCED flags: every rank must arrive at the
+            // same capacities and the same skin)
+            if (h->st_host->halt_reason & 2) h->dd_slack_div = std::max(1, h->dd_slack_div / 2); // lists grow faster than assumed
+            if (h->st_host->halt_reason & 1) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f); // the skin did not last dd_every evaluations
+            ramp = 4; // what follows a halt is polled (and its messages resized) at short intervals again
             h->st_host->phase = h->st_host->halt_phase;
             h->st_host->dd_stale = 0;
             h->st_host->dd_overflow = 0;
+            h->st_host->halt_reason = 0;
             if ((rc = push_state(h))) return leave(rc);
             h->prof_eval = 0;
             enqueue_eval(h, PACK_MOVE, FOLD_MIN, 1);

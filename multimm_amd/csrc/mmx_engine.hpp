@@ -531,7 +531,9 @@ int dd_upload_static(mmx_handle_s *h) {
 // adds 10-20 % of ghosts between two polls).
 int dd_capacity(const mmx_handle_s *h, int cnt) {
     if (h->inject_fault & 4) return std::max(cnt, 0); // tests: no slack at all -- any growth of a list halts the evaluation
-    return cnt <= 0 ? 0 : std::min(h->slice, cnt + cnt / h->dd_slack_div + 512);
+    // (an empty list still gets a message of 512 entries = 8 KB: two slices that come into contact during a run -- the
+    // collapse phase re-arranges who touches whom -- would otherwise void an evaluation for their first shared ghost)
+    return std::min(h->slice, std::max(cnt, 0) + std::max(cnt, 0) / h->dd_slack_div + 512);
 }
 
 // Message capacities from the world x world matrix of list lengths (row = sender).  `fresh`: every capacity is set from
@@ -543,7 +545,6 @@ bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
     auto upd = [&](int &cap, int cnt) {
         int want = cap;
         if (fresh || cnt + cnt / (2 * h->dd_slack_div) > cap || (cap > 2048 && dd_capacity(h, cnt) < cap / 2)) want = dd_capacity(h, cnt);
-        if (!fresh && cap == 0 && cnt > 0) want = dd_capacity(h, cnt);
         if (want != cap) {
             cap = want;
             changed = true;

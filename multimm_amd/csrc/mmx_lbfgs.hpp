@@ -506,6 +506,7 @@ __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
     if (st->sums[kSumKernelError] <= 0.5 && (st->sums[kSumStale] > 0.5 || st->sums[kSumOverflow] > 0.5)) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
         st->halt_phase = st->phase;
+        st->halt_reason = (st->sums[kSumStale] > 0.5 ? 1 : 0) | (st->sums[kSumOverflow] > 0.5 ? 2 : 0);
         st->phase = PH_HALT;
         st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
         return;
