@@ -12,7 +12,7 @@ n = nb or n0
 loops = max(1, int(round(l0 * n / n0)))
 ALG = {  # bytes per launch
     "k_backbone": 25.0 * n, "k_loops": 64.0 * loops, "k_confine": 25.0 * n, "k_history": 228.0 * n,
-    "k_pack": (28.0 + 168.0) * n, "k_cell_fill": 28.0 * n, "k_cell_order": 56.0 * n, "k_nb_n3_unsort": 28.0 * n,
+    "k_pack": (28.0 + 168.0) * n, "k_cell_fill": 28.0 * n, "k_cell_order": 56.0 * n, "k_order_items": 56.0 * n, "k_nb_n3_unsort": 28.0 * n,
     "k_nb_n3": 32.0 * n, "k_nb_clusters_j": 32.0 * n,
 }
 stats = {}
