@@ -2,7 +2,7 @@
 per rank, bytes on the wire per evaluation against the all-gather they replace, rebuilds, halts -- in the collapse phase
 (first `iters` iterations from the lattice) and on the relaxed structure (`relax` iterations further).  (Timing on one GPU
 says nothing about 8: only the volumes are reported.)   usage: dd_halo_stats.py [workload] [iters=150] [relax=1500] [worlds=2,4,8]"""
-import sys, threading
+import os, sys, threading
 sys.path.insert(0, '.')
 import numpy as np
 from multimm_amd import synthetic_system
@@ -16,6 +16,11 @@ KEYS = ("dd_ghosts", "dd_ghost_slots", "dd_exchanges", "dd_bytes_sent", "dd_rede
 s = synthetic_system(name)
 for world in worlds:
     engines = [engine_for(s, rank=r, world=world) for r in range(world)]
+    for e in engines:   # DD_EVERY / DD_SKIN in the environment: lists rebuilt every K-th evaluation under a skin (default: every one, none)
+        if os.environ.get("DD_EVERY"):
+            e.set_option("dd_rebuild_every", float(os.environ["DD_EVERY"]))
+        if os.environ.get("DD_SKIN"):
+            e.set_option("dd_skin", float(os.environ["DD_SKIN"]))
     Engine.comm_init_local(engines)
     out = [None] * world
     def work(r):
