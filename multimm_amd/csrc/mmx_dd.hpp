@@ -19,8 +19,8 @@
 //     for the positions they are used with and there is no skin at all.  With a rebuild every K > 1 evaluations the
 //     lists hold while no bead has moved more than skin / 2 (k_dd_displacement).
 //   messages of host-known capacity.  ncclSend / ncclRecv need their sizes on the host, the lists are sized on the
-//     device: a message carries `cap` entries (the length of the list at the last synchronous rebuild + 1/8 + 512),
-//     entries beyond the list are padding (bead id -1).  Every all-gather of the maps also carries the senders' current
+//     device: a message carries `cap` entries (the length of the list when the capacity was last set + 1/8 ... 1/1 of it
+//     + 512), entries beyond the list are padding (bead id -1).  Every all-gather of the maps also carries the senders' current
 //     list lengths, so each poll of the host sees the world x world matrix of lengths and both ends of a message
 //     re-derive its capacity from the same numbers before a list outgrows it.
 //   when it still goes wrong -- a list longer than its message (dd_overflow), or a bead beyond skin / 2 (dd_stale, K > 1)

@@ -527,8 +527,8 @@ int dd_upload_static(mmx_handle_s *h) {
 }
 
 // Capacity of a message for a list of `cnt` entries: room for cnt / dd_slack_div + 512 more before the list outgrows
-// it (1/8 by default; 1/4, 1/2 after a list did outgrow its message in this call: the collapse phase of a minimization
-// adds 10-20 % of ghosts between two polls).
+// it (dd_slack_div: 4 at the start of a minimization, 8 after eight quiet polls, halved -- down to 1 -- whenever a list
+// did outgrow its message: the collapse phase of a minimization from the lattice triples some lists within 30 evaluations).
 int dd_capacity(const mmx_handle_s *h, int cnt) {
     if (h->inject_fault & 4) return std::max(cnt, 0); // tests: no slack at all -- any growth of a list halts the evaluation
     // (an empty list still gets a message of 512 entries = 8 KB: two slices that come into contact during a run -- the
@@ -537,8 +537,8 @@ int dd_capacity(const mmx_handle_s *h, int cnt) {
 }
 
 // Message capacities from the world x world matrix of list lengths (row = sender).  `fresh`: every capacity is set from
-// the length (a synchronous rebuild: the lists are these very ones); otherwise only where a list has come within 1/16
-// of its capacity or shrunk to under half of it.  Both ends of a message evaluate the same rule on the same numbers.
+// the length (a synchronous rebuild: the lists are these very ones); otherwise only where a list has used up half of its
+// slack or would fit a message of half the size.  Both ends of a message evaluate the same rule on the same numbers.
 bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
     const int W = h->world;
     bool changed = false;
@@ -597,10 +597,10 @@ int dd_rebuild(mmx_handle_s *h, bool sync) {
         for (int q = 0; q < h->world; ++q) caps.cap[q] = h->slice;
     hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world, h->x,
                        h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st);
-    if (h->dd_every > 1) { // the lists start a new life: reference positions of the displacement test
+    if (h->dd_every > 1) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
+                         // cleared here: the minimizer halts in the very evaluation that raises it, and an MD call must still
+                         // see at its next poll that one of its steps ran on stale lists)
         HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemsetAsync(&h->st->dd_stale, 0, sizeof(int), h->stream));
-    }
     h->dd_since = 0;
     h->dd_redecompositions++;
     if (!sync) return MMX_OK;
