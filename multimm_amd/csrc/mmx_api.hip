@@ -27,6 +27,10 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         g_create_error = "rank/world out of range";
         return MMX_ERR_BAD_ARG;
     }
+    if ((long long)(world - 1) * ((n_beads + world - 1) / world) >= n_beads) { // slices of ceil(N / world): the last ranks would own nothing
+        g_create_error = "too many ranks for this system: with slices of ceil(n_beads / world) beads some rank would own no bead";
+        return MMX_ERR_BAD_ARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_error = "no HIP device visible (libmmx has no CPU path)";

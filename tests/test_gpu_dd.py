@@ -256,6 +256,16 @@ def test_chromosomal_blocks_fall_back_to_the_all_gather():
         assert np.abs(F - F0).max() <= 1e-5 * np.abs(F0).max()
 
 
+def test_a_rank_must_own_a_bead():
+    """Slices are ceil(N / world) beads: 9 beads on 8 ranks would leave three ranks without any (and their launches
+    without a grid).  mmx_create_dd refuses such a decomposition instead of failing later."""
+    from multimm_amd.engine import MMXError
+    with pytest.raises(MMXError) as exc:
+        Engine(9, rank=7, world=8)
+    assert exc.value.code == -1 and "too many ranks" in str(exc.value)
+    Engine(9, rank=2, world=3).close()
+
+
 def test_local_communicator_argument_checks():
     s = synthetic_system("region_5k", n_beads=600)
     a, b = engine_for(s, rank=0, world=2), engine_for(s, rank=1, world=2)
