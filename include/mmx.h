@@ -114,6 +114,8 @@ int mmx_abi_version(void);
  * minimizer (energies, the three Gram rows an accepted step would change, g.d, x.x, two flags), 16 in a plain
  * evaluation -- RCCL, issued on the handle's stream, no host round trip (csrc/mmx_dd.hpp).  Without a communicator a
  * multi-rank handle still evaluates its owned beads against the positions last set by the host (unit tests). */
+/* (MMX_ERR_BAD_ARG when some rank would own no bead: slices are ceil(N / world) beads, so world must not exceed
+ * N / ceil(N / world) + 1 -- e.g. 9 beads cannot go on 8 ranks.) */
 int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out);
 int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world);
 /* rank 0: 128-byte ncclUniqueId to hand to every rank (e.g. by torch.distributed broadcast). */
