@@ -323,3 +323,17 @@ def test_config5_size_gw_1m_on_8_ranks():
     assert (it, status) == (st0.iterations, st0.status)
     assert abs(e_i - st0.e_initial) <= 2e-6 * (abs(st0.e_initial) + abs(st0.e_final))
     assert abs(e_f - st0.e_final) <= 5e-3 * abs(st0.e_initial - st0.e_final)
+
+
+def test_randomised_decompositions():
+    """scripts/dd_stress.py: ten random combinations of size, rank count, rebuild interval, skin, message slack and pair
+    kernel; each minimizes, runs a few MD steps and ends with forces that must equal a single-domain engine's at the same
+    positions (1e-5 of max |F|), identical on every rank."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dd_stress.py"), "10", "7"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "bad cases: 0" in r.stdout
