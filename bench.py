@@ -247,8 +247,10 @@ def spawn_ranks(args) -> int:
     """`bench.py --gpus N` without a launcher: start N rank processes as ONE child (torch.distributed.run, which starts
     the ranks) before this process has made any GPU call -- it never makes one --, hand their JSON line through and
     return their exit code.  With fewer GPUs visible than ranks (a rehearsal on a one-GPU box) the ranks share devices:
-    torch.distributed then runs on gloo (RCCL refuses two ranks on one device), the line says so, and its numbers are
-    not a scaling measurement."""
+    torch.distributed then runs on gloo, and the library's own RCCL communicator is told that every rank sits on a host
+    of its own (NCCL_HOSTID, set per rank in main()): RCCL's duplicate-GPU check does not apply and the ranks talk through
+    its socket transport over the loopback interface -- the real ncclAllGather / ncclSend / ncclRecv / ncclAllReduce call
+    sites of the decomposed leg run with N ranks.  The line says so; its numbers are not a scaling measurement."""
     import socket
     import subprocess
     import torch  # device_count() does not initialise the GPU
@@ -288,6 +290,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MMX_BENCH_REHEARSAL") and world > 1:
+        # ranks share a GPU: each tells RCCL it is a host of its own, reachable through sockets on the loopback interface
+        os.environ.update({"NCCL_HOSTID": f"mmx-rehearsal-rank-{rank}", "NCCL_IB_DISABLE": "1", "NCCL_SOCKET_IFNAME": "lo",
+                           "NCCL_P2P_DISABLE": "1", "NCCL_SHM_DISABLE": "1", "NCCL_NET": "Socket"})
     import torch
     import torch.distributed as dist
 
