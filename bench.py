@@ -207,8 +207,10 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
                 "allgather_bytes_it_replaces_per_rank": 16.0 * eng.n_own * (world - 1),
                 "allreduce_bytes_per_evaluation": 8.0 * 59,
                 "ghosts_rank0": eng.get_option("dd_ghosts"), "owned_rank0": eng.n_own,
-                "redecompositions": eng.get_option("dd_redecompositions") - r0,
-                "skin_nm_at_end": eng.get_option("dd_skin_now"),
+                "list_rebuilds": eng.get_option("dd_redecompositions") - r0,
+                "list_rebuilds_host_synchronous": eng.get_option("dd_sync_rebuilds"),
+                "evaluations_voided_and_repeated": eng.get_option("dd_halts"),
+                "rebuild_every": eng.get_option("dd_rebuild_every"),
             })
         finally:
             eng.close()

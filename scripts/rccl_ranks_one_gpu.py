@@ -2,7 +2,9 @@
 it sits on a different host (NCCL_HOSTID), so RCCL's duplicate-GPU check does not apply and the ranks talk through its socket
 transport over the loopback interface.  Functional check only (sockets, not xGMI): the library's ncclAllGather / grouped
 ncclSend+ncclRecv / ncclAllReduce call sites, message capacities, halts -- against a single-domain engine.
-usage: rccl_ranks_one_gpu.py [world=2] [n_beads=12000] [iters=30]"""
+usage: rccl_ranks_one_gpu.py [world=2] [n_beads=12000] [iters=30]      (environment: MMX_NB_VARIANT, MMX_DD_EVERY, MMX_DD_SKIN,
+MMX_INJECT = engine options nb_variant, dd_rebuild_every, dd_skin, inject_fault).  Exit code 3: RCCL could not be initialised this
+way on this machine (no loopback interface ...), 0: results equal the single-domain engine's."""
 import os, sys, socket
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,6 +24,9 @@ def worker(rank, world, port, n_beads, iters, q):
         s = synthetic_system("gw_200k", n_beads=n_beads, jitter=0.02, seed=3)
         eng = engine_for(s, device=0, rank=rank, world=world)
         eng.set_option("nb_variant", float(os.environ.get("MMX_NB_VARIANT", "0")))
+        for key, env in (("dd_rebuild_every", "MMX_DD_EVERY"), ("dd_skin", "MMX_DD_SKIN"), ("inject_fault", "MMX_INJECT")):
+            if os.environ.get(env):
+                eng.set_option(key, float(os.environ[env]))
         uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128)
         try:
             eng.comm_init(uid)
