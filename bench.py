@@ -365,7 +365,8 @@ def main():
         nb_us = d["kernel_us_mean"]["nonbonded"]
         census = None
         try:
-            census = eng.nb_census() if args.cutoff > 0 else None
+            # (a census on a decomposed handle is a collective -- it rebuilds the ghost lists -- and only rank 0 is here)
+            census = eng.nb_census() if args.cutoff > 0 and not dd else None
         except Exception:
             census = None
         roofline = None
