@@ -174,8 +174,14 @@ __global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, i
                                                         const unsigned long long *__restrict__ maps /* [world][kDDPayload] */,
                                                         const unsigned long long *__restrict__ static_mask,
                                                         int *__restrict__ send_ids, int slice, int *__restrict__ send_cnt,
-                                                        const DDCaps caps, MinState *__restrict__ st) {
+                                                        const DDCaps caps, MinState *__restrict__ st,
+                                                        int *__restrict__ cntmat = nullptr) {
     if (st->phase >= PH_DONE) return;
+    // rebuilds on the stream: block 0 also copies the list lengths that came with the maps -- rank r's send list for q as it
+    // was until now -- into the world x world matrix the host reads at its next poll
+    if (cntmat && blockIdx.x == 0)
+        for (int t = threadIdx.x; t < world * world; t += 256)
+            cntmat[t] = reinterpret_cast<const int *>(maps + (size_t)(t / world) * kDDPayload + kDDWords)[t % world];
     const DDGrid G = *grid;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n_own;
@@ -201,12 +207,6 @@ __global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, i
         }
         if (need) send_ids[(size_t)q * slice + base + __popcll(m & ((1ull << lane) - 1ull))] = own_lo + i;
     }
-}
-
-// cntmat[r][q] = length of rank r's send list for q as carried by the last all-gather of the maps; one block
-__global__ void k_dd_gather_counts(const unsigned long long *__restrict__ maps, int world, int *__restrict__ cntmat) {
-    for (int t = threadIdx.x; t < world * world; t += blockDim.x)
-        cntmat[t] = reinterpret_cast<const int *>(maps + (size_t)(t / world) * kDDPayload + kDDWords)[t % world];
 }
 
 // sendbuf[q][k] = pos4[send_ids[q][k]] for the entries of the list, padding (bead id -1) up to the message's capacity;

@@ -589,14 +589,14 @@ int dd_rebuild(mmx_handle_s *h, bool sync) {
                        h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
     coll_allgather_small(h, h->dd_maps, sizeof(unsigned long long) * kDDPayload,
                          [](mmx_handle_s *o) { return (void *)o->dd_maps; });
-    if (!sync) // the lengths of the lists in use until now, of every rank: what the next poll sizes the messages by
-        hipLaunchKernelGGL(k_dd_gather_counts, dim3(1), dim3(256), 0, h->stream, h->dd_maps, h->world, h->dd_cntmat);
     HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
     DDCaps caps = h->dd_scap;
     if (sync)
         for (int q = 0; q < h->world; ++q) caps.cap[q] = h->slice;
     hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world, h->x,
-                       h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st);
+                       h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st,
+                       sync ? nullptr : h->dd_cntmat); // (on the stream: + the lengths of the lists in use until now, of every
+                                                      // rank: what the next poll sizes the messages by)
     if (h->dd_every > 1) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
                          // cleared here: the minimizer halts in the very evaluation that raises it, and an MD call must still
                          // see at its next poll that one of its steps ran on stale lists)
