@@ -73,26 +73,29 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__re
                 float c[MMX_NBASIS];
 #pragma unroll
                 for (int b = 0; b < MMX_NBASIS; ++b) c[b] = (float)st->coef[b];
-                const float4 G = reinterpret_cast<const float4 *>(D.g)[e4];
-                float4 o = make_float4(c[2 * MMX_M] * G.x, c[2 * MMX_M] * G.y, c[2 * MMX_M] * G.z, c[2 * MMX_M] * G.w);
+                // ALL 14 loads first, unconditionally (history slots not yet written hold zeros: mmx_minimize clears S and Y):
+                // behind `if (c[a] != 0)` every load sat in a basic block of its own and the kernel was 13 dependent memory
+                // round trips long (12.7 us at 200 000 beads, 10.5 at 50 000: latency, not bandwidth)
+                float4 sv[MMX_M], yv[MMX_M];
 #pragma unroll
                 for (int a = 0; a < MMX_M; ++a) {
-                    if (c[a] != 0.f) {
-                        const float4 sv = reinterpret_cast<const float4 *>(D.S + (size_t)a * D.nv)[e4];
-                        o.x = fmaf(c[a], sv.x, o.x);
-                        o.y = fmaf(c[a], sv.y, o.y);
-                        o.z = fmaf(c[a], sv.z, o.z);
-                        o.w = fmaf(c[a], sv.w, o.w);
-                    }
-                    if (c[MMX_M + a] != 0.f) {
-                        const float4 yv = reinterpret_cast<const float4 *>(D.Y + (size_t)a * D.nv)[e4];
-                        o.x = fmaf(c[MMX_M + a], yv.x, o.x);
-                        o.y = fmaf(c[MMX_M + a], yv.y, o.y);
-                        o.z = fmaf(c[MMX_M + a], yv.z, o.z);
-                        o.w = fmaf(c[MMX_M + a], yv.w, o.w);
-                    }
+                    sv[a] = reinterpret_cast<const float4 *>(D.S + (size_t)a * D.nv)[e4];
+                    yv[a] = reinterpret_cast<const float4 *>(D.Y + (size_t)a * D.nv)[e4];
                 }
+                const float4 G = reinterpret_cast<const float4 *>(D.g)[e4];
                 xp4 = reinterpret_cast<const float4 *>(x)[e4];
+                float4 o = make_float4(c[2 * MMX_M] * G.x, c[2 * MMX_M] * G.y, c[2 * MMX_M] * G.z, c[2 * MMX_M] * G.w);
+#pragma unroll
+                for (int a = 0; a < MMX_M; ++a) { // same operations in the same order (a zero coefficient adds c * v = 0)
+                    o.x = fmaf(c[a], sv[a].x, o.x);
+                    o.y = fmaf(c[a], sv[a].y, o.y);
+                    o.z = fmaf(c[a], sv[a].z, o.z);
+                    o.w = fmaf(c[a], sv[a].w, o.w);
+                    o.x = fmaf(c[MMX_M + a], yv[a].x, o.x);
+                    o.y = fmaf(c[MMX_M + a], yv[a].y, o.y);
+                    o.z = fmaf(c[MMX_M + a], yv[a].z, o.z);
+                    o.w = fmaf(c[MMX_M + a], yv[a].w, o.w);
+                }
                 d4 = o;
                 reinterpret_cast<float4 *>(xp)[e4] = xp4;
                 reinterpret_cast<float4 *>(D.gp)[e4] = G;
