@@ -373,6 +373,27 @@ def test_full_size_oracle_parity_200k():
                 assert np.abs(F - F_ref).max() <= f_rtol * fmax + F_ATOL, (relaxed, variant)
 
 
+def test_full_size_oracle_parity_1m():
+    """BASELINE config 5 size against the fp64 oracle itself (1 000 000 beads: a few seconds of its OpenMP evaluation on the
+    box's host cores): the state the default path reaches after 40 iterations, both cell-list pair kernels, every term on."""
+    import dataclasses
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_1m", **ALL_ON)
+    with engine_for(s) as eng:
+        eng.minimize(tolerance=0.0, max_iters=40)
+        x = eng.get_positions().astype(np.float64)
+    s2 = dataclasses.replace(s, positions=x)
+    et_ref, F_ref = Oracle(s2).eval()
+    scale_e, fmax = np.abs(et_ref).sum(), np.abs(F_ref).max()
+    with engine_for(s2) as eng:
+        for variant in (4096, 8192):
+            eng.set_option("nb_variant", variant)
+            et, F = eng.compute()
+            print(f"ACC gw_1m variant {variant}: max err / max|F| = {np.abs(F - F_ref).max() / fmax:.2e}")
+            assert np.all(np.abs(et - et_ref) <= E_RTOL * scale_e + E_ATOL), (variant, et, et_ref)
+            assert np.abs(F - F_ref).max() <= F_RTOL * fmax + F_ATOL, variant
+
+
 def test_one_million_beads_runs():
     """BASELINE config 5 size on one GPU: allocation, cell build and kernels at N = 1e6."""
     s = synthetic_system("gw_1m")
