@@ -639,6 +639,9 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_redecompositions") *value = (double)h->dd_redecompositions;
     else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
     else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
+    else if (k == "n_clusters") *value = h->st_host ? h->st_host->n_clusters : 0;   // read-only: the last cell build
+    else if (k == "n_cells") *value = h->st_host ? h->st_host->ncells : 0;
+    else if (k == "n3_items") *value = h->st_host ? h->st_host->n3_items : 0;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
@@ -1237,5 +1240,16 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
 #ifdef MMX_N3_TIMING
 extern "C" int mmx_debug_n3_times(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_t), sizeof(unsigned long long) * 512 * 20);
+}
+extern "C" int mmx_debug_n3_waits(unsigned *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_w), sizeof(unsigned) * 512 * 16 * 4);
+}
+extern "C" int mmx_debug_n3_counters(unsigned long long *out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_c), sizeof(unsigned long long) * 16);
+    if (!rc && reset) {
+        const unsigned long long z[16] = {};
+        rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(mmx::g_n3_c), z, sizeof(z));
+    }
+    return rc;
 }
 #endif

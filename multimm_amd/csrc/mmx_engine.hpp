@@ -220,7 +220,8 @@ void launch_nb_n3_p(mmx_handle_s *h, int grid) {
     const int tail_sh = !tail ? 0 : (tcfg & 15u) ? (int)((tcfg >> 4) & 3u) : 1;
     const int tail2_items = tail ? grid / 4 : 0, tail2_sh = tail ? 2 : 0;
     const int spin = (h->inject_fault & 1) ? 0 : kN3SpinLimit; // option "inject_fault" bit 0: every wait of the kernel fails
-    const bool dd = h->world > 1 || h->n_own != h->n; // the cell list holds ghosts: the DD instance
+    // the cell list holds ghosts: the DD instance (nb_variant bit 16384 forces it on a single domain: same results, for A/B timing)
+    const bool dd = h->world > 1 || h->n_own != h->n || (h->nb_variant & 16384);
 #define N3L(EV, GA, NE, DDI)                                                                                \
     hipLaunchKernelGGL((k_nb_n3<PMODE, EV, GA, NE, DDI>), dim3(grid), dim3(kN3Threads), lds, h->stream, P,  \
                        h->spos4, h->cl_lo, h->n3_items, h->st, h->fsort, h->fstride, h->part,               \

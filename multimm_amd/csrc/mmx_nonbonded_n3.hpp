@@ -43,7 +43,7 @@
 // k_nb_clusters_j, which is.
 //
 // `diag` (nb_variant >> 16; timing diagnosis only, results are wrong with any bit but 64): 1 no flush atomics, 2 no LDS
-// adds (and no j-side FMAs), 4 no pair arithmetic, 8 no i-side atomics, 16 cull only, 64 items in ascending order.
+// adds (and no j-side FMAs), 4 no pair arithmetic, 8 no i-side atomics, 16 cull only, 32 ghost i-clusters skipped, 64 items in ascending order.
 //
 // Self tile: the 8 beads of the i-cluster also enter the stream as j beads.  All 64 ordered pairs of that tile are
 // evaluated, so the i side alone gets the complete intra-cluster force; the j-side sums of those lanes are dropped
@@ -57,6 +57,10 @@ namespace mmx {
 constexpr int kN3Waves = 16;        // waves per workgroup
 constexpr int kN3Threads = kN3Waves * 64;
 constexpr int kN3ItemClusters = 16; // i-clusters per work item (grabbed one at a time by the waves)
+#ifndef MMX_N3_ISEG
+#define MMX_N3_ISEG 1
+#endif
+constexpr int kN3ISeg = MMX_N3_ISEG; // the 8 i beads of a cluster are swept in this many groups; a group of padding is skipped
 constexpr int kN3List = 192;        // accepted j-clusters buffered per wave before a sweep (culled 128 candidates at a time)
 constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two windows in flight: 160 KB of LDS, all of it)
 // A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
@@ -272,6 +276,11 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
 
 #ifdef MMX_N3_TIMING
 __device__ unsigned long long g_n3_t[512 * 20];
+// cumulative work counters: [ghost i-cluster ? 4 : 0] + {i-clusters, candidates past the cluster cull, streamed steps of 64 beads,
+// batches of 64 beads x 8 i beads through the pair loop}; [8] launches
+__device__ unsigned long long g_n3_c[16];
+// per wave: ticks (10 ns) spent waiting for a unit to become ready (flush help included), ticks inside i-cluster visits
+__device__ unsigned g_n3_w[512 * 16 * 4];
 #endif
 // float -> int, rounded to nearest (ties up): ONE operation where __float2int_rn is v_rndne + v_cvt
 __device__ __forceinline__ int cvt_nearest(float v) {
@@ -371,6 +380,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         }
     }
     double acc_ev = 0.0, acc_g = 0.0;
+#ifdef MMX_N3_TIMING
+    unsigned cnt_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (diag & 128)) atomicAdd(&g_n3_c[8], 1ull);
+#endif
 
     volatile int *vready = ctl.ready, *vepoch = ctl.fl_epoch;
     // Flush job of parity p (window of unit `unit`): takes one chunk of 256 window slots if there is one left.
@@ -529,9 +542,15 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         stage_unit(1);
         if (lane == 0) vready[1] = 1;
     }
+#ifdef MMX_N3_TIMING
+    unsigned long long t_wait = 0ull, t_visit = 0ull, t_stage = 0ull, n_stage = 0ull;
+#endif
     for (int v = 0;; ++v) {
         const int p = v & 1;
         bool failed = false;
+#ifdef MMX_N3_TIMING
+        const unsigned long long tw0 = wall_clock64();
+#endif
         for (int spins = 0; vready[p] < v; ++spins) {
             help_flush(p, v - 2);
             __builtin_amdgcn_s_sleep(2);
@@ -547,6 +566,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             }
             break;
         }
+#ifdef MMX_N3_TIMING
+        t_wait += wall_clock64() - tw0;
+#endif
         wg_lds_acquire(); // what the stager / the flushers wrote before they raised `ready`
         __builtin_amdgcn_wave_barrier();
         const int *dd = s_desc[p];
@@ -572,10 +594,15 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (lane == 0) gi = atomicAdd(&ctl.grab[p], 1);
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (gi >= D_n) break;
+#ifdef MMX_N3_TIMING
+            const unsigned long long tv0 = wall_clock64();
+#endif
             const int icl = D_a + gi;
             const float4 lo_i = cl_box[2 * icl], hi_i = cl_box[2 * icl + 1];
             // decomposed runs: is this a cluster of owned beads or of ghosts (never both)
+            const int n_i = __builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w)) & 255; // real beads (slots 0 .. n_i - 1)
             const bool i_own = !DD || __builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w) >> 8) != 0;
+            if (DD && !i_own && (diag & 32)) continue; // timing diagnosis only: what the kernel costs without ghost i-clusters
             float4 pv = spos4[(size_t)icl * kCl + slot];
             const int own_w = __float_as_int(pv.w);
             if (own_w < 0) { // padding slots: far away on the i side (they are j entries at +1e18 too)
@@ -598,6 +625,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 wave_lds_sync();
             }
             float ee = 0.f, eg = 0.f;
+#ifdef MMX_N3_TIMING
+            const int cg = i_own ? 0 : 4;
+            cnt_w[cg]++;
+#endif
             // the i-cluster's own place in the window: candidates before it have lower cluster ids (i-clusters of this
             // item or of an earlier one: they take those pairs); it is itself a candidate (the self tile)
             const int own_k = (icl - D_a) - wlo;
@@ -638,6 +669,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                     if (lane < 8) list[nlist + lane] = (unsigned short)cap; // pad to a multiple of 8: the dummy cluster
                     wave_lds_sync();
                     const int nsteps = max((nlist + 7) >> 3, 1);
+#ifdef MMX_N3_TIMING
+                    cnt_w[cg + 1] += nlist;
+                    cnt_w[cg + 2] += nsteps;
+#endif
                     // ---- sweep: 8 j-clusters (64 j beads) per step; ids two steps ahead, positions one
                     int ln = list[sub];
                     float4 qn = spos4[(unsigned)s_jc[ln] * kCl + slot];
@@ -675,6 +710,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 if (lane >= rcount) q = make_float4(-1e18f, -1e18f, -1e18f, __int_as_float(((cap * 8) << 3) | 2));
                             }
                             const int took = min(rcount, 64);
+#ifdef MMX_N3_TIMING
+                            cnt_w[cg + 3]++;
+#endif
                             rhead = (rhead + took) & 127;
                             rcount -= took;
                             const int wq = __float_as_int(q.w);
@@ -688,7 +726,10 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 continue;
                             }
 #pragma unroll
-                            for (int s = 0; s < kCl; ++s) {
+                            for (int sg = 0; sg < kN3ISeg; ++sg) {
+                              if (sg > 0 && n_i <= sg * (kCl / kN3ISeg)) break; // (wave-uniform: the rest of the i-cluster is padding)
+#pragma unroll
+                            for (int s = sg * (kCl / kN3ISeg); s < (sg + 1) * (kCl / kN3ISeg); ++s) {
                                 const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
                                 const float r2t = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, tiny)));
                                 const float in = fma_sat(r2t, nbig, cut_all);
@@ -718,6 +759,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 fjx = fmaf(fs, dx, fjx);
                                 fjy = fmaf(fs, dy, fjy);
                                 fjz = fmaf(fs, dz, fjz);
+                            }
                             }
                             const bool self = (jslot >> 3) == own_lc;
                             const bool big = fmaxf(fmaxf(fabsf(fjx), fabsf(fjy)), fabsf(fjz)) >= fix_lim;
@@ -777,6 +819,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 acc_ev += (double)ee;
                 acc_g += (double)eg;
             }
+#ifdef MMX_N3_TIMING
+            t_visit += wall_clock64() - tv0;
+#endif
         }
         // ---- out of i-clusters: leave the unit; the last wave to do so opens the flush and stages unit v + 2
         wg_lds_release(); // this wave's adds into the window, before it is counted out
@@ -797,12 +842,27 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             wg_lds_release(); // the job description, before the epoch that opens it
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) vepoch[p] = v; // the job is open
+#ifdef MMX_N3_TIMING
+            const unsigned long long ts0 = wall_clock64();
+#endif
             stage_unit(v + 2);
+#ifdef MMX_N3_TIMING
+            t_stage += wall_clock64() - ts0;
+            n_stage++;
+#endif
             if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
         }
     }
 #ifdef MMX_N3_TIMING
-    if (lane == 0) g_n3_t[blockIdx.x * 20 + 1 + wave] = wall_clock64();
+    if (lane == 0) {
+        g_n3_t[blockIdx.x * 20 + 1 + wave] = wall_clock64();
+        g_n3_w[(blockIdx.x * 16 + wave) * 4] = (unsigned)t_wait;
+        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 1] = (unsigned)t_visit;
+        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 2] = (unsigned)t_stage;
+        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 3] = (unsigned)n_stage;
+        if (diag & 128) // (4096 waves x 8 contended atomics: a launch that counts is not one to time)
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_n3_c[k], (unsigned long long)cnt_w[k]);
+    }
 #endif
     acc_ev = (double)escale * wave_sum(acc_ev);
     acc_g = wave_sum(acc_g);
