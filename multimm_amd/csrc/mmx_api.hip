@@ -1241,6 +1241,11 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
 extern "C" int mmx_debug_n3_times(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_t), sizeof(unsigned long long) * 512 * 20);
 }
+extern "C" int mmx_debug_n3_trace(unsigned *events, unsigned *counts) {
+    int rc = (int)hipMemcpyFromSymbol(events, HIP_SYMBOL(mmx::g_n3_v), sizeof(unsigned) * mmx::kN3TraceBlocks * mmx::kN3TraceEvents * 8);
+    if (!rc) rc = (int)hipMemcpyFromSymbol(counts, HIP_SYMBOL(mmx::g_n3_vn), sizeof(unsigned) * mmx::kN3TraceBlocks);
+    return rc;
+}
 extern "C" int mmx_debug_n3_waits(unsigned *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_w), sizeof(unsigned) * 512 * 16 * 4);
 }

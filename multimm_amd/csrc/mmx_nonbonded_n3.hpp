@@ -56,7 +56,11 @@ namespace mmx {
 
 constexpr int kN3Waves = 16;        // waves per workgroup
 constexpr int kN3Threads = kN3Waves * 64;
-constexpr int kN3ItemClusters = 16; // i-clusters per work item (grabbed one at a time by the waves)
+#ifndef MMX_N3_ITEM
+#define MMX_N3_ITEM 24
+#endif
+constexpr int kN3ItemClusters = MMX_N3_ITEM; // i-clusters per work item (grabbed one at a time by the waves)
+constexpr int kN3DenseRun = MMX_N3_ITEM == 16 ? 16 : 30; // ... of a dense cell cut by itself: 14 n candidates must fit the window
 #ifndef MMX_N3_ISEG
 #define MMX_N3_ISEG 1
 #endif
@@ -66,8 +70,8 @@ constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two wind
 // A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
 // overflow; a larger one (overlapping beads) bypasses LDS with a global float atomic.
 constexpr float kN3Fix = 8192.f;
-constexpr float kN3FixLim = 134217728.f * 0.999f; // 2^27 units = 16384 kJ/mol/nm
-static_assert(kN3ItemClusters * 134217728.0 <= 2147483648.0, "a window slot must not overflow");
+constexpr float kN3FixLim = (float)(2147483648.0 / kN3ItemClusters) * 0.999f; // 2^26 units = 8192 kJ/mol/nm for items of 32 clusters
+static_assert(kN3ItemClusters * (double)kN3FixLim <= 2147483648.0, "a window slot must not overflow");
 
 struct N3Item { // 64 bytes
     int a, n;          // i-clusters [a, a + n)
@@ -101,7 +105,7 @@ constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gi
 // cells into its window); the sparse cells between two dense ones (or row ends) form a segment that is cut into runs
 // of kN3ItemClusters clusters from its start, wherever the cell boundaries fall.  Run starts follow from a segmented
 // prefix sum over the lanes, so nothing walks the row sequentially.
-constexpr int kN3Dense = 22; // 19 cells (a run across a cell boundary) of fewer clusters than this still fit one window
+constexpr int kN3Dense = MMX_N3_ITEM == 16 ? 22 : 17; // cells (a run across a cell boundary) of fewer clusters than this still fit one window
 
 struct N3Row {
     const int *cstart;
@@ -159,7 +163,7 @@ __device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart o
     C.p = sum - (C.dense ? 0 : C.n);
     C.runs = 0;
     if (valid && C.n > 0)
-        C.runs = C.dense ? (C.n + kN3ItemClusters - 1) / kN3ItemClusters
+        C.runs = C.dense ? (C.n + kN3DenseRun - 1) / kN3DenseRun
                          : (C.p + C.n + kN3ItemClusters - 1) / kN3ItemClusters - (C.p + kN3ItemClusters - 1) / kN3ItemClusters;
     carry_p = __shfl(sum, 63, 64);
     carry_dense = __shfl((int)C.dense, 63, 64) != 0;
@@ -281,6 +285,28 @@ __device__ unsigned long long g_n3_t[512 * 20];
 __device__ unsigned long long g_n3_c[16];
 // per wave: ticks (10 ns) spent waiting for a unit to become ready (flush help included), ticks inside i-cluster visits
 __device__ unsigned g_n3_w[512 * 16 * 4];
+// event trace of the first kN3TraceBlocks workgroups: {kind | wave << 8, unit, i-cluster of the unit, t0, t1 (10 ns ticks, low 32 bits), batches, -, -};
+// kind 0 visit, 1 wait at the entry of a unit, 2 staging (of unit), 3 last wave left the unit (flush job open), 4 window ready for unit
+constexpr int kN3TraceBlocks = 32, kN3TraceEvents = 1024;
+__device__ unsigned g_n3_v[kN3TraceBlocks * kN3TraceEvents * 8];
+__device__ unsigned g_n3_vn[kN3TraceBlocks];
+#define N3_TRACE(kind, unit, gi, t0, t1, nb)                                                          \
+    do {                                                                                               \
+        if (blockIdx.x < kN3TraceBlocks && lane == 0) {                                                \
+            const unsigned ix_ = atomicAdd(&g_n3_vn[blockIdx.x], 1u);                                  \
+            if (ix_ < (unsigned)kN3TraceEvents) {                                                      \
+                unsigned *e_ = g_n3_v + ((size_t)blockIdx.x * kN3TraceEvents + ix_) * 8;               \
+                e_[0] = (unsigned)(kind) | ((unsigned)wave << 8);                                      \
+                e_[1] = (unsigned)(unit);                                                              \
+                e_[2] = (unsigned)(gi);                                                                \
+                e_[3] = (unsigned)(t0);                                                                \
+                e_[4] = (unsigned)(t1);                                                                \
+                e_[5] = (unsigned)(nb);                                                                \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+#else
+#define N3_TRACE(kind, unit, gi, t0, t1, nb) do {} while (0)
 #endif
 // float -> int, rounded to nearest (ties up): ONE operation where __float2int_rn is v_rndne + v_cvt
 __device__ __forceinline__ int cvt_nearest(float v) {
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     if (threadIdx.x == 0) {
         g_n3_t[blockIdx.x * 20] = wall_clock64();
         g_n3_t[blockIdx.x * 20 + 18] = g_n3_t[blockIdx.x * 20 + 19] = 0ull;
+        if (blockIdx.x < kN3TraceBlocks) g_n3_vn[blockIdx.x] = 0u;
     }
     __syncthreads();
 #endif
@@ -421,7 +448,12 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         if (c == 0 && lane < 8) wx[cap * 8 + lane] = wy[cap * 8 + lane] = wz[cap * 8 + lane] = 0; // the dummy cluster
         wg_lds_release(); // the zeroed chunk, before the token that may declare the window ready
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == total) vready[p] = unit + 2;
+        if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == total) {
+            vready[p] = unit + 2;
+#ifdef MMX_N3_TIMING
+            N3_TRACE(4, unit + 2, 0, wall_clock64(), 0, 0);
+#endif
+        }
     };
     // Decides what unit `v` is (the next pass of the item of unit v - 1, or the next item of the queue), stages its
     // window -- candidate k of the concatenated runs -> cluster id, box -- and writes its descriptor.  One wave.
@@ -567,7 +599,11 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             break;
         }
 #ifdef MMX_N3_TIMING
-        t_wait += wall_clock64() - tw0;
+        {
+            const unsigned long long tw1 = wall_clock64();
+            t_wait += tw1 - tw0;
+            N3_TRACE(1, v, 0, tw0, tw1, 0);
+        }
 #endif
         wg_lds_acquire(); // what the stager / the flushers wrote before they raised `ready`
         __builtin_amdgcn_wave_barrier();
@@ -596,6 +632,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (gi >= D_n) break;
 #ifdef MMX_N3_TIMING
             const unsigned long long tv0 = wall_clock64();
+            const unsigned nb0 = cnt_w[3] + cnt_w[7];
 #endif
             const int icl = D_a + gi;
             const float4 lo_i = cl_box[2 * icl], hi_i = cl_box[2 * icl + 1];
@@ -820,7 +857,11 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 acc_g += (double)eg;
             }
 #ifdef MMX_N3_TIMING
-            t_visit += wall_clock64() - tv0;
+            {
+                const unsigned long long tv1 = wall_clock64();
+                t_visit += tv1 - tv0;
+                N3_TRACE(0, v, gi, tv0, tv1, cnt_w[3] + cnt_w[7] - nb0);
+            }
 #endif
         }
         // ---- out of i-clusters: leave the unit; the last wave to do so opens the flush and stages unit v + 2
@@ -844,13 +885,23 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (lane == 0) vepoch[p] = v; // the job is open
 #ifdef MMX_N3_TIMING
             const unsigned long long ts0 = wall_clock64();
+            N3_TRACE(3, v, 0, ts0, 0, 0);
 #endif
             stage_unit(v + 2);
 #ifdef MMX_N3_TIMING
-            t_stage += wall_clock64() - ts0;
-            n_stage++;
+            {
+                const unsigned long long ts1 = wall_clock64();
+                t_stage += ts1 - ts0;
+                n_stage++;
+                N3_TRACE(2, v + 2, 0, ts0, ts1, 0);
+            }
 #endif
-            if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) vready[p] = v + 2;
+            if (lane == 0 && atomicAdd(&ctl.fl_done[p], 1) == ctl.fl_total[p]) {
+                vready[p] = v + 2;
+#ifdef MMX_N3_TIMING
+                N3_TRACE(4, v + 2, 0, wall_clock64(), 0, 0);
+#endif
+            }
         }
     }
 #ifdef MMX_N3_TIMING
