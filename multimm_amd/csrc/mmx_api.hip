@@ -1068,8 +1068,8 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             break;
         case MMX_K_BACKBONE:
             if (!h->flags) break;
-            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
-                               h->st);
+            hipLaunchKernelGGL(k_backbone, dim3(std::min((h->n_own + 255) / 256, 2048)), dim3(256), 0, h->stream, h->P,
+                               h->pos4, h->flags, h->g, h->part, h->st, 1);
             bytes = 25.0 * h->n;
             break;
         case MMX_K_LOOPS:
@@ -1247,7 +1247,7 @@ extern "C" int mmx_debug_n3_trace(unsigned *events, unsigned *counts) {
     return rc;
 }
 extern "C" int mmx_debug_n3_waits(unsigned *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_w), sizeof(unsigned) * 512 * 16 * 4);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_w), sizeof(unsigned) * 512 * 16 * 8);
 }
 extern "C" int mmx_debug_n3_counters(unsigned long long *out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_c), sizeof(unsigned long long) * 16);

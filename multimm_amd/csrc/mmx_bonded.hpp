@@ -128,10 +128,12 @@ __device__ __forceinline__ void backbone_lane(const FFParams &P, const float4 *_
 // stands for owned bead t * kBBTile + l - 2 (lanes 0, 1: the hand-over beads, possibly of another rank or non-existent).
 __device__ __forceinline__ int bb_tiles(int n_own) { return (n_own + kBBTile - 1) / kBBTile; }
 
-// Algorithmic traffic: read 12 B position + 1 B flag, read-modify-write 12 B gradient = 25 B/bead (+12 RMW read).
+// Algorithmic traffic: read 12 B position + 1 B flag, write 12 B gradient = 25 B/bead (moved: 16 B pos4 + 1 + 12).
+// first: this launch is the first writer of the gradient (stores; no memset before it), else it adds to it.
 __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4 *__restrict__ pos4,
                                                   const uint8_t *__restrict__ flags, float *__restrict__ g,
-                                                  double *__restrict__ part, const MinState *__restrict__ st) {
+                                                  double *__restrict__ part, const MinState *__restrict__ st,
+                                                  const int first) {
     if (st->phase >= PH_DONE) return;
     __shared__ double s_w[4];
     double eb = 0.0, ea = 0.0;
@@ -142,9 +144,14 @@ __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4
         float gx = 0.f, gy = 0.f, gz = 0.f;
         backbone_lane(P, pos4, flags, i, i >= 0 && i < P.n && li < P.n_own, out, eb, ea, gx, gy, gz);
         if (out) {
-            g[3 * li] += gx;
-            g[3 * li + 1] += gy;
-            g[3 * li + 2] += gz;
+            if (!first) {
+                gx += g[3 * li];
+                gy += g[3 * li + 1];
+                gz += g[3 * li + 2];
+            }
+            g[3 * li] = gx;
+            g[3 * li + 1] = gy;
+            g[3 * li + 2] = gz;
         }
     }
     const double sb = block_sum<256>(eb, s_w);

@@ -768,6 +768,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
 void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan) {
     EventPair ep{};
     const int gb = grid_beads(h->n_own);
+    const int gs = gb; // blocks of the confinement pass (= of every term when the passes are fused)
     const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
     const bool loops_on = h->n_rows > 0 && h->lstart;
     bool on;
@@ -783,13 +784,16 @@ void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan) {
         prof_end(h, on, ep);
         A.nblk[P_BOND] = A.nblk[P_ANGLE] = A.nblk[P_LOOP] = gb;
     } else {
-        (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
+        // k_backbone is a dependent load chain per 62-bead tile: 8 waves per SIMD (2 048 blocks) instead of 4, and it STORES
+        // the gradient (first writer, no memset before it): 167 -> 130 -> ... us at 16 M beads.  (k_confine is slower on 2 048.)
+        const int gk = std::min((h->n_own + 255) / 256, 2048);
+        if (!bb_on) (void)hipMemsetAsync(h->g, 0, sizeof(float) * 4 * (size_t)h->n4, h->stream);
         if (bb_on) {
             on = prof_begin(h, MMX_K_BACKBONE, ep);
-            hipLaunchKernelGGL(k_backbone, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
-                               h->st);
+            hipLaunchKernelGGL(k_backbone, dim3(gk), dim3(256), 0, h->stream, h->P, h->pos4, h->flags, h->g, h->part,
+                               h->st, 1);
             prof_end(h, on, ep);
-            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gb;
+            A.nblk[P_BOND] = A.nblk[P_ANGLE] = gk;
         }
         if (h->n_rows > 0) {
             const int gl = std::min((h->n_rows + 255) / 256, 1024);
@@ -800,11 +804,11 @@ void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan) {
             A.nblk[P_LOOP] = gl;
         }
         on = prof_begin(h, MMX_K_CONFINE, ep);
-        hipLaunchKernelGGL(k_confine, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part, h->st,
+        hipLaunchKernelGGL(k_confine, dim3(gs), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part, h->st,
                            h->Q.lam_form, h->Q.cf_form);
         prof_end(h, on, ep);
     }
-    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = gb;
+    A.nblk[P_CONT] = A.nblk[P_LAM] = A.nblk[P_CENT] = gs;
     if (h->P.use_chb && h->chrom_of) {
         const int gc = (h->n_own + 255) / 256; // one block per 256 owned beads (no grid-stride: LDS tiling)
         on = prof_begin(h, MMX_K_CHB, ep);

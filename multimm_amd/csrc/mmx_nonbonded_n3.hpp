@@ -284,7 +284,7 @@ __device__ unsigned long long g_n3_t[512 * 20];
 // batches of 64 beads x 8 i beads through the pair loop}; [8] launches
 __device__ unsigned long long g_n3_c[16];
 // per wave: ticks (10 ns) spent waiting for a unit to become ready (flush help included), ticks inside i-cluster visits
-__device__ unsigned g_n3_w[512 * 16 * 4];
+__device__ unsigned g_n3_w[512 * 16 * 8]; // + ticks of a visit's phases: set-up (loads, scalar i beads), sweeps, fold + i-side atomics
 // event trace of the first kN3TraceBlocks workgroups: {kind | wave << 8, unit, i-cluster of the unit, t0, t1 (10 ns ticks, low 32 bits), batches, -, -};
 // kind 0 visit, 1 wait at the entry of a unit, 2 staging (of unit), 3 last wave left the unit (flush job open), 4 window ready for unit
 constexpr int kN3TraceBlocks = 32, kN3TraceEvents = 1024;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
         if (lane == 0) vready[1] = 1;
     }
 #ifdef MMX_N3_TIMING
-    unsigned long long t_wait = 0ull, t_visit = 0ull, t_stage = 0ull, n_stage = 0ull;
+    unsigned long long t_wait = 0ull, t_visit = 0ull, t_stage = 0ull, n_stage = 0ull, t_setup = 0ull, t_sweep = 0ull, t_fold = 0ull;
 #endif
     for (int v = 0;; ++v) {
         const int p = v & 1;
@@ -665,6 +665,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 #ifdef MMX_N3_TIMING
             const int cg = i_own ? 0 : 4;
             cnt_w[cg]++;
+            t_setup += wall_clock64() - tv0;
 #endif
             // the i-cluster's own place in the window: candidates before it have lower cluster ids (i-clusters of this
             // item or of an earlier one: they take those pairs); it is itself a candidate (the self tile)
@@ -709,6 +710,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 #ifdef MMX_N3_TIMING
                     cnt_w[cg + 1] += nlist;
                     cnt_w[cg + 2] += nsteps;
+                    const unsigned long long tsw0 = wall_clock64();
 #endif
                     // ---- sweep: 8 j-clusters (64 j beads) per step; ids two steps ahead, positions one
                     int ln = list[sub];
@@ -841,8 +843,14 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                     }
                     nlist = 0;
                     wave_lds_sync();
+#ifdef MMX_N3_TIMING
+                    t_sweep += wall_clock64() - tsw0;
+#endif
                 }
             }
+#ifdef MMX_N3_TIMING
+            const unsigned long long tf0 = wall_clock64();
+#endif
             // ---- i side: fold over the wave; lane s (< 8) ends up owning bead s of the i-cluster.  Transposed butterfly: every
             // step halves the values a lane carries (lane bit k picks which half it keeps summing), so the 8 sums of a
             // component cost ~27 operations instead of 8 full wave reductions (56)
@@ -860,6 +868,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             {
                 const unsigned long long tv1 = wall_clock64();
                 t_visit += tv1 - tv0;
+                t_fold += tv1 - tf0;
                 N3_TRACE(0, v, gi, tv0, tv1, cnt_w[3] + cnt_w[7] - nb0);
             }
 #endif
@@ -907,10 +916,14 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 #ifdef MMX_N3_TIMING
     if (lane == 0) {
         g_n3_t[blockIdx.x * 20 + 1 + wave] = wall_clock64();
-        g_n3_w[(blockIdx.x * 16 + wave) * 4] = (unsigned)t_wait;
-        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 1] = (unsigned)t_visit;
-        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 2] = (unsigned)t_stage;
-        g_n3_w[(blockIdx.x * 16 + wave) * 4 + 3] = (unsigned)n_stage;
+        unsigned *gw_ = g_n3_w + (blockIdx.x * 16 + wave) * 8;
+        gw_[0] = (unsigned)t_wait;
+        gw_[1] = (unsigned)t_visit;
+        gw_[2] = (unsigned)t_stage;
+        gw_[3] = (unsigned)n_stage;
+        gw_[4] = (unsigned)t_setup;
+        gw_[5] = (unsigned)t_sweep;
+        gw_[6] = (unsigned)t_fold;
         if (diag & 128) // (4096 waves x 8 contended atomics: a launch that counts is not one to time)
             for (int k = 0; k < 8; ++k) atomicAdd(&g_n3_c[k], (unsigned long long)cnt_w[k]);
     }

@@ -34,16 +34,19 @@ def tail(e, label):
     wend = (b[:, 1:17] - t0) / 100.0
     bend = (b[:, 17] - t0) / 100.0
     units, later = int(b[:, 19].sum()), int(b[:, 18].sum())
-    wv = np.zeros(512 * 16 * 4, np.uint32)
+    wv = np.zeros(512 * 16 * 8, np.uint32)
     lib.mmx_debug_n3_waits(C.c_void_p(wv.ctypes.data))
-    wv = wv.reshape(512, 16, 4)[:256].astype(np.float64)
+    wv = wv.reshape(512, 16, 8)[:256].astype(np.float64)
+    ph = wv[:, :, 4:7].sum(axis=(0, 1)) / 100.0
     nst = wv[:, :, 3].sum()
     wv = wv[:, :, :3] / 100.0       # us
+    nvis = max(c[0] + c[4], 1)
     life = wend - ((b[:, 0] - t0) / 100.0)[:, None]
     work += (f"\n      per wave (us): lifetime {life.mean():.1f}, in i-cluster visits {wv[:, :, 1].mean():.1f} ({100 * wv[:, :, 1].mean() / life.mean():.0f} %), "
              f"waiting for a unit / helping its flush {wv[:, :, 0].mean():.1f} ({100 * wv[:, :, 0].mean() / life.mean():.0f} %), "
              f"staging {wv[:, :, 2].mean():.1f} ({nst:.0f} units staged after the first two, {wv[:, :, 2].sum() / max(nst, 1):.1f} us each), "
-             f"rest {life.mean() - wv.sum(axis=2).mean():.1f}; a visit takes {wv[:, :, 1].sum() / max(c[0] + c[4], 1):.1f} us")
+             f"rest {life.mean() - wv.sum(axis=2).mean():.1f}; a visit takes {wv[:, :, 1].sum() / nvis:.1f} us: "
+             f"set-up {ph[0] / nvis:.2f}, sweeps {ph[1] / nvis:.2f}, fold + i-side atomics {ph[2] / nvis:.2f}, culls and the rest {(wv[:, :, 1].sum() - ph.sum()) / nvis:.2f}")
     ncl, ncells, items = (int(e.get_option(k)) for k in ("n_clusters", "n_cells", "n3_items"))
     label += f" clusters {ncl} cells {ncells} items {items}"
     print(f"{label}: kernel {t:7.1f} us; units {units} (later passes {later}); wave exit mean {wend.mean():6.1f} max {wend.max():6.1f}; "
