@@ -56,11 +56,18 @@ namespace mmx {
 
 constexpr int kN3Waves = 16;        // waves per workgroup
 constexpr int kN3Threads = kN3Waves * 64;
-#ifndef MMX_N3_ITEM
-#define MMX_N3_ITEM 24
-#endif
-constexpr int kN3ItemClusters = MMX_N3_ITEM; // i-clusters per work item (grabbed one at a time by the waves)
-constexpr int kN3DenseRun = MMX_N3_ITEM == 16 ? 16 : 30; // ... of a dense cell cut by itself: 14 n candidates must fit the window
+// i-clusters per work item (grabbed one at a time by the waves).  Large systems take LONG items (fewer units, fewer waits
+// for a unit's slowest sweep: -4..-6 % of the kernel at 200 000 beads, -12 % at 1 M); below ~150 000 beads a workgroup
+// would be left with 2-4 units per launch and the short ones win by 1-4 % (scripts/ab_choice.sh).  The host picks.
+constexpr int kN3ItemClusters = 24, kN3ItemClustersSmall = 16, kN3LongItemsFrom = 150000;
+struct N3ItemShape {
+    int run;       // clusters per run of a sparse segment
+    int dense;     // a cell of at least this many clusters is cut by itself (fewer still fit one window across a cell boundary)
+    int dense_run; // ... into equal runs of at most this many clusters: 14 n candidates must fit the window
+};
+__host__ __device__ constexpr N3ItemShape n3_item_shape(bool long_items) {
+    return long_items ? N3ItemShape{kN3ItemClusters, 17, 30} : N3ItemShape{kN3ItemClustersSmall, 22, 16};
+}
 #ifndef MMX_N3_ISEG
 #define MMX_N3_ISEG 1
 #endif
@@ -70,8 +77,8 @@ constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two wind
 // A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
 // overflow; a larger one (overlapping beads) bypasses LDS with a global float atomic.
 constexpr float kN3Fix = 8192.f;
-constexpr float kN3FixLim = (float)(2147483648.0 / kN3ItemClusters) * 0.999f; // 2^26 units = 8192 kJ/mol/nm for items of 32 clusters
-static_assert(kN3ItemClusters * (double)kN3FixLim <= 2147483648.0, "a window slot must not overflow");
+constexpr float kN3FixLim = (float)(2147483648.0 / 32) * 0.999f; // 2^26 units = 8192 kJ/mol/nm: items of up to 32 clusters
+static_assert(n3_item_shape(true).dense_run <= 32 && kN3ItemClusters <= 32, "a window slot must not overflow");
 
 struct N3Item { // 64 bytes
     int a, n;          // i-clusters [a, a + n)
@@ -100,12 +107,11 @@ constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gi
                                       // the kernel takes the limit as an argument so that a test can inject the failure
 
 // ---- item builder ---------------------------------------------------------------------------------------------
-// One wave per row of the cell grid, lanes = cells of the row.  A cell of >= kN3Dense clusters is cut into equal runs
-// of at most kN3ItemClusters clusters by itself (a run that left a dense cell would drag the candidates of five more
+// One wave per row of the cell grid, lanes = cells of the row.  A cell of >= S.dense clusters is cut into equal runs
+// of at most S.dense_run clusters by itself (a run that left a dense cell would drag the candidates of five more
 // cells into its window); the sparse cells between two dense ones (or row ends) form a segment that is cut into runs
-// of kN3ItemClusters clusters from its start, wherever the cell boundaries fall.  Run starts follow from a segmented
+// of S.run clusters from its start, wherever the cell boundaries fall.  Run starts follow from a segmented
 // prefix sum over the lanes, so nothing walks the row sequentially.
-constexpr int kN3Dense = MMX_N3_ITEM == 16 ? 22 : 17; // cells (a run across a cell boundary) of fewer clusters than this still fit one window
 
 struct N3Row {
     const int *cstart;
@@ -137,13 +143,13 @@ struct N3Cell {
     int c0, n, p, runs;
     bool dense;
 };
-__device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart of the row */, int nx, int x, int lane,
-                                          int &carry_p, bool &carry_dense) {
+__device__ __forceinline__ N3Cell n3_cell(const N3ItemShape S, const int *__restrict__ cs /* cstart of the row */, int nx,
+                                          int x, int lane, int &carry_p, bool &carry_dense) {
     N3Cell C;
     const bool valid = x < nx;
     C.c0 = valid ? cs[x] : 0;
     C.n = valid ? cs[x + 1] - C.c0 : 0;
-    C.dense = C.n >= kN3Dense;
+    C.dense = C.n >= S.dense;
     bool prev_dense = __shfl_up((int)C.dense, 1, 64) != 0;
     if (lane == 0) prev_dense = carry_dense;
     // segmented inclusive sum of the sparse cells' cluster counts; a segment starts at a dense cell (which counts 0
@@ -163,8 +169,8 @@ __device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart o
     C.p = sum - (C.dense ? 0 : C.n);
     C.runs = 0;
     if (valid && C.n > 0)
-        C.runs = C.dense ? (C.n + kN3DenseRun - 1) / kN3DenseRun
-                         : (C.p + C.n + kN3ItemClusters - 1) / kN3ItemClusters - (C.p + kN3ItemClusters - 1) / kN3ItemClusters;
+        C.runs = C.dense ? (C.n + S.dense_run - 1) / S.dense_run
+                         : (C.p + C.n + S.run - 1) / S.run - (C.p + S.run - 1) / S.run;
     carry_p = __shfl(sum, 63, 64);
     carry_dense = __shfl((int)C.dense, 63, 64) != 0;
     return C;
@@ -173,8 +179,9 @@ __device__ __forceinline__ N3Cell n3_cell(const int *__restrict__ cs /* cstart o
 // `bid` of `nblk` workgroups of 256 threads
 __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
                                                const int *__restrict__ cstart, N3Item *__restrict__ items, int max_items,
-                                               MinState *__restrict__ st) {
+                                               MinState *__restrict__ st, const bool long_items) {
     const GridParams G = *grid;
+    const N3ItemShape S = n3_item_shape(long_items);
     const int nrows = G.ny * G.nz, nx = G.nx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = bid * 4 + wave; row < nrows; row += nblk * 4) {
@@ -194,7 +201,7 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         int total = 0, carry_p = 0;
         bool carry_dense = true; // the row start opens a segment
         for (int xc = 0; xc < nx; xc += 64) {
-            const N3Cell C = n3_cell(cs, nx, xc + lane, lane, carry_p, carry_dense);
+            const N3Cell C = n3_cell(S, cs, nx, xc + lane, lane, carry_p, carry_dense);
             int r = C.runs;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
@@ -212,7 +219,7 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         carry_dense = true;
         for (int xc = 0; xc < nx; xc += 64) {
             const int x = xc + lane;
-            const N3Cell C = n3_cell(cs, nx, x, lane, carry_p, carry_dense);
+            const N3Cell C = n3_cell(S, cs, nx, x, lane, carry_p, carry_dense);
             int inc = C.runs; // inclusive scan of the run counts: where my runs go
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -227,11 +234,11 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
                     a = C.c0 + (int)(((long long)C.n * j) / C.runs);
                     n = C.c0 + (int)(((long long)C.n * (j + 1)) / C.runs) - a;
                 } else {
-                    const int m0 = (C.p + kN3ItemClusters - 1) / kN3ItemClusters * kN3ItemClusters; // first run start at or after p
-                    a = C.c0 + (m0 - C.p) + j * kN3ItemClusters;
-                    n = min(kN3ItemClusters, c_hi - a);
+                    const int m0 = (C.p + S.run - 1) / S.run * S.run; // first run start at or after p
+                    a = C.c0 + (m0 - C.p) + j * S.run;
+                    n = min(S.run, c_hi - a);
                     while (a + n > cs[xb + 1]) { // the run goes on into the next cell, unless that one is dense
-                        if (cs[xb + 2] - cs[xb + 1] >= kN3Dense) {
+                        if (cs[xb + 2] - cs[xb + 1] >= S.dense) {
                             n = cs[xb + 1] - a;
                             break;
                         }
@@ -267,11 +274,11 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      const int *__restrict__ biglist,
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
                                                      MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
-                                                     int *__restrict__ sbead = nullptr) {
+                                                     int *__restrict__ sbead = nullptr, const int n3_long_items = 0) {
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
-        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st);
+        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st, n3_long_items != 0);
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
