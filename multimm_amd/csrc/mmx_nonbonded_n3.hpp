@@ -10,9 +10,9 @@
 // per work item needs a tenth of that, in 256-byte contiguous wave instructions.
 //
 // Work item (n3_items_block builds the list after every cell scan, inside the launch of the in-cell ordering) = a run of
-// up to 16 consecutive clusters of one ROW of
-// the cell grid (x is the fastest cell index, so a row is one contiguous stretch of the cell-sorted cluster list); the
-// run may span several cells when they are sparse.  Half shell by cells: the j candidates of the run are, in
+// up to 24 consecutive clusters (16 on systems below 150 000 beads; a dense cell by itself: equal runs of up to 30) of one
+// ROW of the cell grid (x is the fastest cell index, so a row is one contiguous stretch of the cell-sorted cluster list);
+// the run may span several cells when they are sparse.  Half shell by cells: the j candidates of the run are, in
 // increasing cluster order, (0) the clusters of its own row from the run's first cluster to the end of the cell after
 // its last one, (1) row y+1 and (2-4) the three rows of layer z+1, each from the cell before the run's first cell to
 // the cell after its last one: five contiguous stretches of the cluster list.  Their concatenation is the index
@@ -29,6 +29,12 @@
 // after next (queue pop, item descriptor, candidate boxes and ids) while the others compute; the flush is done, a chunk
 // at a time, by the waves that wait for that window.  No workgroup barrier in the steady state; every wait is a bounded
 // spin that raises an error (failed evaluation) instead of hanging.
+// Where a wave's time goes (gw_200k after 150 iterations, -DMMX_N3_TIMING build, scripts/dd_n3_tail.py and n3_trace.py):
+// 74 % inside i-cluster visits (14.5 us each: set-up 0.5, culls 1.2, sweeps 11.6, fold + i-side atomics 1.3), 15 %
+// waiting for its next unit -- a unit ends with its slowest visit (they range 5-48 us) and a wave may run only one unit
+// ahead --, 11 % unit hand-over, staging, prologue and epilogue.  With 16-cluster items the waits were 24 %: the item
+// length is what the measurement moved; staging ahead of the windows, splitting long visits between two waves and a
+// queue in weight order were built and did not pay (profiles/r03_experiments/README.md).
 //
 // The tail.  A wave sweeps ~6 i-clusters per launch at 200 000 beads, ~35 us each, so without care the last sweep leaves
 // most waves idle for a sixth of the kernel.  The items the queue hands out LAST are therefore handed out 2 or 4 times, as

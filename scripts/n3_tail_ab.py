@@ -9,8 +9,8 @@ from multimm_amd.engine import engine_for, K_NONBONDED
 name = sys.argv[1] if len(sys.argv) > 1 else "gw_200k"
 eng = engine_for(synthetic_system(name))
 done = 0
-cfgs = [(2, 1), (1, 1), (1, 2), (3, 1), (64, 0)]
-for upto in (0, 400, 2000):
+cfgs = [(2, 1), (4, 1), (6, 1), (2, 2), (1, 1), (3, 1), (64, 0)]
+for upto in (0, 60, 400, 2000):
     if upto > done:
         eng.set_option("nb_variant", 0)
         eng.minimize(tolerance=0.0, max_iters=upto - done); done = upto
