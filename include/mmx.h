@@ -227,6 +227,10 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "dd_freeze"         measurement only (scripts/dd_projection.py): 1 = a rank of a decomposed run issues no collective any
  *                     more -- ghost lists and the ghost positions last received stay, sums are not all-reduced -- so
  *                     that mmx_time_kernel can time ONE rank's kernels on exactly the beads it holds in the run   0
+ * "n3_long_items"     work items of the half-shell pair kernel: -1 = by size (24 clusters from 150 000 local beads,
+ *                     16 below), 0 / 1 = short / long forced (tests, A/B)                                        -1
+ * "n_clusters", "n_cells", "n3_items"  (get only) 8-bead clusters, grid cells and half-shell work items of the last
+ *                     cell build, as of the last poll
  * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
  *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE;
  *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a

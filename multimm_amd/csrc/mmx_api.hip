@@ -603,6 +603,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else if (k == "inject_fault") h->inject_fault = (int)value;
+    else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
@@ -639,6 +640,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_redecompositions") *value = (double)h->dd_redecompositions;
     else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
     else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
+    else if (k == "n3_long_items") *value = h->n3_long_items;
     else if (k == "n_clusters") *value = h->st_host ? h->st_host->n_clusters : 0;   // read-only: the last cell build
     else if (k == "n_cells") *value = h->st_host ? h->st_host->ncells : 0;
     else if (k == "n3_items") *value = h->st_host ? h->st_host->n3_items : 0;

@@ -202,6 +202,7 @@ struct mmx_handle_s {
     float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
     int fstride = 0;
     bool nb_lean = false;                        // the lean pair loop applies (default forms, one cutoff): refresh_params
+    int n3_long_items = -1;                      // work items of k_nb_n3: -1 by size (kN3LongItemsFrom), 0 short (16 clusters), 1 long (24)
     int n3_cap = 0;                              // LDS force window of k_nb_n3 in clusters (0: not usable on this device)
     N3Item *n3_items = nullptr;                  // its work items (k_n3_items, after every cell scan)
     int n3_max_items = 0, n_cus = 0;

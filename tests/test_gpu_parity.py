@@ -7,6 +7,8 @@ Tolerances (stated per north_star: "within a stated fp32 tolerance"):
 The absolute force floor covers fp32 round-off of bond lengths: k_bond * ulp(r) ~ 3e5 * 1e-8 nm.  (E_RTOL, E_ATOL, F_RTOL,
 F_ATOL below; round 1 stood at 2e-5 / 5e-3 while the pair kernels worked in scaled length units.)
 """
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -71,6 +73,36 @@ def test_all_terms_jittered(n, cutoff):
     if n == 20000 and cutoff == 0.0:
         pytest.skip("all-pairs oracle at 20k is minutes of CPU")
     _check(synthetic_system("gw_200k", n_beads=n, jitter=0.03, seed=3, **ALL_ON), cutoff, f"jitter n={n} rc={cutoff}")
+
+
+@pytest.mark.parametrize("long_items", [0, 1])
+def test_half_shell_work_item_lengths(long_items):
+    """The half-shell kernel's work items come in two lengths (runs of 16 clusters below 150 000 beads, of 24 -- dense
+    cells: 30 -- above; option n3_long_items forces either).  Both against the fp64 oracle where the other one is the
+    default, over the densities a run passes through: the lattice (216 beads per cell: dense cells cut by themselves,
+    windows in two passes), a jittered lattice, the state after 40 iterations, and a dilute gas (runs that span many cells)."""
+    from oracle.oracle import Oracle
+    cases = [("lattice", synthetic_system("gw_200k", n_beads=30000, **ALL_ON), E_RTOL_AT_CUTOFF, F_RTOL_AT_CUTOFF),
+             ("jitter", synthetic_system("gw_200k", n_beads=30000, jitter=0.03, seed=11, **ALL_ON), E_RTOL, F_RTOL)]
+    s40 = synthetic_system("gw_200k", n_beads=30000, **ALL_ON)
+    with engine_for(s40) as eng:
+        eng.minimize(tolerance=0.0, max_iters=40)
+        x = eng.get_positions()
+    cases.append(("after 40 iterations", dataclasses.replace(s40, positions=x.astype(np.float64)), E_RTOL, F_RTOL))
+    gas = synthetic_system("gw_200k", n_beads=30000, **ALL_ON)
+    rng = np.random.default_rng(5)
+    cases.append(("gas", dataclasses.replace(gas, positions=rng.uniform(-9.0, 9.0, size=(30000, 3))), E_RTOL, F_RTOL))
+    for label, s, e_rtol, f_rtol in cases:
+        et_ref, F_ref = Oracle(s).eval()
+        with engine_for(s) as eng:
+            eng.set_option("nb_variant", 4096)
+            eng.set_option("n3_long_items", long_items)
+            et, F = eng.compute()
+            assert eng.get_option("n3_launches") > 0 and eng.get_option("n3_items") > 0
+        assert np.all(np.abs(et - et_ref) <= e_rtol * np.abs(et_ref).sum() + E_ATOL), (label, et, et_ref)
+        ferr = np.abs(F - F_ref).max()
+        print(f"ACC items {'long' if long_items else 'short'}, {label}: max err / max|F| = {ferr / np.abs(F_ref).max():.2e}")
+        assert ferr <= f_rtol * np.abs(F_ref).max() + F_ATOL, (label, ferr)
 
 
 def test_region_preset_circle_start():
