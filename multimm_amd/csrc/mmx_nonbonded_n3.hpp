@@ -74,10 +74,6 @@ struct N3ItemShape {
 __host__ __device__ constexpr N3ItemShape n3_item_shape(bool long_items) {
     return long_items ? N3ItemShape{kN3ItemClusters, 17, 30} : N3ItemShape{kN3ItemClustersSmall, 22, 16};
 }
-#ifndef MMX_N3_ISEG
-#define MMX_N3_ISEG 1
-#endif
-constexpr int kN3ISeg = MMX_N3_ISEG; // the 8 i beads of a cluster are swept in this many groups; a group of padding is skipped
 constexpr int kN3List = 192;        // accepted j-clusters buffered per wave before a sweep (culled 128 candidates at a time)
 constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two windows in flight: 160 KB of LDS, all of it)
 // A window slot receives at most one batch sum per i-cluster of the item, so sums below 2^31 / 16 units cannot
@@ -650,7 +646,6 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             const int icl = D_a + gi;
             const float4 lo_i = cl_box[2 * icl], hi_i = cl_box[2 * icl + 1];
             // decomposed runs: is this a cluster of owned beads or of ghosts (never both)
-            const int n_i = __builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w)) & 255; // real beads (slots 0 .. n_i - 1)
             const bool i_own = !DD || __builtin_amdgcn_readfirstlane(__float_as_int(hi_i.w) >> 8) != 0;
             if (DD && !i_own && (diag & 32)) continue; // timing diagnosis only: what the kernel costs without ghost i-clusters
             float4 pv = spos4[(size_t)icl * kCl + slot];
@@ -778,10 +773,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 continue;
                             }
 #pragma unroll
-                            for (int sg = 0; sg < kN3ISeg; ++sg) {
-                              if (sg > 0 && n_i <= sg * (kCl / kN3ISeg)) break; // (wave-uniform: the rest of the i-cluster is padding)
-#pragma unroll
-                            for (int s = sg * (kCl / kN3ISeg); s < (sg + 1) * (kCl / kN3ISeg); ++s) {
+                            for (int s = 0; s < kCl; ++s) {
                                 const float dx = xi[s] - q.x, dy = yi[s] - q.y, dz = zi[s] - q.z;
                                 const float r2t = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, tiny)));
                                 const float in = fma_sat(r2t, nbig, cut_all);
@@ -811,7 +803,6 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 fjx = fmaf(fs, dx, fjx);
                                 fjy = fmaf(fs, dy, fjy);
                                 fjz = fmaf(fs, dz, fjz);
-                            }
                             }
                             const bool self = (jslot >> 3) == own_lc;
                             const bool big = fmaxf(fmaxf(fabsf(fjx), fabsf(fjy)), fabsf(fjz)) >= fix_lim;
