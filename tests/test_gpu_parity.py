@@ -105,6 +105,26 @@ def test_half_shell_work_item_lengths(long_items):
         assert ferr <= f_rtol * np.abs(F_ref).max() + F_ATOL, (label, ferr)
 
 
+@pytest.mark.parametrize("iters", [0, 30])
+def test_half_shell_kernel_repeats_itself(iters):
+    """The half-shell kernel's unit pipeline is a protocol between 16 waves (windows handed over, flushed and restaged
+    without a workgroup barrier): a rare race would show as an occasional wrong force, not as a wrong one every time.  Forty
+    evaluations of one state with each work-item length against the full-shell kernel's forces (scripts/n3_repeat_check.py
+    is the long version; it caught a work-stealing experiment that every single-shot parity test had passed)."""
+    s = synthetic_system("gw_200k", n_beads=30000, **ALL_ON)
+    with engine_for(s) as eng:
+        if iters:
+            eng.minimize(tolerance=0.0, max_iters=iters)
+        eng.set_option("nb_variant", 8192)
+        _, F0 = eng.compute()
+        fmax = np.abs(F0).max()
+        eng.set_option("nb_variant", 4096)
+        for long_items in (0, 1):
+            eng.set_option("n3_long_items", long_items)
+            worst = max(np.abs(eng.compute()[1] - F0).max() for _ in range(40))
+            assert worst <= 2e-5 * fmax, (long_items, worst / fmax)
+
+
 def test_region_preset_circle_start():
     """BASELINE config 1: EV + bonds + angles + loops, circle start (config_specific_region.ini)."""
     for n in (500, 5000):
