@@ -125,6 +125,28 @@ def test_half_shell_kernel_repeats_itself(iters):
             assert worst <= 2e-5 * fmax, (long_items, worst / fmax)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7])
+def test_tiny_systems(n):
+    """Edge of the input range: a chain of one to seven beads, no loops (the reference builds its forces from whatever the
+    structure holds: `model.py:625-720` loops over empty lists).  Forces against the oracle with and without cutoff, and a
+    minimization that ends with finite positions.  (Energies to 2e-2 kJ/mol: the angle term near theta = pi is where fp32
+    `acos` loses digits -- the reason the kernel clamps its argument --, and three beads have nothing to average it out.)"""
+    from oracle.oracle import Oracle
+    base = synthetic_system("region_5k", n_beads=8, start="circle")
+    for cutoff in (0.0, 0.6):
+        s = dataclasses.replace(base, n_beads=n, positions=base.positions[:n].copy(), chr_ends=np.array([0, n], np.int32),
+                                labels=base.labels[:n].copy(), loop_m=np.zeros(0, np.int32), loop_n=np.zeros(0, np.int32),
+                                loop_r0=np.zeros(0)).with_ff(NB_CUTOFF=cutoff)
+        et_ref, F_ref = Oracle(s).eval()
+        with engine_for(s) as eng:
+            et, F = eng.compute()
+            st = eng.minimize(tolerance=10.0, max_iters=50)
+            x = eng.get_positions()
+        assert np.abs(et - et_ref).max() <= 2e-2 + 1e-5 * np.abs(et_ref).sum(), (n, cutoff, et, et_ref)
+        assert np.abs(F - F_ref).max() <= F_RTOL * max(np.abs(F_ref).max(), 1.0) + F_ATOL, (n, cutoff)
+        assert st.status in (0, 1) and np.isfinite(x).all() and x.shape == (n, 3)
+
+
 def test_region_preset_circle_start():
     """BASELINE config 1: EV + bonds + angles + loops, circle start (config_specific_region.ini)."""
     for n in (500, 5000):
