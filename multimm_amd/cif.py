@@ -37,9 +37,17 @@ def _chain_of(i: int, chr_ends: np.ndarray) -> int:
 
 
 def write_structure(path: str, positions_nm: np.ndarray, chr_ends) -> None:
-    """Whole-structure file (metadata/MultiMM_init.cif, model/MultiMM_minimized.cif): chain letter
-    per chromosome, chromosome-boundary beads as HETATM/ALB/CB (initial_structure_tools.py:299-309)."""
-    xyz = np.asarray(positions_nm, dtype=np.float64) * 10.0
+    """Whole-structure file from nm positions (model/MultiMM_minimized.cif): x10 in float64, then as below."""
+    write_structure_angstrom(path, np.asarray(positions_nm, dtype=np.float64) * 10.0, chr_ends)
+
+
+def write_structure_angstrom(path: str, xyz_angstrom: np.ndarray, chr_ends) -> None:
+    """Whole-structure file (metadata/MultiMM_init.cif): the numbers are written as they are handed over, ``%.3f`` --
+    ``build_init_mmcif`` formats what ``compute_init_struct`` returns, no unit conversion in between
+    (initial_structure_tools.py:292-358; a x0.1 x10 round trip flips ``%.3f`` ties).  Chain letter per chromosome,
+    chromosome-boundary beads as HETATM/ALB/CB (:299-309).  Byte-identical to the reference's output for the
+    deterministic curves: tests/test_reference_fixtures.py."""
+    xyz = np.asarray(xyz_angstrom, dtype=np.float64)
     ce = np.asarray(chr_ends, dtype=np.int64)
     n = len(xyz)
     ends = set(int(e) for e in ce)
@@ -67,8 +75,13 @@ def write_structure(path: str, positions_nm: np.ndarray, chr_ends) -> None:
 
 
 def write_chromosome(path: str, positions_nm: np.ndarray) -> None:
+    """Per-chromosome file from nm positions: ``10 * V`` in float64 as save_chromosomes does (model.py:899-905)."""
+    write_chromosome_angstrom(path, np.asarray(positions_nm, dtype=np.float64) * 10.0)
+
+
+def write_chromosome_angstrom(path: str, xyz_angstrom: np.ndarray) -> None:
     """Per-chromosome file (model/chromosomes/*.cif, initial_structure_tools.py:417-458)."""
-    xyz = np.asarray(positions_nm, dtype=np.float64) * 10.0
+    xyz = np.asarray(xyz_angstrom, dtype=np.float64)
     n = len(xyz)
     rows, conns = [], []
     for i in range(n):

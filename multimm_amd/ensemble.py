@@ -33,12 +33,14 @@ def archive_run(run_path: str) -> str:
 
 
 def run_ensemble(args: SimulationConfig | str | dict, n_ensemble: Optional[int] = None, rank: int = 0, world: int = 1,
-                 archive: bool = True, device: Optional[int] = None, concurrent: int = 1, **model_inputs) -> list:
+                 archive: bool = True, device: Optional[int] = None, concurrent: int = 1, observer=None,
+                 **model_inputs) -> list:
     """Runs replicas ``i = rank, rank + world, ...`` of ``n_ensemble`` (default ``args.N_ENSEMBLE``); returns
     ``[(i, run_path_or_archive, stats)]`` of the replicas this rank ran, in replica order.  ``model_inputs`` are
     passed to ``MultiMM`` (``ms, ns, ds, chr_ends, Cs``) when the tensors are given instead of files.
     ``concurrent`` > 1 keeps that many replicas in flight on this rank's GPU (threads; the library calls release
-    the GIL); every replica's result is the one it has when run alone (replicas share nothing)."""
+    the GIL); every replica's result is the one it has when run alone (replicas share nothing).
+    ``observer(i, stage, model)``: see ``MultiMM.run``."""
     base = args if isinstance(args, SimulationConfig) else load_config(args)
     n = int(n_ensemble if n_ensemble is not None else (base.N_ENSEMBLE or 1))
     name = base.OUT_PATH
@@ -52,7 +54,7 @@ def run_ensemble(args: SimulationConfig | str | dict, n_ensemble: Optional[int] 
         os.makedirs(run_path, exist_ok=True)
         md = MultiMM(cfg, **model_inputs)
         try:
-            stats = md.run()
+            stats = md.run(observer=None if observer is None else (lambda stage, m: observer(i, stage, m)))
         finally:
             if md.engine is not None:
                 md.engine.close()

@@ -127,7 +127,7 @@ def import_mns_from_bedpe(bedpe_file, n_beads, coords=None, chrom=None, threshol
     ms, ns, cs = ms[far], ns[far], cs[far]
     if len(cs) and not np.all(cs == cs[0]):
         w = 1.0 / cs ** (2.0 / 3.0)
-        ds = 0.1 + 0.1 * (w - w.min()) / (w.max() - w.min())
+        ds = 0.1 + 0.1 * ((w - w.min()) / (w.max() - w.min()))     # min_max_trans first (utils.py:396-397,520): bit-equal
     else:
         ds = np.ones(len(ms))
     nz = (ns - ms) != 0

@@ -66,9 +66,13 @@ def self_avoiding_random_walk(n: int, rng, step: float = 1.0, bead_radius: float
 
 def circle(n: int, z_stretch: float = 50.0, radius: float = 5.0) -> np.ndarray:
     """polymer_circle(n, 50, 5), initial_structure_tools.py:169-182, 268-269: one turn of a helix of radius 5 that
-    climbs z_stretch in total."""
-    th = 2.0 * np.pi * np.arange(n) / n
-    return np.stack([radius * np.cos(th), radius * np.sin(th), z_stretch * (np.arange(n) + 1) / n], axis=1)
+    climbs z_stretch in total.  The reference's order of operations is kept (angle in degrees, ``inc * i * pi / 180``
+    left to right; z accumulated step by step), so the float64 values are bit-equal
+    (tests/test_reference_fixtures.py)."""
+    inc = 360 / float(n)
+    ang = inc * np.arange(n) * np.pi / 180
+    z = np.cumsum(np.full(n, z_stretch / n))          # sequential additions, as the reference's ``z += z_stretch``
+    return np.stack([radius * np.cos(ang), radius * np.sin(ang), z], axis=1)
 
 
 def helix(n: int, radius: float = 1.0, pitch: float = 2.0) -> np.ndarray:

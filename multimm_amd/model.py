@@ -61,9 +61,9 @@ class MultiMM:
             common = dict(coords=coords, chrom=chrom, shuffle=bool(a.SHUFFLE_CHROMS), seed=int(a.SHUFFLING_SEED),
                           path=a.OUT_PATH)
             if a.COMPARTMENT_PATH and str(a.COMPARTMENT_PATH).lower().endswith(".bed"):
-                Cs, chr_ends, _ = import_bed(a.COMPARTMENT_PATH, n, flip_prob=float(a.COMPARTMENT_FLIP_PROB),
+                Cs, chr_ends, self.chrom_idxs = import_bed(a.COMPARTMENT_PATH, n, flip_prob=float(a.COMPARTMENT_FLIP_PROB),
                                              noise_strength=float(a.COMPARTMENT_NOISE_STD), **common)
-            ms, ns, ds, chr_ends, _ = import_mns_from_bedpe(a.LOOPS_PATH, n, down_prob=float(a.DOWNSAMPLING_PROB),
+            ms, ns, ds, chr_ends, self.chrom_idxs = import_mns_from_bedpe(a.LOOPS_PATH, n, down_prob=float(a.DOWNSAMPLING_PROB),
                                                              **common)
         if ms is None:
             # no CHROM = genome-wide layout (22 chromosome intervals), as the parsers produce for chrom=None
@@ -74,6 +74,8 @@ class MultiMM:
             chr_ends = syn.chr_ends if chr_ends is None else chr_ends
             Cs = syn.labels if Cs is None else Cs
         self.ms, self.ns, self.ds = np.asarray(ms), np.asarray(ns), np.asarray(ds)
+        if not hasattr(self, "chrom_idxs"):                 # which chromosome each interval is (model.py:107,123)
+            self.chrom_idxs = np.arange(max(len(chr_ends) - 1, 1) if chr_ends is not None else 1)
         self.chr_ends = np.asarray(chr_ends if chr_ends is not None else [0, n], dtype=np.int32)
         self.Cs = np.zeros(n, np.int8) if Cs is None else np.asarray(Cs, dtype=np.int8)
         # model.py:158-162: per-bead central-force weights by chromosome INTERVAL position (utils.py:137); a single
@@ -103,7 +105,7 @@ class MultiMM:
         if self.args.BUILD_INITIAL_STRUCTURE or not self.args.INITIAL_STRUCTURE_PATH:
             from .initial_structure import compute_init_struct
             pts_angstrom = compute_init_struct(n, self.args.INITIAL_STRUCTURE_TYPE, seed=int(self.args.SHUFFLING_SEED))
-            cif.write_structure(init_cif, pts_angstrom * 0.1, self.chr_ends)
+            cif.write_structure_angstrom(init_cif, pts_angstrom, self.chr_ends)   # the file's unit, no nm round trip
             positions = cif.read_positions(init_cif)      # %.3f Angstrom round trip, as the reference does
         else:
             positions = cif.read_positions(self.args.INITIAL_STRUCTURE_PATH)
@@ -158,8 +160,12 @@ class MultiMM:
         for i in range(len(self.chr_ends) - 1):
             seg = self.state_positions[self.chr_ends[i]:self.chr_ends[i + 1]]
             if len(seg):
+                # named after the chromosome the interval holds (model.py:904: chrs[self.chrom_idxs[i]]), which is not
+                # chr{i+1} once SHUFFLE_CHROMS has permuted them
+                k = int(self.chrom_idxs[i]) if i < len(self.chrom_idxs) else i
+                name = "chrX" if k == 22 else "chrY" if k == 23 else f"chr{k + 1}"
                 cif.write_chromosome(os.path.join(self.args.OUT_PATH, "model", "chromosomes",
-                                                  f"MultiMM_minimized_chr{i + 1}.cif"), seg)
+                                                  f"MultiMM_minimized_{name}.cif"), seg)
 
     # --- model.py:907-995 -----------------------------------------------------------------------------
     def run_md(self):
@@ -213,11 +219,17 @@ class MultiMM:
         logger.info("MD finished: %d steps in %.2f s (%.0f steps/s)", done, dt, done / max(dt, 1e-9))
 
     # --- model.py:1216-1248 ---------------------------------------------------------------------------
-    def run(self):
+    def run(self, observer=None):
+        """``observer(stage, self)``, when given, is called after the force field is installed ("forcefield") and after
+        the minimization ("minimized"): what the parity tests use to look at a replica from inside the ensemble loop."""
         self.set_radiuses()
         self.initialize_simulation()
         self.add_forcefield()
+        if observer is not None:
+            observer("forcefield", self)
         self.min_energy()
+        if observer is not None:
+            observer("minimized", self)
         if self.args.LOC_START is None:
             self.save_chromosomes()
         if self.args.SIM_RUN_MD:

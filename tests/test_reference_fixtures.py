@@ -1,0 +1,96 @@
+"""Reference-pinned, bit-exact: the ingest parsers, the mmCIF writers (a13 / f3) and the
+deterministic start curves (a2, the non-Hilbert part) against OUTPUTS OF THE REFERENCE ITSELF.
+
+tests/golden/ref_* were produced by scripts/make_reference_fixtures.py, which runs the reference's own
+`import_mns_from_bedpe`, `import_bed` (utils.py:425-547, 220-347), `build_init_mmcif`, `write_mmcif_chrom`,
+`compute_init_struct` (initial_structure_tools.py:292-358, 417-458, 256-289) in the build container; the inputs are the
+reference's own test fixture `tests/fixtures/ENCFF045MJY_simple.bedpe` (a data file) and a synthetic `.bed` written by
+that script.  Nothing here reads /root/reference.  The force / minimizer rows (a4-a12) are NOT pinned by this: their
+arithmetic lives in OpenMM, which the image lacks."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from multimm_amd import cif
+from multimm_amd.ingest import import_bed, import_mns_from_bedpe
+from multimm_amd.initial_structure import compute_init_struct
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "ref_manifest.json")))
+INGEST = np.load(os.path.join(GOLD, "ref_ingest.npz"))
+CURVES = np.load(os.path.join(GOLD, "ref_curves.npz"))
+BEDPE = os.path.join(GOLD, "ref_inputs", "ENCFF045MJY_simple.bedpe")
+BED = os.path.join(GOLD, "ref_inputs", "synthetic_subcompartments.bed")
+
+_RENAME = {"N_beads": "n_beads"}
+
+
+def _kwargs(kw):
+    return {_RENAME.get(k, k): v for k, v in kw.items()}
+
+
+def _ref(kind, case, name):
+    return INGEST[f"{kind}__{case}__{name}"]
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST["bedpe"]))
+def test_bedpe_parser_equals_the_reference(case, tmp_path):
+    kw = _kwargs(MANIFEST["bedpe"][case]["kwargs"])
+    n = kw.pop("n_beads")
+    ms, ns, ds, ends, idxs = import_mns_from_bedpe(BEDPE, n, path=str(tmp_path), **kw)
+    assert len(ms) == MANIFEST["bedpe"][case]["n_loops"]
+    assert np.array_equal(ms, _ref("bedpe", case, "ms"))
+    assert np.array_equal(ns, _ref("bedpe", case, "ns"))
+    assert np.array_equal(np.asarray(ds, np.float64), _ref("bedpe", case, "ds"))       # bit for bit, float64
+    assert np.array_equal(ends, _ref("bedpe", case, "chr_ends"))
+    assert np.array_equal(idxs, _ref("bedpe", case, "chrom_idxs"))
+    # the metadata files of utils.py:477,536-539
+    for f in ("chrom_lengths", "chrom_idxs", "ms", "ns", "ds"):
+        assert os.path.exists(tmp_path / "metadata" / (f + ".npy"))
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST["bed"]))
+def test_bed_parser_equals_the_reference(case, tmp_path):
+    kw = _kwargs(MANIFEST["bed"][case]["kwargs"])
+    n = kw.pop("n_beads")
+    cs, ends, idxs = import_bed(BED, n, path=str(tmp_path), **kw)
+    assert np.array_equal(cs, _ref("bed", case, "Cs").astype(np.int64))
+    assert np.array_equal(ends, _ref("bed", case, "chr_ends"))
+    assert np.array_equal(idxs, _ref("bed", case, "chrom_idxs"))
+    hist = {int(k): v for k, v in MANIFEST["bed"][case]["histogram"].items()}
+    assert {v: int((cs == v).sum()) for v in (-2, -1, 0, 1, 2)} == hist
+
+
+@pytest.mark.parametrize("entry", MANIFEST["cif"], ids=lambda e: f"{e['curve']}_{e['n']}")
+def test_start_curves_and_mmcif_writers_equal_the_reference(entry, tmp_path):
+    curve, n, ends = entry["curve"], entry["n"], entry["chrom_ends"]
+    pts = compute_init_struct(n, curve)
+    assert pts.dtype == np.float64 and np.array_equal(pts, CURVES[f"{curve}_{n}"])       # the formulas, bit for bit
+    out = tmp_path / "init.cif"
+    cif.write_structure_angstrom(str(out), pts, np.array(ends))
+    ref = open(os.path.join(GOLD, "ref_cif", entry["init"]), "rb").read()
+    assert out.read_bytes() == ref                                                         # build_init_mmcif, byte for byte
+    lo, hi = entry["chrom_slice"]
+    outc = tmp_path / "chrom.cif"
+    cif.write_chromosome_angstrom(str(outc), pts[lo:hi])
+    refc = open(os.path.join(GOLD, "ref_cif", entry["chrom"]), "rb").read()
+    assert outc.read_bytes() == refc                                                       # write_mmcif_chrom
+
+
+def test_multimm_writes_the_init_structure_in_the_files_unit(tmp_path):
+    """MultiMM.initialize_simulation hands the curve to the writer in the file's own unit: the x0.1 x10 round trip that
+    round 3 had flipped %.3f ties (helix, 257 beads, row 233: 465.812 in the reference, 465.813 here)."""
+    from multimm_amd.config import load_config
+    from multimm_amd.model import MultiMM
+    cfg = load_config({"PLATFORM": "MI355X", "N_BEADS": 257, "OUT_PATH": str(tmp_path), "CHROM": "chr1",
+                       "INITIAL_STRUCTURE_TYPE": "helix", "NB_CUTOFF": 0.6})
+    m = MultiMM(cfg, ms=np.array([3]), ns=np.array([40]), ds=np.array([0.1]), chr_ends=np.array([0, 257]),
+                Cs=np.zeros(257, np.int8))
+    m.set_radiuses()
+    m.initialize_simulation()
+    got = open(tmp_path / "metadata" / "MultiMM_init.cif", "rb").read()
+    ref = open(os.path.join(GOLD, "ref_cif", "init_helix_257.cif"), "rb").read()
+    assert got == ref
+    assert b" 465.812\n" in got
