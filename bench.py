@@ -187,6 +187,7 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
             stage = at("rccl communicator")
             uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128, device=tdev)
             eng.comm_init(uid)
+            eng.set_option("profile", 16)      # HIP events around the kernel slots AND the collectives of every 16th evaluation
             stage = at("warm-up")
             if args.warmup > 0:
                 eng.minimize(tolerance=0.0, max_iters=args.warmup)
@@ -211,6 +212,20 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
                 "list_rebuilds_host_synchronous": eng.get_option("dd_sync_rebuilds"),
                 "evaluations_voided_and_repeated": eng.get_option("dd_halts"),
                 "rebuild_every": eng.get_option("dd_rebuild_every"),
+                # spatial ownership: 62-bead segments re-assigned by recursive bisection while the structure deforms
+                "segment_reassignments": eng.get_option("dd_reassignments"),
+                "segment_reassignment_attempts": eng.get_option("dd_reassign_attempts"),
+                "segments_moved": eng.get_option("dd_segments_moved"),
+                # where an evaluation's time goes on rank 0 (HIP events on the library's stream, every 16th evaluation):
+                # each collective from the end of the work before it to its own end = transfer + waiting for the peers
+                "rank0_us_per_evaluation": {
+                    "needmap_allgather": eng.get_option("dd_us_needmap_allgather"),
+                    "halo_send_recv": eng.get_option("dd_us_halo_exchange"),
+                    "allreduce_59_doubles": eng.get_option("dd_us_allreduce"),
+                    "collective_samples": eng.get_option("dd_collective_samples"),
+                    "kernel_slots": st.as_dict()["kernel_us_mean"],
+                    "note": "cell_build contains the need-map all-gather and the halo exchange, reduce the all-reduce",
+                },
             })
         finally:
             eng.close()

@@ -106,18 +106,26 @@ const char *mmx_last_error(mmx_handle h);
 int mmx_abi_version(void);
 
 /* ---- multi-GPU (BASELINE config 5; no counterpart in the reference, which is single-device) ----
- * One process and one handle per GPU.  Rank r of `world` owns the contiguous bead range
- * [r*slice, min(N, (r+1)*slice)), slice = ceil(N/world): forces, energies and the L-BFGS state of those
- * beads live on its GPU.  Every setter still takes the arrays of the WHOLE system.  Per evaluation the
+ * One process and one handle per GPU.  The beads are cut into SEGMENTS of 62 consecutive beads; a rank owns a set of
+ * segments: forces, energies and the L-BFGS state of their beads live on its GPU, in ascending bead order (the "local
+ * order": what mmx_compute's forces_out and mmx_dd_owned_beads use).  At creation rank r owns the contiguous bead range
+ * [r*slice, min(N, (r+1)*slice)), slice = 62 * ceil(ceil(N/62) / world) -- the Hilbert start makes index ranges
+ * compact bricks.  While a minimization deforms the structure, mmx_minimize RE-ASSIGNS the segments to the ranks by
+ * recursive bisection of their centroids (every rank a compact region of space again; the L-BFGS vectors of a segment
+ * migrate with it, so the optimisation itself is unaffected; option "dd_spatial", default 1).  Ownership only changes
+ * inside mmx_minimize; ask mmx_dd_owned_beads after it.  Every setter still takes the arrays of the WHOLE system.
+ * Per evaluation the
  * ranks exchange ghost beads (what lies within the cutoff of a peer's owned beads, by the peers' need-maps; backbone
- * neighbours and loop partners across slice ends) with ncclSend/ncclRecv and all-reduce once: 59 doubles in the
+ * neighbours and loop partners across segment ends) with ncclSend/ncclRecv and all-reduce once: 59 doubles in the
  * minimizer (energies, the three Gram rows an accepted step would change, g.d, x.x, two flags), 16 in a plain
  * evaluation -- RCCL, issued on the handle's stream, no host round trip (csrc/mmx_dd.hpp).  Without a communicator a
  * multi-rank handle still evaluates its owned beads against the positions last set by the host (unit tests). */
-/* (MMX_ERR_BAD_ARG when some rank would own no bead: slices are ceil(N / world) beads, so world must not exceed
- * N / ceil(N / world) + 1 -- e.g. 9 beads cannot go on 8 ranks.) */
+/* (MMX_ERR_BAD_ARG when some rank would own no bead at creation: (world - 1) * slice must be below N.) */
 int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_id, mmx_handle *out);
+/* n_own: beads this handle owns now; own_lo: its first owned bead (the whole range while the ownership is the initial one). */
 int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world);
+/* bead_ids[n_own]: the owned beads in local order (ascending).  Single-domain handles: 0 .. N-1. */
+int mmx_dd_owned_beads(mmx_handle h, int32_t *bead_ids);
 /* rank 0: 128-byte ncclUniqueId to hand to every rank (e.g. by torch.distributed broadcast). */
 int mmx_comm_unique_id(uint8_t *id128);
 /* every rank: ncclCommInitRank on the handle's device with the handle's rank/world (collective). */
@@ -207,6 +215,20 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     cutoff + dd_skin and hold while no bead has moved more than dd_skin / 2 (checked on the
  *                     device; a violation voids the evaluation, which is repeated with fresh lists)          1
  * "dd_skin"           nm, K > 1 only; doubled (up to 0.8) for the rest of a call whenever a list went stale   0.2
+ * "dd_spatial"        1: mmx_minimize re-assigns the 62-bead segments to the ranks by recursive bisection of their
+ *                     centroids while the structure deforms (first attempt after "dd_reassign_first" evaluations, the
+ *                     interval doubling up to "dd_reassign_max"; an attempt that would move < 2 % of the segments
+ *                     changes nothing); 0: ownership stays the initial index ranges                         1
+ * "dd_reassign_first", "dd_reassign_max"   see "dd_spatial"                                                48, 768
+ * "dd_reassignments", "dd_reassign_attempts", "dd_segments_moved"   (get only) statistics of it
+ * "md_step"           (get only) MD steps integrated so far; after an MMX_ERR_STATE of mmx_md_step on a decomposed run (a ghost
+ *                     list went out of date: the steps since the last poll were taken back) it says where to go on from
+ * "dd_us_needmap_allgather", "dd_us_halo_exchange", "dd_us_allreduce", "dd_collective_samples"
+ *                     (get only; with "profile" > 0) mean HIP-event time in us of the three collectives of an evaluation
+ *                     -- need-map all-gather, grouped send/recv of the halo, the 59-double all-reduce -- over the
+ *                     sampled evaluations of mmx_minimize, each from the end of the work before it to its own end on
+ *                     this rank's stream (transfer + waiting for the peers); they lie INSIDE the "cell_build" /
+ *                     "reduce" brackets of mmx_stats.kernel_ns
  * "dd_ghosts", "dd_ghost_slots", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_sync_rebuilds",
  * "dd_halts", "dd_capacity_updates", "dd_skin_now"
  *                     (get only) statistics of the decomposed run: ghosts listed for this rank / slots of its

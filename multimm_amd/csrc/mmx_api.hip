@@ -27,8 +27,12 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         g_create_error = "rank/world out of range";
         return MMX_ERR_BAD_ARG;
     }
-    if ((long long)(world - 1) * ((n_beads + world - 1) / world) >= n_beads) { // slices of ceil(N / world): the last ranks would own nothing
-        g_create_error = "too many ranks for this system: with slices of ceil(n_beads / world) beads some rank would own no bead";
+    // decomposed runs: ownership in segments of kSeg beads, seg_per of them per rank
+    const int nseg_real = (n_beads + kSeg - 1) / kSeg;
+    const int seg_per = world > 1 ? (nseg_real + world - 1) / world : 0;
+    const int slice0 = world > 1 ? seg_per * kSeg : n_beads;
+    if ((long long)(world - 1) * slice0 >= n_beads) { // the last ranks would own nothing
+        g_create_error = "too many ranks for this system: with slices of 62 * ceil(ceil(n_beads / 62) / world) beads some rank would own no bead";
         return MMX_ERR_BAD_ARG;
     }
     int ndev = 0;
@@ -54,11 +58,15 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
     h->n = n_beads;
     h->rank = rank;
     h->world = world;
-    h->slice = (n_beads + world - 1) / world;       // equal slices (ncclAllGather), the last one is padded
+    h->slice = slice0;                              // equal slices (ncclAllGather), the last one is padded
+    h->seg_per = seg_per;
+    h->nseg = seg_per * world;
     h->n_all = h->slice * world;
     h->own_lo = rank * h->slice;
     h->n_own = std::max(0, std::min(n_beads, h->own_lo + h->slice) - h->own_lo);
-    h->n4 = (3 * h->n_own + 3) / 4;
+    // decomposed handles: vectors sized for a full slice (a re-assignment may hand this rank up to seg_per segments);
+    // what lies beyond the owned beads is zero and stays zero
+    h->n4 = (3 * (world > 1 ? h->slice : h->n_own) + 3) / 4;
     h->device = device_id;
     h->max_items = (h->n_all + kChunk - 1) / kChunk + std::min(h->n_all, h->maxcells) + 64;
     auto boot = [&]() -> int {
@@ -113,7 +121,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->cl_lo, (size_t)h->n_all * 2)); // interleaved {lo, hi} box records
         HIPCHK(h, dalloc(&h->cl_hi, (size_t)1));             // (kept as a kernel argument, unused)
         HIPCHK(h, dalloc(&h->grid, 2));
-        HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((h->n_own + 255) / 256 + 1)));
+        HIPCHK(h, dalloc(&h->bbox_part, (size_t)6 * ((std::max(h->n_own, world > 1 ? h->slice : 0) + 255) / 256 + 1)));
         HIPCHK(h, dalloc(&h->part, (size_t)P_NSLOTS * kPartStride));
         HIPCHK(h, dalloc(&h->rows, (size_t)MMX_NROWSUM * kPartStride));
         HIPCHK(h, dalloc(&h->st, 1));
@@ -146,10 +154,16 @@ int mmx_create_dd(int32_t n_beads, int32_t rank, int32_t world, int32_t device_i
 
 int mmx_dd_info(mmx_handle h, int32_t *own_lo, int32_t *n_own, int32_t *rank, int32_t *world) try {
     if (!h) return MMX_ERR_BAD_ARG;
-    if (own_lo) *own_lo = h->own_lo;
+    if (own_lo) *own_lo = h->n_own > 0 ? bead_of(h, 0) : h->own_lo;
     if (n_own) *n_own = h->n_own;
     if (rank) *rank = h->rank;
     if (world) *world = h->world;
+    return MMX_OK;
+} MMX_CATCH(h)
+
+int mmx_dd_owned_beads(mmx_handle h, int32_t *bead_ids) try {
+    if (!h || !bead_ids) return fail(h, MMX_ERR_BAD_ARG, "null argument");
+    for (int li = 0; li < h->n_own; ++li) bead_ids[li] = bead_of(h, li);
     return MMX_OK;
 } MMX_CATCH(h)
 
@@ -231,9 +245,12 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead})
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead,
+                    (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
+                    (void *)h->md_snap})
         if (p) (void)hipFree(p);
     if (h->dd_cnt_host) (void)hipHostFree(h->dd_cnt_host);
+    if (h->seg_cent_host) (void)hipHostFree(h->seg_cent_host);
     void *bufs[] = {h->x,     h->xp,     h->g,      h->gp,    h->d,      h->S,        h->Y,         h->pos4,
                     h->labels, h->flags,  h->cf_w,   h->cell_of, h->count, h->rank_in_cell, h->start, h->istart,
                     h->perm,  h->items,  h->grid,   h->bbox_part, h->part,   h->rows,     h->st,        h->row_bead,
@@ -262,8 +279,15 @@ int mmx_set_positions(mmx_handle h, const float *xyz) try {
     for (size_t i = 0; i < (size_t)3 * h->n; ++i)
         if (!std::isfinite(xyz[i])) return fail(h, MMX_ERR_BAD_ARG, "non-finite position");
     // the L-BFGS point holds the owned beads only; xyz is always the WHOLE system [N,3]
-    HIPCHK(h, hipMemcpyAsync(h->x, xyz + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own,
-                             hipMemcpyHostToDevice, h->stream));
+    std::vector<float> own_x; // (must outlive the asynchronous copy: synchronised below)
+    if (h->seg_owner.empty()) {
+        HIPCHK(h, hipMemcpyAsync(h->x, xyz + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own,
+                                 hipMemcpyHostToDevice, h->stream));
+    } else { // the owned segments, in local order
+        own_x.resize((size_t)3 * h->n_own);
+        for (int li = 0; li < h->n_own; ++li) std::memcpy(&own_x[(size_t)3 * li], xyz + (size_t)3 * bead_of(h, li), 3 * sizeof(float));
+        HIPCHK(h, hipMemcpyAsync(h->x, own_x.data(), sizeof(float) * own_x.size(), hipMemcpyHostToDevice, h->stream));
+    }
     if (h->xg) {
         HIPCHK(h, hipMemcpyAsync(h->xg, xyz, sizeof(float) * 3 * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
         h->pos4_dirty = true;
@@ -286,8 +310,23 @@ int mmx_get_positions(mmx_handle h, float *xyz) try {
     // the owned slice is taken from the L-BFGS point itself
     int rc = prepare(h);
     if (rc) return rc;
+    if (has_comm(h) && !h->seg_owner.empty()) {
+        // re-assigned ownership: every rank's x (local order) is all-gathered into the staging area and put back in
+        // bead order with the ownership tables (identical on every rank)
+        if ((rc = coll_allgather_vec(h, h->x))) return rc;
+        std::vector<float> all((size_t)3 * h->slice * h->world);
+        HIPCHK(h, hipMemcpyAsync(all.data(), h->mig, sizeof(float) * all.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+        for (int b = 0; b < h->n; ++b) {
+            const int sg = b / kSeg, q = h->seg_owner[sg];
+            const size_t src = (size_t)3 * ((size_t)q * h->slice + (size_t)h->seg_lidx[sg] * kSeg + (b - sg * kSeg));
+            std::memcpy(xyz + (size_t)3 * b, &all[src], 3 * sizeof(float));
+        }
+        return MMX_OK;
+    }
     if (has_comm(h)) { // a collective: every rank calls it (between calls a rank only holds its own beads and its halo)
-        hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+        hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->labels, h->pos4);
         coll_allgather_pos4(h);
         h->dd_lists_valid = false;
@@ -367,69 +406,11 @@ int mmx_set_loops(mmx_handle h, const int32_t *m, const int32_t *n, const float 
             return fail(h, MMX_ERR_BAD_ARG, "loop anchor out of range or degenerate");
         if (!std::isfinite(r0[l])) return fail(h, MMX_ERR_BAD_ARG, "non-finite loop rest length");
     }
-    // CSR over beads that carry a loop end; entries of a bead keep loop order (fixed summation order).
-    std::vector<int> deg((size_t)h->n, 0);
-    for (int l = 0; l < n_loops; ++l) {
-        deg[m[l]]++;
-        deg[n[l]]++;
-    }
-    std::vector<int> row_of((size_t)h->n, -1), row_bead, row_start;
-    int ne = 0;
-    for (int b = h->own_lo; b < h->own_lo + h->n_own; ++b) // rows of the beads this handle owns
-        if (deg[b]) {
-            row_of[b] = (int)row_bead.size();
-            row_bead.push_back(b);
-            row_start.push_back(ne);
-            ne += deg[b];
-        }
-    row_start.push_back(ne);
-    std::vector<int> fill(row_start.begin(), row_start.end()), partner((size_t)ne);
-    std::vector<float> er0((size_t)ne);
-    for (int l = 0; l < n_loops; ++l) {
-        if (row_of[m[l]] >= 0) {
-            const int q = fill[row_of[m[l]]]++;
-            partner[q] = n[l];
-            er0[q] = r0[l];
-        }
-        if (row_of[n[l]] >= 0) {
-            const int q = fill[row_of[n[l]]]++;
-            partner[q] = m[l];
-            er0[q] = r0[l];
-        }
-    }
-    // decomposed runs: the owner of a loop end always needs the other end (static part of the ghost lists)
-    h->dd_loop_mask.assign((size_t)std::max(h->n_own, 1), 0ull);
-    if (h->world > 1 && h->world <= kDDMaxWorld)
-        for (int l = 0; l < n_loops; ++l) {
-            const int rm = m[l] / h->slice, rn = n[l] / h->slice;
-            if (rm == rn) continue;
-            if (rm == h->rank) h->dd_loop_mask[m[l] - h->own_lo] |= 1ull << rn;
-            if (rn == h->rank) h->dd_loop_mask[n[l] - h->own_lo] |= 1ull << rm;
-        }
-    h->dd_static_dirty = true;
-    for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0, (void *)h->lstart})
-        if (p) (void)hipFree(p);
-    h->row_bead = h->row_start = h->partner = h->lstart = nullptr;
-    h->loop_r0 = nullptr;
-    h->n_rows = (int)row_bead.size();
-    h->n_loops = n_loops;
+    h->loop_m.assign(m, m + n_loops);
+    h->loop_n.assign(n, n + n_loops);
+    h->loop_r0v.assign(r0, r0 + n_loops);
     h->P.loop_k = k_loop;
-    if (h->n_rows > 0) {
-        HIPCHK(h, dalloc(&h->row_bead, row_bead.size()));
-        HIPCHK(h, dalloc(&h->row_start, row_start.size()));
-        HIPCHK(h, dalloc(&h->partner, partner.size()));
-        HIPCHK(h, dalloc(&h->loop_r0, er0.size()));
-        HIPCHK(h, hipMemcpy(h->row_bead, row_bead.data(), row_bead.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->row_start, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->loop_r0, er0.data(), er0.size() * sizeof(float), hipMemcpyHostToDevice));
-        // the same entries addressed per owned bead (rows are in bead order): offsets for the fused bonded kernel
-        std::vector<int> lstart((size_t)h->n_own + 1, 0);
-        for (int li = 0; li < h->n_own; ++li) lstart[(size_t)li + 1] = lstart[li] + deg[h->own_lo + li];
-        HIPCHK(h, dalloc(&h->lstart, lstart.size()));
-        HIPCHK(h, hipMemcpy(h->lstart, lstart.data(), lstart.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
-    return MMX_OK;
+    return rebuild_loops(h);
 } MMX_CATCH(h)
 
 int mmx_set_excluded_volume(mmx_handle h, float eps, float sigma, float r_small, float power, float cutoff_nm) try {
@@ -605,6 +586,9 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "inject_fault") h->inject_fault = (int)value;
     else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
+    else if (k == "dd_spatial") h->dd_spatial = value != 0.0;
+    else if (k == "dd_reassign_first") h->dd_reassign_first = std::max(1, (int)value);
+    else if (k == "dd_reassign_max") h->dd_reassign_max = std::max(1, (int)value);
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
     return MMX_OK;
 } MMX_CATCH(h)
@@ -641,8 +625,23 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_exchanges") *value = (double)h->dd_exchanges;
     else if (k == "dd_bytes_sent") *value = (double)h->dd_bytes_sent;
     else if (k == "n3_long_items") *value = h->n3_long_items;
+    else if (k == "dd_us_needmap_allgather" || k == "dd_us_halo_exchange" || k == "dd_us_allreduce") {
+        // mean HIP-event time (us) of that collective over the sampled evaluations since the handle was created; 0: no sample
+        const int w = k == "dd_us_needmap_allgather" ? kCollNeedmap : k == "dd_us_halo_exchange" ? kCollHalo : kCollAllreduce;
+        *value = h->coll_samples[w] ? h->coll_ns[w] / (double)h->coll_samples[w] / 1e3 : 0.0;
+    }
+    else if (k == "dd_collective_samples") *value = (double)h->coll_samples[kCollAllreduce];
+    else if (k == "md_step") *value = (double)h->md_step; // read-only: MD steps integrated (and not taken back) so far
+    else if (k == "dd_spatial") *value = h->dd_spatial;
+    else if (k == "dd_reassign_first") *value = h->dd_reassign_first;
+    else if (k == "dd_reassign_max") *value = h->dd_reassign_max;
+    else if (k == "dd_reassignments") *value = (double)h->dd_reassignments;
+    else if (k == "dd_reassign_attempts") *value = (double)h->dd_reassign_attempts;
+    else if (k == "dd_segments_moved") *value = (double)h->dd_segments_moved;
     else if (k == "n_clusters") *value = h->st_host ? h->st_host->n_clusters : 0;   // read-only: the last cell build
     else if (k == "n_cells") *value = h->st_host ? h->st_host->ncells : 0;
+    else if (k == "max_per_cell") *value = h->st_host ? h->st_host->max_per_cell : 0;
+    else if (k == "kernel_error") *value = h->st_host ? h->st_host->kernel_error : 0;
     else if (k == "n3_items") *value = h->st_host ? h->st_host->n3_items : 0;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
     else return fail(h, MMX_ERR_BAD_ARG, "unknown option " + k);
@@ -729,6 +728,12 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     GraphKey gkey{};
     long long eval_no = 1;
     int ramp = use_halo(h) ? 4 : h->poll_interval, quiet_polls = 0;
+    // decomposed runs: the segments are re-assigned to the ranks while the structure deforms (dd_reassign) -- attempted at
+    // polls, first after dd_reassign_first evaluations, then at doubling intervals; an attempt that changed the ownership
+    // is followed by a synchronous rebuild of the ghost lists
+    int reassign_interval = h->dd_reassign_first;
+    long long next_reassign = (h->dd_spatial && use_halo(h)) ? reassign_interval : std::numeric_limits<long long>::max();
+    bool sync_lists = false;
     while (h->st_host->phase != PH_DONE) {
         int batch = std::min(h->poll_interval, ramp);
         ramp = std::min(2 * ramp, std::max(h->poll_interval, 1));
@@ -747,7 +752,8 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
                 continue;
             }
             h->prof_eval = s0 ? 1 : (h->profile > 0 && h->profile_nb > 0 && eval_no % h->profile_nb == 0) ? 2 : 0;
-            enqueue_eval(h, PACK_MOVE, FOLD_MIN, dd_schedule(h));
+            enqueue_eval(h, PACK_MOVE, FOLD_MIN, sync_lists ? 1 : dd_schedule(h));
+            sync_lists = false;
             if (h->dd_rc != MMX_OK) return leave(h->dd_rc);
             ++b;
             ++eval_no;
@@ -787,6 +793,16 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             if (h->dd_rc != MMX_OK) return leave(h->dd_rc);
             if ((rc = pull_state(h))) return leave(rc);
         }
+        if (eval_no >= next_reassign && h->st_host->phase != PH_DONE) {
+            bool changed = false;
+            if ((rc = dd_reassign(h, changed))) return leave(rc);
+            reassign_interval = std::min(2 * reassign_interval, std::max(h->dd_reassign_max, 1));
+            next_reassign = eval_no + reassign_interval;
+            if (changed) {
+                sync_lists = true;
+                ramp = 4; // new lists: their messages are sized at short intervals again
+            }
+        }
         if ((int)h->ev_used.size() > 200) prof_collect(h, &local);
     }
     h->prof_eval = -1;
@@ -799,9 +815,11 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->xp, (float4 *)h->x);
         hipLaunchKernelGGL(k_copy4, dim3(g4), dim3(256), 0, h->stream, h->n4, (const float4 *)h->gp, (float4 *)h->g);
         if (h->world > 1) { // every rank reverted its own slice: what the others hold of it (pos4) is the rejected trial point
-            hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, h->own_lo,
+            hipLaunchKernelGGL(k_repack_own, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own, own_of(h),
                                h->x, h->labels, h->pos4);
-            if (has_comm(h)) coll_allgather_pos4(h);
+            if (has_comm(h) && h->seg_owner.empty()) coll_allgather_pos4(h); // (re-assigned ownership: only ever with the halo,
+                                                                             //  whose next call starts from a synchronous rebuild)
+            h->dd_lists_valid = false;
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
@@ -895,7 +913,7 @@ int mmx_md_set_velocities_to_temperature(mmx_handle h, double temperature_K, uin
     HIPCHK(h, hipSetDevice(h->device));
     const float sigma = (float)std::sqrt(kBoltz * temperature_K / h->md_mass);
     hipLaunchKernelGGL(k_md_init_velocities, dim3((h->n_own + 255) / 256), dim3(256), 0, h->stream, h->n_own,
-                       h->own_lo, sigma, (uint32_t)seed, (uint32_t)(seed >> 32), h->v);
+                       own_of(h), sigma, (uint32_t)seed, (uint32_t)(seed >> 32), h->v);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return MMX_OK;
@@ -905,7 +923,9 @@ int mmx_set_velocities(mmx_handle h, const float *vel) try {
     if (!h || !vel) return fail(h, MMX_ERR_BAD_ARG, "null argument");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpy(h->v, vel + (size_t)3 * h->own_lo, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyHostToDevice));
+    std::vector<float> own_v((size_t)3 * std::max(h->n_own, 1));
+    for (int li = 0; li < h->n_own; ++li) std::memcpy(&own_v[(size_t)3 * li], vel + (size_t)3 * bead_of(h, li), 3 * sizeof(float));
+    HIPCHK(h, hipMemcpy(h->v, own_v.data(), sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyHostToDevice));
     return MMX_OK;
 } MMX_CATCH(h)
 
@@ -914,7 +934,9 @@ int mmx_get_velocities(mmx_handle h, float *vel) try {
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(vel + (size_t)3 * h->own_lo, h->v, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
+    std::vector<float> own_v((size_t)3 * std::max(h->n_own, 1));
+    HIPCHK(h, hipMemcpy(own_v.data(), h->v, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToHost));
+    for (int li = 0; li < h->n_own; ++li) std::memcpy(vel + (size_t)3 * bead_of(h, li), &own_v[(size_t)3 * li], 3 * sizeof(float));
     return MMX_OK;
 } MMX_CATCH(h)
 
@@ -945,6 +967,33 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         h->md_forces_valid = true;
     }
     const int poll_every = 8 * std::max(1, h->poll_interval);
+    // Decomposed runs: a ghost list that goes out of date (a bead beyond half the skin, dd_every > 1) or outgrows its message
+    // is only seen at a poll, after positions and velocities have been integrated with forces that lacked ghosts -- on
+    // every rank, through the stale ghosts.  Those steps are VOID: x, v, xlo and the step counter are kept as of the last
+    // poll that found the lists in order and are put back before the error is returned, so the retry the message asks for
+    // repeats exactly those steps (the noise of a bead at a step is a function of (seed, bead, step) only).
+    const bool snap = use_halo(h);
+    const size_t nvf = (size_t)h->n4 * 4;
+    auto md_snapshot = [&]() -> int {
+        if (!h->md_snap) HIPCHK(h, dalloc(&h->md_snap, 3 * nvf));
+        HIPCHK(h, hipMemcpyAsync(h->md_snap, h->x, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->md_snap + nvf, h->v, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->md_snap + 2 * nvf, h->xlo, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        h->md_snap_step = h->md_step;
+        return MMX_OK;
+    };
+    auto md_rollback = [&]() -> int {
+        HIPCHK(h, hipMemcpyAsync(h->x, h->md_snap, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->v, h->md_snap + nvf, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->xlo, h->md_snap + 2 * nvf, sizeof(float) * nvf, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->md_step = h->md_snap_step;
+        h->md_forces_valid = false;
+        h->dd_lists_valid = false;
+        h->md_sync_next = true; // the step that failed is retried with lists and capacities made for its own positions
+        return MMX_OK;
+    };
+    if (snap && (rc = md_snapshot())) return rc;
     for (int s = 0; s < n_steps; ++s) {
         // pair energies are only needed where they are read: at the last step (report) and at the polls (NaN check)
         // aMD reads the potential energy of the current positions at every step
@@ -952,7 +1001,8 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         h->nb_skip_energy = !report;
         // decomposed runs: a call that has no ghost lists builds them synchronously at its first step; afterwards they are
         // rebuilt on the stream like the minimizer's (every dd_rebuild_every-th step; checked at the polls all the same)
-        const int redecomp = !use_halo(h) ? 0 : !h->dd_lists_valid ? 1 : dd_schedule(h);
+        const int redecomp = !use_halo(h) ? 0 : (!h->dd_lists_valid || h->md_sync_next) ? 1 : dd_schedule(h);
+        h->md_sync_next = false;
         enqueue_eval(h, PACK_MD, report ? FOLD_PLAIN : FOLD_NONE, redecomp);
         h->nb_skip_energy = false;
         h->md_step++;
@@ -964,17 +1014,20 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
                 return rc;
             }
             if (h->st_host->sums[kSumStale] > 0.5 || h->st_host->sums[kSumOverflow] > 0.5) { // all-reduced: every rank sees it
+                if (snap && (rc = md_rollback())) return rc;
                 h->md_forces_valid = false;
                 h->dd_lists_valid = false;
                 return fail(h, MMX_ERR_STATE, "a ghost list of the decomposed run went out of date during MD (a bead moved more "
                                               "than half of dd_skin between two rebuilds, or a list outgrew its message): "
-                                              "the steps since the last poll are void; call again (the lists are rebuilt)");
+                                              "the steps since the last poll are void and have been taken back; call again "
+                                              "for the steps not yet reported (the lists are rebuilt)");
             }
             const double f = h->st_host->ftrial;
             if (!(f - f == 0.0)) {
                 h->md_forces_valid = false;
                 return fail(h, MMX_ERR_NAN, "non-finite energy during MD (step too large?)");
             }
+            if (snap && (rc = md_snapshot())) return rc; // the lists were in order up to here
         }
     }
     // kinetic energy with the half-step shift OpenMM applies to leap-frog velocities (none for brownian)
@@ -990,10 +1043,12 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
         return rc;
     }
     if (h->st_host->sums[kSumStale] > 0.5 || h->st_host->sums[kSumOverflow] > 0.5) {
+        if (snap && (rc = md_rollback())) return rc;
         h->md_forces_valid = false;
         h->dd_lists_valid = false;
-        return fail(h, MMX_ERR_STATE, "a ghost list of the decomposed run went out of date during MD: the last steps are void; "
-                                      "call again (the lists are rebuilt)");
+        return fail(h, MMX_ERR_STATE, "a ghost list of the decomposed run went out of date during MD: the steps since the last "
+                                      "poll are void and have been taken back; call again for the steps not yet reported "
+                                      "(the lists are rebuilt)");
     }
     double ke = 0.0;
     HIPCHK(h, hipMemcpy(&ke, h->ke_out, sizeof(double), hipMemcpyDeviceToHost));

@@ -126,7 +126,13 @@ __device__ __forceinline__ void backbone_lane(const FFParams &P, const float4 *_
 
 // Tiles of a launch of `nwaves` waves over n_own owned beads: wave `gw` takes tiles gw, gw + nwaves, ...; lane l of tile t
 // stands for owned bead t * kBBTile + l - 2 (lanes 0, 1: the hand-over beads, possibly of another rank or non-existent).
+// A tile is one ownership SEGMENT (kSeg == kBBTile): its beads are consecutive global ids wherever the rank's other
+// segments lie, and the two beads before it are the global predecessors of its first bead (ghosts when not owned).
+static_assert(kBBTile == kSeg, "one backbone tile per ownership segment");
 __device__ __forceinline__ int bb_tiles(int n_own) { return (n_own + kBBTile - 1) / kBBTile; }
+__device__ __forceinline__ int bb_tile_bead(const FFParams &P, int t, int lane) { // global bead of lane `lane` of tile t
+    return (P.seg_own ? P.seg_own[t] * kBBTile : P.own_lo + t * kBBTile) + lane - 2;
+}
 
 // Algorithmic traffic: read 12 B position + 1 B flag, write 12 B gradient = 25 B/bead (moved: 16 B pos4 + 1 + 12).
 // first: this launch is the first writer of the gradient (stores; no memset before it), else it adds to it.
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void k_backbone(const FFParams P, const float4
     double eb = 0.0, ea = 0.0;
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (int t = gw; t < bb_tiles(P.n_own); t += nw) {
-        const int li = t * kBBTile + lane - 2, i = P.own_lo + li;
+        const int li = t * kBBTile + lane - 2, i = bb_tile_bead(P, t, lane);
         const bool out = lane >= 2 && li < P.n_own;
         float gx = 0.f, gy = 0.f, gz = 0.f;
         backbone_lane(P, pos4, flags, i, i >= 0 && i < P.n && li < P.n_own, out, eb, ea, gx, gy, gz);
@@ -179,9 +185,10 @@ __global__ __launch_bounds__(256) void k_loops(const FFParams P, int n_rows, con
         float gx = 0.f, gy = 0.f, gz = 0.f;
         for (int q = row_start[r]; q < row_start[r + 1]; ++q)
             e += 0.5 * (double)loop_grad(loop_form, pb, f3(pos4[partner[q]]), r0[q], P.loop_k, gx, gy, gz);
-        g[3 * (b - P.own_lo)] += gx;
-        g[3 * (b - P.own_lo) + 1] += gy;
-        g[3 * (b - P.own_lo) + 2] += gz;
+        const int lb = P.own().local(b); // (rows are built for owned beads only)
+        g[3 * lb] += gx;
+        g[3 * lb + 1] += gy;
+        g[3 * lb + 2] += gz;
     }
     const double s = block_sum<256>(e, s_w);
     if (threadIdx.x == 0) part[P_LOOP * kPartStride + blockIdx.x] = s;
@@ -270,9 +277,10 @@ __global__ __launch_bounds__(256) void k_confine(const FFParams P, const float4 
     const bool any = P.use_container | P.use_lamina | P.use_central;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < P.n_own; i += gridDim.x * 256) { // i: local index
         if (!any) break;
-        const float4 p = pos4[P.own_lo + i];
+        const int b = P.own().bead(i);
+        const float4 p = pos4[b];
         float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
-        confine_bead(P, p, P.use_central ? cf_w[P.own_lo + i] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
+        confine_bead(P, p, P.use_central ? cf_w[b] : 0.f, lam_form, cf_form, ec, el, ef, gx, gy, gz);
         g[3 * i] = gx;
         g[3 * i + 1] = gy;
         g[3 * i + 2] = gz;
@@ -312,7 +320,7 @@ __device__ __forceinline__ void bonded_fused_block(const FFParams &P, const floa
     const int lane = threadIdx.x & 63, gw = vb * 4 + (tv >> 6), nw = nvb * 4;
     for (int t = vb < nvb ? gw : bb_tiles(P.n_own); t < bb_tiles(P.n_own); t += nw) {
         const int li = t * kBBTile + lane - 2;
-        const int i = P.own_lo + li;
+        const int i = bb_tile_bead(P, t, lane);
         const bool out = lane >= 2 && li < P.n_own;
         float gx = 0.f, gy = 0.f, gz = 0.f; // first writer of the gradient: the pair kernels add to it afterwards
         if (bb) {

@@ -49,7 +49,7 @@ struct DirArgs {
 };
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
-__global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__restrict__ x, float *__restrict__ xp,
+__global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *__restrict__ x, float *__restrict__ xp,
                                               float *__restrict__ d, const int8_t *__restrict__ labels,
                                               float4 *__restrict__ pos4, float *__restrict__ bbox_part,
                                               const MinState *__restrict__ st,
@@ -125,11 +125,11 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, int own_lo, float *__re
             py = x[3 * i + 1];
             pz = x[3 * i + 2];
         }
-        const int bead = own_lo + i;
+        const int bead = own.bead(i);
         const int w = (bead << 3) | ((int)labels[bead] + 2);
         pos4[bead] = make_float4(px, py, pz, __int_as_float(w));
     }
-    if (COUNT) { // own_lo == 0 and n_own == n_all here: every bead is owned
+    if (COUNT) { // single-domain handles only: every bead is owned, bead == i
         const GridParams G = *grid;
         int c = 0;
         if (act) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_grid_init(const float *__restrict__ bbo
 // (a bead outside the box by more than one cell edge cannot be within the cutoff of an interior cell
 // two layers in).  Lanes of a wave that share a cell issue one atomicAdd (Hilbert-ordered beads: ~3
 // distinct cells per wave) and derive their slot in the cell from the returned base.
-__global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n_own,
+__global__ __launch_bounds__(256) void k_cell_count(int n_all, const Own own,
                                                     const float4 *__restrict__ pos4,
                                                     const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                     int *__restrict__ rank, int *__restrict__ count,
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_cell_count(int n_all, int own_lo, int n
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool todo = i < n_all;
     int c = 0;
-    const bool owned = (unsigned)(i - own_lo) < (unsigned)n_own;
+    const bool owned = own.owns(i);
     if (todo) {
         const float4 p = pos4[i];
         if (!owned) {
@@ -409,7 +409,7 @@ __device__ __forceinline__ unsigned hilbert12(unsigned x, unsigned y, unsigned z
     return (spread4(x) << 2) | (spread4(y) << 1) | spread4(z);
 }
 __device__ __forceinline__ unsigned long long order_key(const float4 p, const GridParams &G, int cx, int cy, int cz,
-                                                        int bead, int own_lo, int n_own) {
+                                                        int bead, const bool is_ghost) {
     const float fx = ((p.x - G.ox) * G.inv_h - (float)cx) * 16.f;
     const float fy = ((p.y - G.oy) * G.inv_h - (float)cy) * 16.f;
     const float fz = ((p.z - G.oz) * G.inv_h - (float)cz) * 16.f;
@@ -417,7 +417,7 @@ __device__ __forceinline__ unsigned long long order_key(const float4 p, const Gr
                    qz = (unsigned)min(max((int)fz, 0), 15);
     const unsigned m = hilbert12(qx, qy, qz);
     // owned beads first (multi-GPU: clusters are then all-owned, one mixed, all-ghost), then along the curve, then id
-    const unsigned long long ghost = (unsigned)(bead - own_lo) < (unsigned)n_own ? 0ull : 1ull;
+    const unsigned long long ghost = is_ghost ? 1ull : 0ull;
     return (ghost << 63) | ((unsigned long long)m << 32) | (unsigned)bead;
 }
 
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
                                                    const int *__restrict__ rank, const int *__restrict__ start,
                                                    int *__restrict__ perm, unsigned long long *__restrict__ okeys,
                                                    const float4 *__restrict__ pos4, const GridParams *__restrict__ grid,
-                                                   int own_lo, int n_own, const MinState *__restrict__ st) {
+                                                   const Own own, const MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_all) return;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
     const GridParams G = *grid;
     const int slot = start[c] + rank[i];
     perm[slot] = i;
-    okeys[slot] = order_key(pos4[i], G, c % G.nx, (c / G.nx) % G.ny, c / (G.nx * G.ny), i, own_lo, n_own);
+    okeys[slot] = order_key(pos4[i], G, c % G.nx, (c / G.nx) % G.ny, c / (G.nx * G.ny), i, !own.owns(i));
 }
 
 // Orders every cell's beads along a Hilbert curve of 16^3 sub-cells (ties by bead id: bitwise
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
 __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int cb, const int *__restrict__ perm,
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
-                                              int nthr, int own_lo, int n_own,
+                                              int nthr, const Own &own,
                                               const unsigned long long *keys = nullptr, int *__restrict__ sbead = nullptr) {
     const int o8 = ((no + 7) >> 3) << 3; // slots of the owned clusters
     const int ncl = cell_clusters(cnt, no);
@@ -468,7 +468,7 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
             const int b = keys ? (int)(unsigned)(keys[src] & 0xffffffffull) : perm[s + src];
             p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
-            nown = (unsigned)(b - own_lo) < (unsigned)n_own ? 1 : 0;
+            nown = own.owns(b) ? 1 : 0;
             bead = b;
         }
         spos4[(size_t)cb * 8 + e] = p;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  int *__restrict__ count, int *__restrict__ perm, int2 *__restrict__ items,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ pos4,
                                                  float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
-                                                 float4 *__restrict__ cl_hi, int own_lo, int n_own,
+                                                 float4 *__restrict__ cl_hi, const Own own,
                                                  const unsigned long long *__restrict__ okeys,
                                                  const int *__restrict__ biglist,
                                                  MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
@@ -623,7 +623,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own_lo, n_own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own, nullptr, sbead);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -648,7 +648,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, s_buf, sbead);
+            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -698,7 +698,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         }
         else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
         // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own_lo, n_own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead);
     }
 }
 
@@ -710,12 +710,12 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const int *__restrict__ cstart,
                                                     const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
-                                                    int own_lo, int n_own, const unsigned long long *__restrict__ okeys,
+                                                    const Own own, const unsigned long long *__restrict__ okeys,
                                                     const int *__restrict__ biglist,
                                                     MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own);
+                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own);
 }
 
 } // namespace mmx

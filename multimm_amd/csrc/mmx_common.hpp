@@ -36,11 +36,45 @@ struct GridParams {
     int nx, ny, nz, ncells;
 };
 
+// Ownership of a decomposed run.  The beads are cut into SEGMENTS of kSeg consecutive beads (one backbone
+// tile of k_backbone each, so the implicit bonds and angles stay inside a segment or reach two beads into its
+// neighbours); a rank owns a set of segments, its L-BFGS vectors hold them in ascending segment order: local index
+// li = (local segment) * kSeg + offset.  At the start a rank owns a contiguous run of segments (seg_own == nullptr:
+// beads [lo, lo + n)); mmx_minimize re-assigns the segments to the ranks by recursive bisection of their centroids
+// while the structure deforms (dd_reassign, mmx_engine.hpp), after which the two tables translate.
+constexpr int kSeg = 62;
+struct Own {
+    int lo, n;            // identity mapping: owned beads [lo, lo + n); with tables: n = owned beads, lo unused
+    int nseg;             // entries of seg_local (segments of the whole padded system)
+    const int *seg_own;   // [owned segments] global segment id per local segment (nullptr: identity)
+    const int *seg_local; // [nseg] local segment index of a global segment, -1: not owned
+    __device__ __forceinline__ int bead(int li) const { // global bead id of local index li
+        if (!seg_own) return lo + li;
+        const int s = li / kSeg;
+        return seg_own[s] * kSeg + (li - s * kSeg);
+    }
+    __device__ __forceinline__ int local(int b) const { // local index of global bead b, -1: not owned (or no bead: b < 0)
+        if (!seg_local) {
+            const int l = b - lo;
+            return (unsigned)l < (unsigned)n ? l : -1;
+        }
+        const unsigned s = (unsigned)b / (unsigned)kSeg;
+        if (s >= (unsigned)nseg) return -1;
+        const int ls = seg_local[s];
+        const int l = ls * kSeg + (b - (int)s * kSeg);
+        return ls >= 0 && l < n ? l : -1;
+    }
+    __device__ __forceinline__ bool owns(int b) const { return local(b) >= 0; }
+};
+
 // Force-field constants, passed by value as kernel arguments.
 struct FFParams {
     int n;                 // beads of the whole system
     int n_all;             // entries of pos4 (n padded to world * slice in a multi-GPU run)
-    int own_lo, n_own;     // this handle owns beads [own_lo, own_lo + n_own): forces / L-BFGS state are local
+    int own_lo, n_own;     // this handle owns n_own beads: forces / L-BFGS state are local (which ones: own())
+    int nseg;              // decomposed runs after a re-assignment: the ownership tables (see Own), else nullptr
+    const int *seg_own, *seg_local;
+    __device__ __forceinline__ Own own() const { return Own{own_lo, n_own, nseg, seg_own, seg_local}; }
     int use_ev, ev_pmode; // pmode: 6 / 3 integer fast paths, 0 generic pow
     float ev_eps, ev_sigma, ev_rs, ev_power, ev_rc2; // rc2 = +inf when NoCutoff
     int use_gauss;

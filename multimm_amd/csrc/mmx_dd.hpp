@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_dd_dilate(const unsigned long long *__r
 // partner) or its coarse cell is set in q's need-map.  Lanes of a wave that go to the same rank share one atomic; the
 // order inside a list is arbitrary (the receiver's cell build sorts ghosts by position and id).  A list that would
 // outgrow its message raises st->dd_overflow and stops growing (the evaluation will be repeated).
-__global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, int rank, int world,
+__global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, const Own own, int rank, int world,
                                                         const float *__restrict__ x, const DDGrid *__restrict__ grid,
                                                         const unsigned long long *__restrict__ maps /* [world][kDDPayload] */,
                                                         const unsigned long long *__restrict__ static_mask,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, int own_lo, i
             if (lane == leader) st->dd_overflow = 1;
             continue;
         }
-        if (need) send_ids[(size_t)q * slice + base + __popcll(m & ((1ull << lane) - 1ull))] = own_lo + i;
+        if (need) send_ids[(size_t)q * slice + base + __popcll(m & ((1ull << lane) - 1ull))] = own.bead(i);
     }
 }
 
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_dd_displacement(int n_own, const float 
 
 // Cell id + slot of the owned beads and of the listed ghosts (the decomposed twin of k_cell_count: nothing outside
 // the halo is looked at).  Ghosts outside the grid of this build get cell -1.  Whole waves must call (cell_rank).
-__global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, int n_ghost, const int *__restrict__ ghost_ids,
+__global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, const Own own, int n_ghost, const int *__restrict__ ghost_ids,
                                                        const float4 *__restrict__ pos4,
                                                        const GridParams *__restrict__ grid, int *__restrict__ cell_of,
                                                        int *__restrict__ rank, int *__restrict__ count,
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, in
     int bead = 0, c = 0;
     if (todo) {
         const bool owned = t < n_own;
-        bead = owned ? own_lo + t : ghost_ids[t - n_own];
+        bead = owned ? own.bead(t) : ghost_ids[t - n_own];
         todo = bead >= 0; // padding of a message
     }
     if (todo) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_cell_count_dd(int n_own, int own_lo, in
 }
 
 // Bead ids and sort keys into the cells' slices, for the owned beads and the listed ghosts (twin of k_cell_fill).
-__global__ __launch_bounds__(256) void k_cell_fill_dd(int n_own, int own_lo, int n_ghost, const int *__restrict__ ghost_ids,
+__global__ __launch_bounds__(256) void k_cell_fill_dd(int n_own, const Own own, int n_ghost, const int *__restrict__ ghost_ids,
                                                       const int *__restrict__ cell_of, const int *__restrict__ rank,
                                                       const int *__restrict__ start, int *__restrict__ perm,
                                                       unsigned long long *__restrict__ okeys,
@@ -292,14 +292,14 @@ __global__ __launch_bounds__(256) void k_cell_fill_dd(int n_own, int own_lo, int
     if (st->phase >= PH_DONE) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_own + n_ghost) return;
-    const int i = t < n_own ? own_lo + t : ghost_ids[t - n_own];
+    const int i = t < n_own ? own.bead(t) : ghost_ids[t - n_own];
     if (i < 0) return;
     const int c = cell_of[i];
     if (c < 0) return;
     const GridParams G = *grid;
     const int slot = start[c] + rank[i];
     perm[slot] = i;
-    okeys[slot] = order_key(pos4[i], G, c % G.nx, (c / G.nx) % G.ny, c / (G.nx * G.ny), i, own_lo, n_own);
+    okeys[slot] = order_key(pos4[i], G, c % G.nx, (c / G.nx) % G.ny, c / (G.nx * G.ny), i, t >= n_own);
 }
 
 } // namespace mmx

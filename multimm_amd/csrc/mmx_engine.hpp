@@ -24,6 +24,10 @@ template <class T>
 hipError_t dalloc(T **p, size_t count) {
     hipError_t e = hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T));
     if (e == hipSuccess) e = hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    // hipMemset on device memory is enqueued on the NULL stream and may return before it has run; the handle's stream is
+    // non-blocking (it does not wait for the null stream), so a buffer allocated in the middle of a call -- the migration
+    // staging area of dd_reassign -- could be zeroed AFTER the first copy into it (seen: 12 MB at 400 000 beads)
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
 }
 
@@ -59,6 +63,9 @@ void refresh_params(mmx_handle_s *h) {
     P.n_all = h->n_all;
     P.own_lo = h->own_lo;
     P.n_own = h->n_own;
+    P.nseg = h->nseg;
+    P.seg_own = h->d_seg_own;     // nullptr while the ownership is the initial contiguous one
+    P.seg_local = h->d_seg_local;
     const float inf = std::numeric_limits<float>::infinity();
     P.ev_rc2 = (P.use_ev && h->ev_cut > 0.f) ? h->ev_cut * h->ev_cut : inf;
     P.g_rc2 = (P.use_gauss && h->g_cut > 0.f) ? h->g_cut * h->g_cut : inf;
@@ -147,6 +154,30 @@ bool use_n3(const mmx_handle_s *h) {
 
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
 
+// ---- ownership (decomposed runs: segments of kSeg beads, see Own in mmx_common.hpp) ----------------------------
+Own own_of(const mmx_handle_s *h) { return Own{h->own_lo, h->n_own, h->nseg, h->d_seg_own, h->d_seg_local}; }
+// rank that owns global bead b
+int owner_of(const mmx_handle_s *h, int b) {
+    if (h->world == 1) return 0;
+    return h->seg_owner.empty() ? b / h->slice : h->seg_owner[(size_t)(b / kSeg)];
+}
+// local index of global bead b on this handle, -1: not owned
+int local_of(const mmx_handle_s *h, int b) {
+    if (h->seg_owner.empty()) {
+        const int l = b - h->own_lo;
+        return l >= 0 && l < h->n_own ? l : -1;
+    }
+    const int s = b / kSeg;
+    if (b < 0 || s >= (int)h->seg_owner.size() || h->seg_owner[s] != h->rank) return -1;
+    const int l = h->seg_lidx[s] * kSeg + (b - s * kSeg);
+    return l < h->n_own ? l : -1;
+}
+// global bead of local index li
+int bead_of(const mmx_handle_s *h, int li) {
+    if (h->seg_owner.empty()) return h->own_lo + li;
+    return h->my_segs[(size_t)(li / kSeg)] * kSeg + li % kSeg;
+}
+
 // ---- profiling helpers ----------------------------------------------------------------------
 bool prof_begin(mmx_handle_s *h, int slot, EventPair &ep) {
     h->launches[slot]++;
@@ -167,10 +198,25 @@ void prof_end(mmx_handle_s *h, bool on, EventPair &ep) {
     (void)hipEventRecord(ep.b, h->stream);
     h->ev_used.push_back(ep);
 }
+// Collectives of a decomposed run, timed in the sampled evaluations of a minimization (slot = kCollBase + which)
+enum { kCollBase = 64, kCollNeedmap = 0, kCollHalo = 1, kCollAllreduce = 2, kCollOther = 3 };
+bool coll_prof_begin(mmx_handle_s *h, int which, EventPair &ep) {
+    if (h->profile <= 0 || h->capturing || h->prof_eval != 1 || h->ev_pool.empty()) return false;
+    ep = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    ep.slot = kCollBase + which;
+    (void)hipEventRecord(ep.a, h->stream);
+    return true;
+}
 void prof_collect(mmx_handle_s *h, mmx_stats *out) {
     for (auto &ep : h->ev_used) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess && out) {
+        if (ep.slot >= kCollBase) {
+            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+                h->coll_ns[ep.slot - kCollBase] += (double)ms * 1e6;
+                h->coll_samples[ep.slot - kCollBase] += 1;
+            }
+        } else if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess && out) {
             out->kernel_ns[ep.slot] += (double)ms * 1e6;
             out->kernel_samples[ep.slot] += 1;
         }
@@ -250,7 +296,7 @@ void launch_nb_finish(mmx_handle_s *h) {
     const int cl = h->last_clusters > 0 ? h->last_clusters : h->n_all / 8 + 4096;
     const int gu = std::max(64, std::min((cl * 8 + 255) / 256, 2048));
     hipLaunchKernelGGL(k_nb_n3_unsort, dim3(gu), dim3(256), 0, h->stream, h->sbead, h->fsort, h->fstride, h->g, h->st,
-                       h->own_lo, h->n_own);
+                       own_of(h));
 }
 
 template <int PMODE>
@@ -350,11 +396,11 @@ __global__ __launch_bounds__(256) void k_fill_pos4_all(int n, int n_all, const f
 }
 
 // pos4 of the owned beads from x, whatever the minimizer's phase (after a reverted line search: the state is DONE)
-__global__ __launch_bounds__(256) void k_repack_own(int n_own, int own_lo, const float *__restrict__ x,
+__global__ __launch_bounds__(256) void k_repack_own(int n_own, const Own own, const float *__restrict__ x,
                                                     const int8_t *__restrict__ labels, float4 *__restrict__ pos4) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_own) return;
-    const int bead = own_lo + i;
+    const int bead = own.bead(i);
     pos4[bead] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], __int_as_float((bead << 3) | ((int)labels[bead] + 2)));
 }
 
@@ -494,7 +540,7 @@ int dd_alloc(mmx_handle_s *h) {
     HIPCHK(h, dalloc(&h->dd_grid, (size_t)1));
     HIPCHK(h, dalloc(&h->dd_occ, (size_t)kDDWords));
     HIPCHK(h, dalloc(&h->dd_maps, W * kDDPayload));
-    HIPCHK(h, dalloc(&h->dd_static, (size_t)std::max(h->n_own, 1)));
+    HIPCHK(h, dalloc(&h->dd_static, (size_t)std::max(h->slice, 1)));
     HIPCHK(h, dalloc(&h->dd_send_ids, W * S));
     HIPCHK(h, dalloc(&h->dd_send_cnt, W));
     HIPCHK(h, dalloc(&h->dd_cntmat, W * W));
@@ -503,7 +549,7 @@ int dd_alloc(mmx_handle_s *h) {
     HIPCHK(h, dalloc(&h->dd_ghost_ids, W * S));
     HIPCHK(h, dalloc(&h->dd_sendbuf, W * S));
     HIPCHK(h, dalloc(&h->dd_recvbuf, W * S));
-    HIPCHK(h, dalloc(&h->dd_xref, (size_t)3 * std::max(h->n_own, 1)));
+    HIPCHK(h, dalloc(&h->dd_xref, (size_t)3 * std::max(h->slice, 1)));
     return MMX_OK;
 }
 
@@ -512,12 +558,12 @@ int dd_alloc(mmx_handle_s *h) {
 int dd_upload_static(mmx_handle_s *h) {
     std::vector<unsigned long long> m((size_t)std::max(h->n_own, 1), 0ull);
     for (int i = 0; i < h->n_own; ++i) {
-        const int b = h->own_lo + i;
+        const int b = bead_of(h, i);
         unsigned long long bits = (size_t)i < h->dd_loop_mask.size() ? h->dd_loop_mask[i] : 0ull;
         for (int d = -2; d <= 2; ++d) {
             const int o = b + d;
             if (o < 0 || o >= h->n) continue;
-            const int r = o / h->slice;
+            const int r = owner_of(h, o);
             if (r != h->rank) bits |= 1ull << r;
         }
         m[i] = bits;
@@ -588,13 +634,18 @@ int dd_rebuild(mmx_handle_s *h, bool sync) {
     hipLaunchKernelGGL(k_dd_occupancy, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
     hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
                        h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
-    coll_allgather_small(h, h->dd_maps, sizeof(unsigned long long) * kDDPayload,
-                         [](mmx_handle_s *o) { return (void *)o->dd_maps; });
+    {
+        EventPair cep{};
+        const bool con = coll_prof_begin(h, kCollNeedmap, cep);
+        coll_allgather_small(h, h->dd_maps, sizeof(unsigned long long) * kDDPayload,
+                             [](mmx_handle_s *o) { return (void *)o->dd_maps; });
+        prof_end(h, con, cep);
+    }
     HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
     DDCaps caps = h->dd_scap;
     if (sync)
         for (int q = 0; q < h->world; ++q) caps.cap[q] = h->slice;
-    hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->rank, h->world, h->x,
+    hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->rank, h->world, h->x,
                        h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st,
                        sync ? nullptr : h->dd_cntmat); // (on the stream: + the lengths of the lists in use until now, of every
                                                       // rank: what the next poll sizes the messages by)
@@ -643,11 +694,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
 #define MDP(K)                                                                                              \
     do {                                                                                                    \
         if (fuse_count)                                                                                     \
-            hipLaunchKernelGGL((k_md_pack<K, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, \
+            hipLaunchKernelGGL((k_md_pack<K, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, \
                                h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial,      \
                                h->grid + (h->build_idx & 1), h->cell_of, h->rank_in_cell, h->count);        \
         else                                                                                                \
-            hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,   \
+            hipLaunchKernelGGL((k_md_pack<K>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,   \
                                h->xlo, h->v, h->g, h->labels, h->pos4, h->bbox_part, M, &h->st->ftrial);     \
     } while (0)
         if (h->md_kind == MD_LANGEVIN) MDP(MD_LANGEVIN);
@@ -658,18 +709,18 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
         GridParams *cur = h->grid + (h->build_idx & 1);
         if (mode == PACK_MOVE) // trial move of the minimizer: also forms the new direction after an accepted step
-            hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+            hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
                                h->count, dir_args(h));
         else
-            hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp,
+            hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp,
                                h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
     } else if (mode == PACK_MOVE)
-        hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x,
+        hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
                            (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h));
     else
-        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->x, h->xp, h->d,
+        hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st);
     // dd_frozen (measurement: scripts/dd_projection.py): no collective is issued -- the ghost lists and the ghost positions
     // last received stay, so one rank's kernels can be timed alone on exactly the beads it holds in a real run
@@ -691,7 +742,12 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         const dim3 gq(std::min((mx + 255) / 256, 256), h->world);
         hipLaunchKernelGGL(k_dd_pack, gq, dim3(256), 0, h->stream, h->dd_send_ids, h->dd_send_cnt, h->slice, h->pos4,
                            h->dd_sendbuf, h->dd_scap, h->st);
-        coll_halo_exchange(h);
+        {
+            EventPair cep{};
+            const bool con = coll_prof_begin(h, kCollHalo, cep);
+            coll_halo_exchange(h);
+            prof_end(h, con, cep);
+        }
         hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
                            h->dd_ghost_ids, h->n_all, h->st);
     } else if (has_comm(h) && !h->dd_frozen) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
@@ -706,11 +762,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                                dd ? hm : 0.f, cur, h->st);
         const int gl = (h->n_own + h->dd_nghost + 255) / 256; // owned beads + listed ghosts
         if (halo)
-            hipLaunchKernelGGL(k_cell_count_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo,
+            hipLaunchKernelGGL(k_cell_count_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, own_of(h),
                                h->dd_nghost, h->dd_ghost_ids, h->pos4, cur, h->cell_of, h->rank_in_cell, h->count,
                                h->count_own, h->st);
         else if (!fuse_count)
-            hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->own_lo, h->n_own, h->pos4,
+            hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, own_of(h), h->pos4,
                                cur, h->cell_of, h->rank_in_cell, h->count, h->st, h->count_own);
         // (count_own: decomposed handles only -- a cell's owned beads and its ghosts form separate clusters)
         const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next,
@@ -727,11 +783,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             hipLaunchKernelGGL((k_cell_scan<kChunk>), dim3(1), dim3(1024), 0, h->stream, sa, h->st);
         }
         if (halo)
-            hipLaunchKernelGGL(k_cell_fill_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, h->own_lo, h->dd_nghost,
+            hipLaunchKernelGGL(k_cell_fill_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, own_of(h), h->dd_nghost,
                                h->dd_ghost_ids, h->cell_of, h->rank_in_cell, h->start, h->perm, h->okeys, h->pos4, cur, h->st);
         else
             hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
-                               h->start, h->perm, h->okeys, h->pos4, cur, h->own_lo, h->n_own, h->st);
+                               h->start, h->perm, h->okeys, h->pos4, cur, own_of(h), h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order; the work items
         // of the half-shell pair kernel are built by extra workgroups of the same launch (k_order_items)
         const bool small_cells = h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
@@ -741,23 +797,23 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             if (small_cells)
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
+                                   h->cl_hi, own_of(h), h->okeys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
                                    h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, h->own_lo, h->n_own, h->okeys, h->biglist, h->n3_items,
+                                   h->cl_hi, own_of(h), h->okeys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
                                    h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st, h->count_own);
+                               own_of(h), h->okeys, h->biglist, h->st, h->count_own);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               h->own_lo, h->n_own, h->okeys, h->biglist, h->st, h->count_own);
+                               own_of(h), h->okeys, h->biglist, h->st, h->count_own);
         h->gcur = cur;
         h->build_idx++;
         h->grid_ready = true;
@@ -883,7 +939,10 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
         } else { // energies, Gram rows, g.d, x.x of all ranks: ONE fp64 all-reduce of 57 doubles per evaluation
             hipLaunchKernelGGL(k_reduce_all, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
+            EventPair cep{};
+            const bool con = coll_prof_begin(h, kCollAllreduce, cep);
             coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            prof_end(h, con, cep);
             hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
         }
         // d = sum_a coef[a] B_a, xp <- x, gp <- g: done per bead by the next trial move (k_pack<.., DIR>)
@@ -1019,6 +1078,285 @@ int ensure_allpairs_scratch(mmx_handle_s *h) {
         HIPCHK(h, dalloc(&h->epart, (size_t)slices * h->n));
         h->ap_slices = slices;
     }
+    return MMX_OK;
+}
+
+// ---- loops: per-rank CSR from the loops as given (mmx_set_loops; again after a re-assignment of the segments) ------
+int rebuild_loops(mmx_handle_s *h) {
+    const int n_loops = (int)h->loop_m.size();
+    const int *m = h->loop_m.data(), *n = h->loop_n.data();
+    const float *r0 = h->loop_r0v.data();
+    // CSR over beads that carry a loop end; entries of a bead keep loop order (fixed summation order).
+    std::vector<int> deg((size_t)h->n, 0);
+    for (int l = 0; l < n_loops; ++l) {
+        deg[m[l]]++;
+        deg[n[l]]++;
+    }
+    std::vector<int> row_of((size_t)h->n, -1), row_bead, row_start;
+    int ne = 0;
+    for (int li = 0; li < h->n_own; ++li) { // rows of the beads this handle owns, in local order
+        const int b = bead_of(h, li);
+        if (deg[b]) {
+            row_of[b] = (int)row_bead.size();
+            row_bead.push_back(b);
+            row_start.push_back(ne);
+            ne += deg[b];
+        }
+    }
+    row_start.push_back(ne);
+    std::vector<int> fill(row_start.begin(), row_start.end()), partner((size_t)ne);
+    std::vector<float> er0((size_t)ne);
+    for (int l = 0; l < n_loops; ++l) {
+        if (row_of[m[l]] >= 0) {
+            const int q = fill[row_of[m[l]]]++;
+            partner[q] = n[l];
+            er0[q] = r0[l];
+        }
+        if (row_of[n[l]] >= 0) {
+            const int q = fill[row_of[n[l]]]++;
+            partner[q] = m[l];
+            er0[q] = r0[l];
+        }
+    }
+    // decomposed runs: the owner of a loop end always needs the other end (static part of the ghost lists)
+    h->dd_loop_mask.assign((size_t)std::max(h->n_own, 1), 0ull);
+    if (h->world > 1 && h->world <= kDDMaxWorld)
+        for (int l = 0; l < n_loops; ++l) {
+            const int rm = owner_of(h, m[l]), rn = owner_of(h, n[l]);
+            if (rm == rn) continue;
+            if (rm == h->rank) h->dd_loop_mask[local_of(h, m[l])] |= 1ull << rn;
+            if (rn == h->rank) h->dd_loop_mask[local_of(h, n[l])] |= 1ull << rm;
+        }
+    h->dd_static_dirty = true;
+    for (void *p : {(void *)h->row_bead, (void *)h->row_start, (void *)h->partner, (void *)h->loop_r0, (void *)h->lstart})
+        if (p) (void)hipFree(p);
+    h->row_bead = h->row_start = h->partner = h->lstart = nullptr;
+    h->loop_r0 = nullptr;
+    h->n_rows = (int)row_bead.size();
+    h->n_loops = n_loops;
+    if (h->n_rows > 0) {
+        HIPCHK(h, dalloc(&h->row_bead, row_bead.size()));
+        HIPCHK(h, dalloc(&h->row_start, row_start.size()));
+        HIPCHK(h, dalloc(&h->partner, partner.size()));
+        HIPCHK(h, dalloc(&h->loop_r0, er0.size()));
+        HIPCHK(h, hipMemcpy(h->row_bead, row_bead.data(), row_bead.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->row_start, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->loop_r0, er0.data(), er0.size() * sizeof(float), hipMemcpyHostToDevice));
+        // the same entries addressed per owned bead (rows are in local order): offsets for the fused bonded kernel
+        std::vector<int> lstart((size_t)h->n_own + 1, 0);
+        for (int li = 0; li < h->n_own; ++li) lstart[(size_t)li + 1] = lstart[li] + deg[bead_of(h, li)];
+        HIPCHK(h, dalloc(&h->lstart, lstart.size()));
+        HIPCHK(h, hipMemcpy(h->lstart, lstart.data(), lstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return MMX_OK;
+}
+
+// ---- spatial re-assignment of the ownership (decomposed runs with a halo; SURVEY 8e "re-decompose") ------------------
+// Index ranges are compact bricks only at the Hilbert start: once the globule has been pushed into the container's shell a
+// range is a bent slab and a rank carries more ghosts than beads (rounds 1-3: 79 k - 217 k ghosts per 125 000 owned beads
+// on 8 ranks of gw_1m).  So the 62-bead segments are re-assigned while the minimization runs: every rank reduces its
+// segments to centroids, the centroids are all-gathered (16 B per segment), every rank runs the same recursive
+// coordinate bisection on the same numbers (longest axis of the centroids' box, cut in proportion to the ranks on either
+// side, never more than seg_per segments per rank) and -- when at least 2 % of the segments would change hands -- the
+// per-bead vectors of the optimizer (x, xp, g, gp, d, the 12 history vectors; v and xlo when MD is configured) migrate
+// with their segments: each is all-gathered block-wise into a staging area (3 * slice floats per rank) and every rank
+// picks the segments it now owns.  L-BFGS is invariant under a permutation of the beads (every reduction is a sum over
+// beads: only the rounding order changes), so the optimisation carries on as if nothing had happened; what follows is a
+// synchronous rebuild of the ghost lists.  Offline comparison of ownership rules on dumped states of gw_1m
+// (scripts/dd_ownership_offline.py, 8 ranks, the need-map rule of mmx_dd.hpp): index ranges 134 k ghosts per rank on
+// average (max 215 k); segments of 62 / 248 / 992 beads by this bisection 69 k / 78 k / 84 k (max 74 k / 90 k / 119 k);
+// single beads 42 k (the bound: chain segments of neighbouring regions interpenetrate).
+__global__ __launch_bounds__(256) void k_seg_centroids(int n_own, const float *__restrict__ x, float4 *__restrict__ out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; // one wave per local segment
+    const int li = t * kSeg + lane;
+    const bool act = lane < kSeg && li < n_own;
+    float sx = act ? x[3 * li] : 0.f, sy = act ? x[3 * li + 1] : 0.f, sz = act ? x[3 * li + 2] : 0.f, c = act ? 1.f : 0.f;
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    sz = wave_sum(sz);
+    c = wave_sum(c);
+    if (lane == 0 && t * kSeg < n_own) out[t] = make_float4(sx / c, sy / c, sz / c, c);
+}
+// vec (local order of the NEW assignment) <- the staging area: new local segment t comes from block src[t] (in segments)
+__global__ __launch_bounds__(256) void k_migrate_vec(int n_own_new, int n_floats_cap, const int *__restrict__ src,
+                                                     const float *__restrict__ mig, float *__restrict__ vec) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_floats_cap; e += gridDim.x * 256) {
+        float v = 0.f; // beyond the owned beads the vectors hold zeros (they enter every dot product)
+        if (e < 3 * n_own_new) {
+            const int li = e / 3, t = li / kSeg;
+            v = mig[(size_t)3 * ((size_t)src[t] * kSeg + (li - t * kSeg)) + (e - 3 * li)];
+        }
+        vec[e] = v;
+    }
+}
+
+// every rank's `vec` (3 * n_own floats in local order) -> h->mig[q][3 * slice] on every rank
+int coll_allgather_vec(mmx_handle_s *h, const float *vec) {
+    const size_t blk = (size_t)3 * h->slice;
+    if (!h->mig) HIPCHK(h, dalloc(&h->mig, blk * h->world));
+    HIPCHK(h, hipMemcpyAsync(h->mig + blk * h->rank, vec, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
+    coll_allgather_small(h, h->mig, blk * sizeof(float), [](mmx_handle_s *o) { return (void *)o->mig; });
+    return MMX_OK;
+}
+
+// Balanced recursive coordinate bisection: segments `ids` (centroids c) -> ranks [r0, r1), at most `cap` each.
+void rcb_assign(const std::vector<float4> &c, std::vector<int> &ids, int lo, int hi, int r0, int r1, int cap, std::vector<int> &owner) {
+    const int nr = r1 - r0, len = hi - lo;
+    if (nr == 1) {
+        for (int k = lo; k < hi; ++k) owner[ids[k]] = r0;
+        return;
+    }
+    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+    for (int k = lo; k < hi; ++k) {
+        const float4 &p = c[ids[k]];
+        mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
+        mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
+        mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
+    }
+    int ax = 0;
+    if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+    if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+    const int nl = nr / 2;
+    long long cut = ((long long)len * nl + nr / 2) / nr;                 // in proportion to the ranks on either side
+    cut = std::max<long long>(cut, (long long)len - (long long)(nr - nl) * cap); // ... and within what either side can hold
+    cut = std::min<long long>(cut, (long long)nl * cap);
+    auto key = [&](int s) { return ax == 0 ? c[s].x : ax == 1 ? c[s].y : c[s].z; };
+    // (ties by segment id: every rank sorts the same numbers the same way)
+    std::nth_element(ids.begin() + lo, ids.begin() + lo + cut, ids.begin() + hi,
+                     [&](int a, int b) { const float ka = key(a), kb = key(b); return ka < kb || (ka == kb && a < b); });
+    rcb_assign(c, ids, lo, lo + (int)cut, r0, r0 + nl, cap, owner);
+    rcb_assign(c, ids, lo + (int)cut, hi, r0 + nl, r1, cap, owner);
+}
+
+// Collective: every rank calls it at the same point of the same call (a poll of mmx_minimize: the stream is idle).
+// changed: the ownership is different now (the ghost lists are invalid, the next evaluation must rebuild them synchronously).
+int dd_reassign(mmx_handle_s *h, bool &changed, double min_moved_fraction = 0.02) {
+    changed = false;
+    if (!use_halo(h) || h->seg_per <= 0) return MMX_OK;
+    h->dd_reassign_attempts++;
+    const int W = h->world, SP = h->seg_per, NS = h->nseg;
+    if (!h->seg_cent) {
+        HIPCHK(h, dalloc(&h->seg_cent, (size_t)W * SP));
+        HIPCHK(h, hipHostMalloc((void **)&h->seg_cent_host, sizeof(float4) * (size_t)W * SP, hipHostMallocDefault));
+        HIPCHK(h, dalloc(&h->d_mig_src, (size_t)SP));
+    }
+    // 1. centroids of the owned segments -> everybody
+    HIPCHK(h, hipMemsetAsync(h->seg_cent + (size_t)h->rank * SP, 0, sizeof(float4) * SP, h->stream));
+    const int nsl = (h->n_own + kSeg - 1) / kSeg;
+    if (nsl > 0)
+        hipLaunchKernelGGL(k_seg_centroids, dim3((nsl + 3) / 4), dim3(256), 0, h->stream, h->n_own, h->x, h->seg_cent + (size_t)h->rank * SP);
+    coll_allgather_small(h, h->seg_cent, sizeof(float4) * SP, [](mmx_handle_s *o) { return (void *)o->seg_cent; });
+    HIPCHK(h, hipMemcpyAsync(h->seg_cent_host, h->seg_cent, sizeof(float4) * (size_t)W * SP, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+    // 2. the current assignment as tables (identity until the first re-assignment), centroid per global segment
+    const int nseg_real = (h->n + kSeg - 1) / kSeg;
+    std::vector<int> old_owner((size_t)NS, -1), old_lidx((size_t)NS, -1);
+    if (h->seg_owner.empty()) {
+        for (int s = 0; s < nseg_real; ++s) {
+            old_owner[s] = s / SP;
+            old_lidx[s] = s % SP;
+        }
+    } else {
+        old_owner = h->seg_owner;
+        old_lidx = h->seg_lidx;
+    }
+    std::vector<float4> cent((size_t)NS);
+    std::vector<int> ids;
+    ids.reserve((size_t)nseg_real);
+    for (int s = 0; s < nseg_real; ++s) {
+        cent[s] = h->seg_cent_host[(size_t)old_owner[s] * SP + old_lidx[s]];
+        if (!(cent[s].w > 0.f) || !std::isfinite(cent[s].x) || !std::isfinite(cent[s].y) || !std::isfinite(cent[s].z))
+            return MMX_OK; // a non-finite state: leave it to the controller
+        ids.push_back(s);
+    }
+    // 3. bisection (the same on every rank) and how much it would move
+    std::vector<int> new_owner((size_t)NS, -1);
+    rcb_assign(cent, ids, 0, nseg_real, 0, W, SP, new_owner);
+    // The bisection numbers its regions arbitrarily: relabel them so that a region goes to the rank that already owns most
+    // of it (greedy by overlap, largest first) -- what then changes hands is what has to.
+    {
+        std::vector<long long> ov((size_t)W * W, 0);
+        for (int s = 0; s < nseg_real; ++s) ov[(size_t)new_owner[s] * W + old_owner[s]]++;
+        std::vector<int> map((size_t)W, -1);
+        std::vector<char> taken((size_t)W, 0);
+        for (int round = 0; round < W; ++round) {
+            long long best = -1;
+            int bi = -1, bj = -1;
+            for (int i = 0; i < W; ++i) {
+                if (map[i] >= 0) continue;
+                for (int j = 0; j < W; ++j)
+                    if (!taken[j] && ov[(size_t)i * W + j] > best) {
+                        best = ov[(size_t)i * W + j];
+                        bi = i;
+                        bj = j;
+                    }
+            }
+            map[bi] = bj;
+            taken[bj] = 1;
+        }
+        for (int s = 0; s < nseg_real; ++s) new_owner[s] = map[new_owner[s]];
+    }
+    int moved = 0;
+    for (int s = 0; s < nseg_real; ++s) moved += new_owner[s] != old_owner[s];
+    if (moved == 0 || (double)moved < min_moved_fraction * (double)nseg_real) return MMX_OK;
+    // the segment that holds the last beads (it may be partial) must stay LAST in its owner's local order: it is, the
+    // local order is ascending in the segment id
+    std::vector<int> new_lidx((size_t)NS, -1), cnt((size_t)W, 0), mine;
+    for (int s = 0; s < nseg_real; ++s) {
+        new_lidx[s] = cnt[new_owner[s]]++;
+        if (new_owner[s] == h->rank) mine.push_back(s);
+    }
+    for (int q = 0; q < W; ++q)
+        if (cnt[q] > SP || cnt[q] == 0) return MMX_OK; // (cannot happen: the cuts respect the capacity; a rank is never left empty-handed on purpose)
+    const int n_own_new = (int)mine.size() * kSeg - (mine.back() == nseg_real - 1 ? nseg_real * kSeg - h->n : 0);
+    // 4. migration of the per-bead vectors
+    std::vector<int> src(mine.size());
+    for (size_t t = 0; t < mine.size(); ++t) src[t] = old_owner[mine[t]] * SP + old_lidx[mine[t]];
+    HIPCHK(h, hipMemcpyAsync(h->d_mig_src, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // (src is pageable)
+    const int cap_floats = h->n4 * 4;
+    const size_t nv = (size_t)h->n4 * 4;
+    std::vector<float *> vecs = {h->x, h->xp, h->g, h->gp, h->d};
+    for (int a = 0; a < MMX_M; ++a) {
+        vecs.push_back(h->S + a * nv);
+        vecs.push_back(h->Y + a * nv);
+    }
+    if (h->v) vecs.push_back(h->v);
+    if (h->xlo) vecs.push_back(h->xlo);
+    const int gm = std::min((cap_floats + 255) / 256, 1024);
+    for (float *vec : vecs) {
+        int rc = coll_allgather_vec(h, vec); // (blocks in the OLD local order: n_own is still the old count)
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_migrate_vec, dim3(gm), dim3(256), 0, h->stream, n_own_new, cap_floats, h->d_mig_src, h->mig, vec);
+    }
+    // 5. the new tables
+    h->seg_owner = new_owner;
+    h->seg_lidx = new_lidx;
+    h->my_segs = mine;
+    h->n_own = n_own_new;
+    h->own_lo = mine.front() * kSeg;
+    std::vector<int> seg_local((size_t)NS, -1);
+    for (size_t t = 0; t < mine.size(); ++t) seg_local[mine[t]] = (int)t;
+    if (!h->d_seg_own) {
+        HIPCHK(h, dalloc(&h->d_seg_own, (size_t)SP));
+        HIPCHK(h, dalloc(&h->d_seg_local, (size_t)NS));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_seg_own, mine.data(), sizeof(int) * mine.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_seg_local, seg_local.data(), sizeof(int) * (size_t)NS, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+    int rc = rebuild_loops(h);
+    if (rc) return rc;
+    if ((rc = dd_upload_static(h))) return rc;
+    h->dd_static_dirty = false;
+    refresh_params(h);
+    h->dd_lists_valid = false;
+    h->md_forces_valid = false;
+    h->dd_reassignments++;
+    h->dd_segments_moved += moved;
+    changed = true;
     return MMX_OK;
 }
 

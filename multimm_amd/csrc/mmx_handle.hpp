@@ -137,6 +137,25 @@ struct mmx_handle_s {
     // domain decomposition (single GPU: rank 0 of 1, owns every bead)
     int rank = 0, world = 1, slice = 0; // slice = beads per rank (n padded to world * slice = n_all)
     int n_all = 0, own_lo = 0, n_own = 0;
+    // Ownership in segments of kSeg beads (Own, mmx_common.hpp).  At creation rank r owns the contiguous segments
+    // [r * seg_per, (r + 1) * seg_per) (slice = seg_per * kSeg beads; the tables are empty / null: "identity").  During a
+    // minimization with a halo the segments are re-assigned by recursive bisection of their centroids (dd_reassign).
+    int seg_per = 0;              // segments per rank of the initial assignment = capacity of a rank's vectors in segments
+    int nseg = 0;                 // segments of the padded system: world * seg_per
+    std::vector<int> seg_owner;   // [nseg] owner of every segment (identical on all ranks; empty: identity); segments past the last bead: -1
+    std::vector<int> seg_lidx;    // [nseg] local segment index at its owner
+    std::vector<int> my_segs;     // owned segments, ascending
+    int *d_seg_own = nullptr, *d_seg_local = nullptr; // device tables of this rank (nullptr: identity)
+    int dd_spatial = 1;           // option: re-assign segments while minimizing (0: ownership stays the initial slices)
+    int dd_reassign_first = 48;   // evaluations of a minimization before the first attempt; the interval doubles up to ...
+    int dd_reassign_max = 768;
+    long long dd_reassignments = 0, dd_reassign_attempts = 0, dd_segments_moved = 0; // statistics
+    float *mig = nullptr;         // staging of a migration: [world][3 * slice] floats (allocated at the first one)
+    float4 *seg_cent = nullptr;   // [world][seg_per] centroids {x, y, z, beads} of the owned segments, all-gathered
+    float4 *seg_cent_host = nullptr; // pinned copy
+    int *d_mig_src = nullptr;     // [seg_per] where each owned segment of the new assignment sits in `mig`
+    std::vector<int> loop_m, loop_n; // the loops as given (mmx_set_loops): the per-rank CSR is rebuilt after a re-assignment
+    std::vector<float> loop_r0v;
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalComm> lcomm; // in-process loopback communicator (tests on one GPU)
     unsigned long long coll_seq = 0;  // collectives issued so far (parity selects the event / mailbox set)
@@ -233,6 +252,9 @@ struct mmx_handle_s {
     float ev_cut = 0.f, g_cut = 0.f, g_rc = 0.15f;
     // molecular dynamics (mmx_md_*): velocities, low-order position bits, integrator constants
     float *v = nullptr, *xlo = nullptr;
+    float *md_snap = nullptr;     // decomposed runs: x, v, xlo as of the last poll that found the ghost lists in order (3 vectors)
+    uint64_t md_snap_step = 0;
+    bool md_sync_next = false;    // the first step after a roll-back rebuilds its ghost lists synchronously (fresh capacities): progress
     double *ke_part = nullptr, *ke_out = nullptr;
     bool md_configured = false, md_forces_valid = false;
     int md_kind = 0;
@@ -258,6 +280,10 @@ struct mmx_handle_s {
                         // -1 = per-slot sampling
     int profile_nb = 0; // minimizer: every profile_nb-th evaluation samples the pair-kernel slot alone (one event pair)
     // profiling
+    // decomposed runs: HIP-event time of the collectives of the sampled evaluations (option "profile"), slots kCollNeedmap..:
+    // from the end of the work before it to its own end on this rank's stream, i.e. transfer + waiting for the peers
+    double coll_ns[4]{};
+    long long coll_samples[4]{};
     std::vector<EventPair> ev_pool, ev_used;
     int64_t launches[MMX_N_KERNELS]{};
     std::string err;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void normal3(uint32_t bead, uint32_t step_lo, uint32_
 // by ~1e-5 nm while an fp32 ulp at 10 nm is 1e-6 nm), writes pos4 and the per-block bounding box.
 // Algorithmic traffic: read 12 B x + 12 B xlo + 12 B v + 12 B g + 1 B label, write 12+12+12+16 B = 101 B/bead.
 template <int KIND, bool COUNT = false>
-__global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *__restrict__ x, float *__restrict__ xlo,
+__global__ __launch_bounds__(256) void k_md_pack(int n_own, const Own own, float *__restrict__ x, float *__restrict__ xlo,
                                                  float *__restrict__ v, const float *__restrict__ g,
                                                  const int8_t *__restrict__ labels, float4 *__restrict__ pos4,
                                                  float *__restrict__ bbox_part, const MdParams M,
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
         }
     }
     if (act) {
-        const int bead = own_lo + i;
+        const int bead = own.bead(i);
         float z[3] = {0.f, 0.f, 0.f};
         if (KIND == MD_LANGEVIN || KIND == MD_BROWNIAN) normal3((uint32_t)bead, M.step_lo, M.step_hi, 0u, M.key0, M.key1, z);
 #pragma unroll
@@ -146,12 +146,12 @@ __global__ __launch_bounds__(256) void k_md_pack(int n_own, int own_lo, float *_
 }
 
 // context.setVelocitiesToTemperature(T, seed): v = sqrt(kT/m) N(0,1) per component (stream 1, step 0).
-__global__ __launch_bounds__(256) void k_md_init_velocities(int n_own, int own_lo, float sigma, uint32_t key0,
+__global__ __launch_bounds__(256) void k_md_init_velocities(int n_own, const Own own, float sigma, uint32_t key0,
                                                             uint32_t key1, float *__restrict__ v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_own) return;
     float z[3];
-    normal3((uint32_t)(own_lo + i), 0u, 0u, 1u, key0, key1, z);
+    normal3((uint32_t)own.bead(i), 0u, 0u, 1u, key0, key1, z);
     v[3 * i] = sigma * z[0];
     v[3 * i + 1] = sigma * z[1];
     v[3 * i + 2] = sigma * z[2];

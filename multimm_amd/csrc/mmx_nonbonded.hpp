@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
         float4 pv = spos4[(size_t)icl * kCl + slot];
         // padding slots sit at +1e18 in spos4 (they are also j entries of this very cluster) and ghost beads
         // of a mixed cluster get no force here: as i beads move both far away so that they meet no pair
-        if ((unsigned)((__float_as_int(pv.w) >> 3) - P.own_lo) >= (unsigned)P.n_own) {
+        if (!P.own().owns(__float_as_int(pv.w) >> 3)) {
             pv.x = pv.y = pv.z = 3e18f;
             pv.w = __int_as_float(-8 + (__float_as_int(pv.w) & 7));
         }
@@ -617,7 +617,8 @@ __global__ __launch_bounds__(256, FORMS ? 2 : (((OPT & 512) && PMODE != 3) ? 7 :
         tev *= escale; // LEAN, p = 6: the loop summed (sigma-free) u^6
         if (own) {
             if (GAUSS && !FORMS && !NOENERGY) teg += s_tab[(ow & 7) * 8 + (ow & 7)];
-            float *gb = g + 3 * (bead - P.own_lo); // the bonded terms wrote the gradient first
+            float *gb = g + 3 * P.own().local(bead); // the bonded terms wrote the gradient first (looked up here, not kept
+                                                     // live across the pair loop: the kernel sits at exactly 80 VGPRs)
             const float g0 = gb[0], g1 = gb[1], g2 = gb[2];
             gb[0] = g0 - ofx;
             gb[1] = g1 - ofy;

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      int *__restrict__ count, int *__restrict__ perm, int2 *__restrict__ items,
                                                      const int *__restrict__ cstart, const float4 *__restrict__ pos4,
                                                      float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
-                                                     float4 *__restrict__ cl_hi, int own_lo, int n_own,
+                                                     float4 *__restrict__ cl_hi, const Own own,
                                                      const unsigned long long *__restrict__ okeys,
                                                      const int *__restrict__ biglist,
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own_lo, n_own, okeys, biglist, st, count_own, sbead);
+                                 spos4, cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead);
 }
 
 #ifdef MMX_N3_TIMING
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     int *const box0 = s_f + 2 * 3 * fstr;           // box buffers
     int *const ids0 = box0 + 2 * 8 * (cap + 1);     // id buffers
     const int far_cl = P.n_all; // a resident all-padding cluster (8 beads at -1e18)
+    const Own own = P.own();
     const int n_items = st->n3_items;
     if (threadIdx.x < 40) {
         const bool in5 = (threadIdx.x & 7) < 5;
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             const unsigned long long mb = __ballot(okb);
                             if (okb) {
                                 int wj = (((lq << 3) | slot) << 3) | (__float_as_int(q.w) & 7);
-                                if (DD) wj |= ((unsigned)((__float_as_int(q.w) >> 3) - P.own_lo) < (unsigned)P.n_own) ? 1 << 15 : 0;
+                                if (DD) wj |= own.owns(__float_as_int(q.w) >> 3) ? 1 << 15 : 0;
                                 q.w = __int_as_float(wj);
                                 ring[(rhead + rcount + prefix_count(mb)) & 127] = q;
                             }
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
 // Decomposed runs: g holds the owned beads only; what landed on a ghost's slot is dropped (its owner computes it).
 __global__ __launch_bounds__(256) void k_nb_n3_unsort(const int *__restrict__ sbead, float *__restrict__ fsort,
                                                       const int fstride, float *__restrict__ g,
-                                                      MinState *__restrict__ st, const int own_lo, const int n_own) {
+                                                      MinState *__restrict__ st, const Own own) {
     if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->n3_queue = 0;
     const int nsl = st->n_clusters * kCl;
@@ -969,8 +970,9 @@ __global__ __launch_bounds__(256) void k_nb_n3_unsort(const int *__restrict__ sb
         fsort[i] = 0.f;
         fsort[fstride + i] = 0.f;
         fsort[2 * fstride + i] = 0.f;
-        if ((unsigned)(bead - own_lo) < (unsigned)n_own) {
-            float *gb = g + 3 * (size_t)(bead - own_lo); // the bonded terms wrote the gradient first
+        const int li = own.local(bead);
+        if (li >= 0) {
+            float *gb = g + 3 * (size_t)li; // the bonded terms wrote the gradient first
             gb[0] -= fx;
             gb[1] -= fy;
             gb[2] -= fz;

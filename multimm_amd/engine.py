@@ -73,6 +73,7 @@ SIGNATURES = {
     "mmx_create_dd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "mmx_dd_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32)]),
+    "mmx_dd_owned_beads": (C.c_int, [_P, _P]),
     "mmx_comm_unique_id": (C.c_int, [_P]),
     "mmx_comm_init": (C.c_int, [_P, _P]),
     "mmx_comm_init_local": (C.c_int, [C.POINTER(_P), C.c_int32]),
@@ -150,9 +151,28 @@ class Engine:
         if rc != 0:
             msg = self._lib.mmx_last_error(None)
             raise MMXError(rc, msg.decode() if msg else "mmx_create failed")
+
+    # what this handle owns NOW: a decomposed minimization re-assigns 62-bead segments to the ranks (mmx.h, "multi-GPU")
+    def _dd_info(self):
         lo, no = C.c_int32(), C.c_int32()
         self._lib.mmx_dd_info(self._h, C.byref(lo), C.byref(no), None, None)
-        self.own_lo, self.n_own = lo.value, no.value
+        return lo.value, no.value
+
+    @property
+    def own_lo(self) -> int:
+        """First owned bead (the whole owned range while the ownership is the initial contiguous one)."""
+        return self._dd_info()[0]
+
+    @property
+    def n_own(self) -> int:
+        return self._dd_info()[1]
+
+    def owned_beads(self) -> np.ndarray:
+        """Global ids of the owned beads in local order (ascending): row k of ``compute()``'s forces belongs to bead
+        ``owned_beads()[k]``."""
+        ids = np.empty(self.n_own, dtype=np.int32)
+        self._chk(self._lib.mmx_dd_owned_beads(self._h, ids.ctypes.data_as(_P)))
+        return ids
 
     @staticmethod
     def comm_unique_id() -> bytes:

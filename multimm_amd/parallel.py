@@ -14,12 +14,19 @@ from typing import Tuple
 import numpy as np
 
 
+SEGMENT = 62   # beads per ownership segment (kSeg, csrc/mmx_common.hpp: one backbone tile)
+
+
 def slice_of(n_beads: int, rank: int, world: int) -> Tuple[int, int]:
-    """Bead range [lo, hi) owned by `rank` -- the rule of mmx_create_dd: equal slices of ceil(N/world),
-    the last one(s) clipped to N."""
+    """Bead range [lo, hi) `rank` owns when a decomposed handle is created -- the rule of mmx_create_dd: one rank alone owns
+    everything; otherwise equal slices of 62 * ceil(ceil(N / 62) / world) beads (whole 62-bead segments), the last one(s)
+    clipped to N.  (mmx_minimize re-assigns segments afterwards: ask Engine.owned_beads().)"""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("rank/world out of range")
-    s = (n_beads + world - 1) // world
+    if world == 1:
+        return 0, n_beads
+    nseg = (n_beads + SEGMENT - 1) // SEGMENT
+    s = SEGMENT * ((nseg + world - 1) // world)
     lo = min(n_beads, rank * s)
     return lo, min(n_beads, lo + s)
 

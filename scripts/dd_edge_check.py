@@ -17,7 +17,7 @@ for n, world in ((2050, 8), (600, 8), (300, 7)):
         try:
             et, f = engines[r].compute()
             st = engines[r].minimize(tolerance=0.0, max_iters=5)
-            out[r] = (et, f, engines[r].own_lo, engines[r].n_own, st.iterations, st.e_final)
+            out[r] = (et, f, engines[r].owned_beads(), None, st.iterations, st.e_final)
         except Exception as ex:
             err.append((r, repr(ex)))
     th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
@@ -26,6 +26,6 @@ for n, world in ((2050, 8), (600, 8), (300, 7)):
         print(n, world, "errors:", err[:2], "alive:", [t.is_alive() for t in th]); continue
     F = np.zeros_like(F0)
     for et, f, lo, no, it, ef in out:
-        F[lo:lo + no] = f
-    print(n, world, "own", [o[3] for o in out], "dE", np.abs(out[0][0] - et0).max(), "dF", np.abs(F - F0).max(), "iters", out[0][4])
+        F[lo] = f
+    print(n, world, "own", [len(o[2]) for o in out], "dE", np.abs(out[0][0] - et0).max(), "dF", np.abs(F - F0).max(), "iters", out[0][4])
     for e in engines: e.close()

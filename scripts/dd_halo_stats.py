@@ -12,7 +12,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 relax = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
 worlds = [int(w) for w in (sys.argv[4] if len(sys.argv) > 4 else "2,4,8").split(",")]
 KEYS = ("dd_ghosts", "dd_ghost_slots", "dd_exchanges", "dd_bytes_sent", "dd_redecompositions", "dd_sync_rebuilds", "dd_halts",
-        "dd_capacity_updates")
+        "dd_capacity_updates", "dd_reassignments", "dd_reassign_attempts", "dd_segments_moved")
 s = synthetic_system(name)
 for world in worlds:
     engines = [engine_for(s, rank=r, world=world) for r in range(world)]
@@ -21,6 +21,8 @@ for world in worlds:
             e.set_option("dd_rebuild_every", float(os.environ["DD_EVERY"]))
         if os.environ.get("DD_SKIN"):
             e.set_option("dd_skin", float(os.environ["DD_SKIN"]))
+        if os.environ.get("DD_SPATIAL"):   # 0: ownership stays the initial index ranges (rounds 1-3)
+            e.set_option("dd_spatial", float(os.environ["DD_SPATIAL"]))
     Engine.comm_init_local(engines)
     out = [None] * world
     def work(r):
@@ -34,7 +36,7 @@ for world in worlds:
             d["dd_ghosts"], d["dd_ghost_slots"] = g["dd_ghosts"], g["dd_ghost_slots"]
             rows.append((phase, st.iterations, st.evaluations, st.e_final, d))
             prev = g
-        out[r] = (rows, e.n_own)
+        out[r] = (rows, s.n_beads // world)
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
     [t.start() for t in th]; [t.join() for t in th]
     for e in engines:
@@ -49,4 +51,5 @@ for world in worlds:
               f"ghosts at the end min/mean/max {min(gh):.0f}/{np.mean(gh):.0f}/{max(gh):.0f}; bytes sent per evaluation per rank "
               f"mean {np.mean(per) / 1e6:.2f} MB max {max(per) / 1e6:.2f} MB (all-gather: {16 * n_own * (world - 1) / 1e6:.1f} MB received per rank); "
               f"list rebuilds {d0['dd_redecompositions']:.0f} ({d0['dd_sync_rebuilds']:.0f} synchronous), halts {d0['dd_halts']:.0f}, "
-              f"message resizes {d0['dd_capacity_updates']:.0f}", flush=True)
+              f"message resizes {d0['dd_capacity_updates']:.0f}; segment re-assignments {d0['dd_reassignments']:.0f} of "
+              f"{d0['dd_reassign_attempts']:.0f} attempts, {d0['dd_segments_moved']:.0f} segments moved", flush=True)

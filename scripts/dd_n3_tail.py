@@ -64,7 +64,7 @@ else:
     xs = {}
     def work(e):
         e.minimize(tolerance=0.0, max_iters=relax)
-        xs[e.own_lo] = e.get_positions()      # a collective: every position, on every rank
+        xs[e.rank] = e.get_positions()      # a collective: every position, on every rank
         e.compute()
     th = [threading.Thread(target=work, args=(e,)) for e in engines]
     [t.start() for t in th]; [t.join() for t in th]
@@ -76,7 +76,7 @@ else:
         total = (whole.count_neighbors(whole, rc) - len(x)) // 2
         print(f"unique pairs within {rc} nm: {total / 1e6:.1f} M; an ideal rank: {total / world / 1e6:.1f} M")
         for r, e in enumerate(engines):
-            own = cKDTree(x[e.own_lo:e.own_lo + e.n_own])
+            own = cKDTree(x[e.owned_beads()])
             oo = (own.count_neighbors(own, rc) - e.n_own) // 2
             og = own.count_neighbors(whole, rc) - e.n_own - 2 * oo
             print(f"  rank {r}: owned-owned {oo / 1e6:6.1f} M, owned-ghost {og / 1e6:6.1f} M, evaluated {(oo + og) / 1e6:6.1f} M = "

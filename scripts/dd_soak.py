@@ -13,7 +13,8 @@ s = synthetic_system(name)
 with engine_for(s) as eng:
     st0 = eng.minimize(tolerance=10.0, max_iters=max_iters)
 print(f"{name} single domain: status {st0.status}, {st0.iterations} iterations, E = {st0.e_final:.6g}, rms force {st0.rms_force:.3g}", flush=True)
-KEYS = ("dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_sync_rebuilds", "dd_halts", "dd_capacity_updates", "n3_launches")
+KEYS = ("dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_sync_rebuilds", "dd_halts", "dd_capacity_updates", "n3_launches", "dd_reassignments",
+        "dd_reassign_attempts", "dd_segments_moved")
 for world in worlds:
     engines = [engine_for(s, rank=r, world=world) for r in range(world)]
     Engine.comm_init_local(engines)
@@ -37,4 +38,6 @@ for world in worlds:
     print(f"{name} {world} ranks: status {st[0]}, {st[1]} iterations ({st[2]} evaluations), E = {st[3]:.6g} ({100 * (st[3] - st0.e_final) / abs(st0.e_final):+.2f} % "
           f"against one domain), rms force {st[4]:.3g}; halts {g[0]['dd_halts']:.0f}, synchronous rebuilds {g[0]['dd_sync_rebuilds']:.0f}, message resizes "
           f"{g[0]['dd_capacity_updates']:.0f}; mean bytes per evaluation per rank {np.mean([x['dd_bytes_sent'] / max(x['dd_exchanges'], 1) for x in g]) / 1e6:.2f} MB; "
-          f"half-shell launches on rank 0: {g[0]['n3_launches']:.0f}", flush=True)
+          f"half-shell launches on rank 0: {g[0]['n3_launches']:.0f}; segment re-assignments {g[0]['dd_reassignments']:.0f} of "
+          f"{g[0]['dd_reassign_attempts']:.0f} attempts ({g[0]['dd_segments_moved']:.0f} segments moved); ghosts at the end "
+          f"min/mean/max {min(x['dd_ghosts'] for x in g):.0f}/{np.mean([x['dd_ghosts'] for x in g]):.0f}/{max(x['dd_ghosts'] for x in g):.0f}", flush=True)

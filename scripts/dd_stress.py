@@ -38,7 +38,7 @@ for case in range(cases):
             x = e.get_positions()
             e.set_positions(x)
             et, f = e.compute()
-            out[r] = (st.iterations, st.status, x, et, f, e.own_lo, e.n_own, e.get_option("dd_halts"), md_ok)
+            out[r] = (st.iterations, st.status, x, et, f, e.owned_beads(), None, e.get_option("dd_halts"), md_ok)
         except Exception as ex:  # noqa: BLE001
             err.append((r, repr(ex)))
     th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
@@ -55,7 +55,7 @@ for case in range(cases):
         et0, F0 = ref.compute()
     F = np.zeros_like(F0)
     for o in out:
-        F[o[5]:o[5] + o[6]] = o[4]
+        F[o[5]] = o[4]
     ferr = np.abs(F - F0).max() / max(np.abs(F0).max(), 1e-30)
     eerr = np.abs(out[0][3] - et0).max() / max(np.abs(et0).sum(), 1e-30)
     same = all(np.array_equal(o[2], x) and o[0] == out[0][0] for o in out)

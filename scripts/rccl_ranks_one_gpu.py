@@ -34,10 +34,11 @@ def worker(rank, world, port, n_beads, iters, q):
             q.put((rank, "norccl", repr(e)))
             return
         et, f = eng.compute()
+        ids = eng.owned_beads()
         st = eng.minimize(tolerance=0.0, max_iters=iters)
         x = eng.get_positions()
         stats = {k: eng.get_option(k) for k in ("dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_halts", "dd_sync_rebuilds")}
-        q.put((rank, "ok", et, f, eng.own_lo, eng.n_own, (st.iterations, st.status, st.e_initial, st.e_final), x, stats))
+        q.put((rank, "ok", et, f, ids, len(ids), (st.iterations, st.status, st.e_initial, st.e_final), x, stats))
         eng.close()
     except Exception as e:  # noqa: BLE001
         q.put((rank, "error", repr(e)))
@@ -74,7 +75,7 @@ if __name__ == "__main__":
         st0 = eng.minimize(tolerance=0.0, max_iters=iters)
     F = np.zeros_like(F0)
     for r in res:
-        F[r[4]:r[4] + r[5]] = r[3]
+        F[r[4]] = r[3]
     print(f"RCCL, {world} ranks (processes) on one GPU, {n_beads} beads: energies equal on every rank: "
           f"{all(np.array_equal(r[2], res[0][2]) for r in res)}; max |dE| vs one domain {np.abs(res[0][2] - et0).max():.3g}; "
           f"max |dF| / max |F| {np.abs(F - F0).max() / np.abs(F0).max():.3g}; minimization {res[0][6]} vs {(st0.iterations, st0.status, st0.e_initial, st0.e_final)}; "

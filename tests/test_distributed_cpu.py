@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
         got = broadcast_bytes(uid, 128)
         assert got == bytes(range(128))
 
-        s = synthetic_system("gw_200k", n_beads=600, jitter=0.02, seed=0)
+        s = synthetic_system("gw_200k", n_beads=620, jitter=0.02, seed=0)   # 10 segments of 62 beads: two equal slices
         lo, hi = slice_of(s.n_beads, rank, world)
         et, F = Oracle(s, as_float32_inputs=False).eval()
         # forces: every rank contributes its slice, the gathered result is the full force field

@@ -57,12 +57,13 @@ def test_compute_all_reduced_energies_and_owned_forces(world):
     s = synthetic_system("gw_200k", n_beads=5000, jitter=0.02, seed=2, **ALL_ON)
     with engine_for(s) as eng:
         et0, F0 = eng.compute()
-    res = run_ranks(s, world, lambda e: (e.compute(), e.own_lo, e.n_own))
+    res = run_ranks(s, world, lambda e: (e.compute(), e.owned_beads()))
     F = np.zeros_like(F0)
-    for (et, f), lo, no in res:
+    for (et, f), ids in res:
         assert np.allclose(et, et0, rtol=2e-6, atol=1e-6)          # all-reduced totals (fp32 pair sums: order differs)
         assert np.array_equal(et, res[0][0][0])                     # ... bit-identical on every rank
-        F[lo:lo + no] = f
+        F[ids] = f
+    assert sorted(np.concatenate([ids for _, ids in res]).tolist()) == list(range(s.n_beads))   # the ranks partition the beads
     assert np.abs(F - F0).max() <= 1e-5 * np.abs(F0).max()
 
 
@@ -79,18 +80,18 @@ def test_half_shell_pair_kernel_on_decomposed_ranks(world):
         et0, F0 = eng.compute()
 
     def job(e):
-        (et, f), n3 = e.compute(), e.get_option("n3_launches")
+        (et, f), n3, ids = e.compute(), e.get_option("n3_launches"), e.owned_beads()
         st = e.minimize(tolerance=0.0, max_iters=12)
-        return et, f, e.own_lo, e.n_own, n3, (st.iterations, st.status, st.e_initial, st.e_final)
+        return et, f, ids, None, n3, (st.iterations, st.status, st.e_initial, st.e_final)
 
     half = run_ranks(s, world, job, nb_variant=4096)
     full = run_ranks(s, world, job, nb_variant=8192)
     F = np.zeros_like(F0)
-    for (et, f, lo, no, n3, mini), ref in zip(half, full):
+    for (et, f, ids, _, n3, mini), ref in zip(half, full):
         assert n3 >= 1 and ref[4] == 0
         assert np.allclose(et, et0, rtol=2e-6, atol=1e-3), (et, et0)
         assert np.array_equal(et, half[0][0])
-        F[lo:lo + no] = f
+        F[ids] = f
         assert mini[:2] == ref[5][:2]
         assert abs(mini[3] - ref[5][3]) <= 3e-3 * abs(ref[5][2] - ref[5][3])
     assert np.abs(F - F0).max() <= 4e-6 * np.abs(F0).max() + 2e-3
@@ -151,6 +152,49 @@ def test_md_decomposed_matches_single_domain():
     res = run_ranks(s, 2, job)
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][1], res[1][1])
+    assert abs(res[0][0][1] - ref[0][1]) <= 1e-4 * ref[0][1]
+    assert np.abs(res[0][1] - ref[1]).max() < 1e-4
+
+
+def test_md_steps_on_stale_ghost_lists_are_taken_back():
+    """A ghost list that outgrows its message during MD is only seen at a poll, after positions and velocities have been
+    integrated with forces that lacked ghosts.  mmx_md_step then returns MMX_ERR_STATE ("void ... call again") -- and the
+    steps really are void: x, v, xlo and the step counter are put back to the last poll that found the lists in order
+    (round 3 left them where the contaminated steps had taken them).  Messages without any slack (inject_fault bit 2)
+    make that happen every few steps (and would make it happen in EVERY call of more than one step: the first step of a call
+    that has no valid lists builds them synchronously with fresh capacities, so the retries go step by step); the
+    trajectory that comes out of the retries must be the single-domain one."""
+    from multimm_amd.engine import MMXError
+    s = synthetic_system("gw_200k", n_beads=5000, **ALL_ON)
+    with engine_for(s) as eng:
+        eng.minimize(tolerance=0.0, max_iters=60)
+        x_start = eng.get_positions()
+    total = 48
+
+    def job(e, tight):
+        chunk = 1 if tight else 4
+        e.set_positions(x_start)
+        e.md_configure("langevin", dt_ps=0.005, seed=3)
+        e.set_velocities_to_temperature(310.0, seed=3)
+        done, failures = 0, 0
+        while done < total:
+            try:
+                st = e.md_step(chunk)
+                done += chunk
+                assert st.step_count == done
+            except MMXError as exc:
+                assert tight and exc.code == -5 and "taken back" in str(exc), exc
+                assert e.get_option("md_step") == done          # the step counter went back with the state
+                failures += 1
+                assert failures < 200
+        return (st.potential, st.kinetic, st.step_count), e.get_positions(), failures
+
+    with engine_for(s) as eng:
+        ref = job(eng, False)
+    res = run_ranks(s, 3, lambda e: job(e, True), inject_fault=4)
+    assert all(r[0] == res[0][0] and np.array_equal(r[1], res[0][1]) and r[2] == res[0][2] for r in res)
+    assert res[0][2] >= 1, "no list outgrew its message: the test did not exercise the roll-back"
+    assert res[0][0][2] == ref[0][2] == total
     assert abs(res[0][0][1] - ref[0][1]) <= 1e-4 * ref[0][1]
     assert np.abs(res[0][1] - ref[1]).max() < 1e-4
 
@@ -244,26 +288,83 @@ def test_chromosomal_blocks_fall_back_to_the_all_gather():
     def job(e):
         e.minimize(tolerance=0.0, max_iters=3)      # leaves positions of an earlier state in every rank's pos4
         e.set_positions(x1)
-        return e.compute(), e.own_lo, e.n_own, e.get_option("dd_exchanges")
+        return e.compute(), e.owned_beads(), e.get_option("dd_exchanges")
 
     for opts in (dict(), dict(dd_halo=0)):
         res = run_ranks(s, 3, job, **opts)
         F = np.zeros_like(F0)
-        for (et, f), lo, no, nx in res:
+        for (et, f), ids, nx in res:
             assert nx == 0                                          # no halo exchange took place
             assert np.allclose(et, et0, rtol=2e-6, atol=1e-6)
-            F[lo:lo + no] = f
+            F[ids] = f
         assert np.abs(F - F0).max() <= 1e-5 * np.abs(F0).max()
 
 
+def test_segments_are_reassigned_spatially_and_the_minimization_carries_on():
+    """north_star / SURVEY 8e: "the particle domain is spatially decomposed ... re-decompose".  Ownership is a set of
+    62-bead segments per rank; while the structure deforms mmx_minimize re-assigns the segments by recursive bisection of
+    their centroids and the per-bead vectors of L-BFGS migrate with them (csrc/mmx_engine.hpp:dd_reassign).  The
+    optimisation must not notice: same iteration count, energies that differ by rounding only, forces equal to a
+    single-domain engine's at the same positions, every rank the same structure -- and afterwards the ranks still partition
+    the beads, in other pieces than before.  MD steps on the re-assigned handles follow the single-domain trajectory."""
+    s = synthetic_system("gw_200k", n_beads=30000, jitter=0.02, seed=3, **ALL_ON)
+    world, iters = 4, 120
+
+    def job(e):
+        ids0 = e.owned_beads()
+        st = e.minimize(tolerance=0.0, max_iters=iters)
+        x = e.get_positions()
+        et, f = e.compute()
+        ids1 = e.owned_beads()
+        e.md_configure("verlet", dt_ps=0.001, seed=5)
+        e.set_velocities_to_temperature(310.0, seed=5)
+        md = e.md_step(6)
+        x_md = e.get_positions()
+        stats = {k: e.get_option(k) for k in ("dd_reassignments", "dd_reassign_attempts", "dd_segments_moved", "dd_halts")}
+        return (st.iterations, st.status, st.e_initial, st.e_final), x, et, f, ids0, ids1, stats, x_md, md.potential
+
+    fixed = run_ranks(s, world, job, dd_spatial=0)
+    moved = run_ranks(s, world, job, dd_reassign_first=8, dd_reassign_max=32)
+    assert all(o[6]["dd_reassignments"] == 0 for o in fixed)
+    assert all(o[6]["dd_reassignments"] >= 2 and o[6]["dd_segments_moved"] > 0 for o in moved)
+    assert len({tuple(sorted(o[6].items())) for o in moved}) == 1            # every rank took the same decisions
+    for res in (fixed, moved):
+        assert all(o[0] == res[0][0] and np.array_equal(o[1], res[0][1]) for o in res)
+        assert sorted(np.concatenate([o[5] for o in res]).tolist()) == list(range(s.n_beads))
+    assert all(np.array_equal(a[4], b[4]) for a, b in zip(fixed, moved))      # the same initial index ranges
+    assert any(not np.array_equal(o[4], o[5]) for o in moved)                  # ... and other pieces afterwards
+    assert all(np.array_equal(o[4], o[5]) for o in fixed)
+    assert all(len(o[5]) % 62 == 0 or r == max(range(world), key=lambda q: moved[q][5][-1]) for r, o in enumerate(moved))
+    (it_f, st_f, e0_f, e1_f), (it_m, st_m, e0_m, e1_m) = fixed[0][0], moved[0][0]
+    assert (it_f, st_f) == (it_m, st_m) == (iters, 1) and e0_f == e0_m
+    assert abs(e1_m - e1_f) <= 2e-2 * abs(e0_f - e1_f)       # same algorithm, other summation order (DESIGN.md section 9)
+    # forces of the re-assigned ranks against one domain at the same positions
+    x = moved[0][1]
+    with engine_for(s) as ref:
+        ref.set_positions(x)
+        et0, F0 = ref.compute()
+        ref.md_configure("verlet", dt_ps=0.001, seed=5)
+        ref.set_velocities_to_temperature(310.0, seed=5)
+        md0 = ref.md_step(6)
+        x_md0 = ref.get_positions()
+    F = np.zeros_like(F0)
+    for o in moved:
+        assert np.allclose(o[2], et0, rtol=2e-6, atol=1e-3)
+        F[o[5]] = o[3]
+    assert np.abs(F - F0).max() <= 1e-5 * np.abs(F0).max()
+    assert np.abs(moved[0][7] - x_md0).max() <= 2e-6 and abs(moved[0][8] - md0.potential) <= 2e-6 * abs(md0.potential)
+    assert all(np.array_equal(o[7], moved[0][7]) for o in moved)
+
+
 def test_a_rank_must_own_a_bead():
-    """Slices are ceil(N / world) beads: 9 beads on 8 ranks would leave three ranks without any (and their launches
-    without a grid).  mmx_create_dd refuses such a decomposition instead of failing later."""
+    """Slices are whole 62-bead segments, ceil(ceil(N / 62) / world) of them: 200 beads (4 segments) on 3 ranks would leave
+    the third rank without any (and its launches without a grid).  mmx_create_dd refuses such a decomposition instead of
+    failing later."""
     from multimm_amd.engine import MMXError
     with pytest.raises(MMXError) as exc:
-        Engine(9, rank=7, world=8)
+        Engine(200, rank=2, world=3)
     assert exc.value.code == -1 and "too many ranks" in str(exc.value)
-    Engine(9, rank=2, world=3).close()
+    Engine(200, rank=1, world=2).close()
 
 
 def test_local_communicator_argument_checks():
@@ -292,18 +393,19 @@ def test_config5_size_gw_1m_on_8_ranks():
 
     def job(e):
         et, f = e.compute()
+        ids = e.owned_beads()
         g0, slots0 = e.get_option("dd_ghosts"), e.get_option("dd_ghost_slots")
         st = e.minimize(tolerance=0.0, max_iters=10)
         stats = {k: e.get_option(k) for k in ("dd_ghosts", "dd_ghost_slots", "dd_exchanges", "dd_bytes_sent",
                                               "dd_sync_rebuilds", "dd_halts", "n3_launches")}
-        return et, f, e.own_lo, e.n_own, g0, slots0, (st.iterations, st.status, st.e_initial, st.e_final), stats
+        return et, f, ids, len(ids), g0, slots0, (st.iterations, st.status, st.e_initial, st.e_final), stats
 
     res = run_ranks(s, world, job, timeout=900)
     F = np.zeros_like(F0)
-    for et, f, lo, no, *_ in res:
+    for et, f, ids, no, *_ in res:
         assert np.allclose(et, et0, rtol=2e-6, atol=1e-3)
         assert np.array_equal(et, res[0][0])
-        F[lo:lo + no] = f
+        F[ids] = f
     err = np.abs(F - F0).max()
     print(f"gw_1m on 8 ranks: max force difference {err:.3g} of max |F| {np.abs(F0).max():.4g}")
     assert err <= 4e-6 * np.abs(F0).max() + 2e-3       # F_RTOL, F_ATOL of tests/test_gpu_parity.py
