@@ -21,8 +21,9 @@ against one GPU minimizing the same system (never part of `value`).
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (the cell-list
 pair kernel) from HIP events recorded live on the library's stream inside the timed region, and
 "cpu_baseline" = OpenMM's CPU platform when `import openmm` works on the box (probed at run time, kind "openmm"),
-else the in-repo fp64 oracle (kind "port", with the import error recorded) timed on the host cores on a bounded
-sample of the same workload.  With `--replicas-per-gpu 3` (N = 1) a third object, "replicas_per_gpu",
+else (kind "port", with the import error recorded) the repository's own tuned CPU evaluation -- fp32, AVX-512 / AVX2, OpenMP,
+the same L-BFGS (oracle/mmx_cpu_fast.c) -- with the plain fp64 restatement beside it, both timed on the host cores on a
+bounded sample of the same workload.  With `--replicas-per-gpu 3` (N = 1) a third object, "replicas_per_gpu",
 reports -- outside the timed region and never as part of `value` -- the aggregate rate of three independent replicas
 sharing the GPU (`run_ensemble(..., concurrent=3)`): a single minimization leaves the GPU idle in its latency-bound
 launches.  Off by default: its concurrent kernels would mix into a profile of the default command.
@@ -127,8 +128,9 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
     """CPU baseline on this box's host cores, bounded sample.  North star: OpenMM's CPU platform -- probed at run time
     (oracle/openmm_probe.py): when ``import openmm`` works, the same System (built by this repo's host code) is
     minimized by LocalEnergyMinimizer with the same cutoff (kind "openmm"), plus NoCutoff as the reference runs it on a
-    20 000-bead sample of the workload; otherwise (this image) the import error is recorded and the in-repo fp64
-    C+OpenMP oracle with the same cell list and L-BFGS rule is timed (kind "port")."""
+    20 000-bead sample of the workload; otherwise (this image) the import error is recorded and the repository's own CPU
+    code is timed (kind "port"): the tuned fp32 / SIMD / OpenMP evaluation with the same L-BFGS as `value`, and the plain
+    fp64 restatement beside it (`restatement_fp64`)."""
     if budget_s <= 0:
         return None
     from oracle.openmm_probe import probe, openmm_minimize
@@ -147,20 +149,48 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
                           f"system on OpenMM's CPU platform, CutoffNonPeriodic at {system.ff.NB_CUTOFF} nm; {why}",
                 "nocutoff_20k_iters_per_s": nocut["iters_per_s"]}
     orc = Oracle(system)
+    # (a) the tuned port (oracle/mmx_cpu_fast.c): fp32, AVX-512 / AVX2 inner loop over cell-sorted neighbours, OpenMP over cells,
+    # the same L-BFGS -- what a CPU platform does; this is `value`.  (b) the plain fp64 restatement (the checker of the parity
+    # tests: scalar pow()/exp() per pair) for continuity with rounds 1-3.  Each gets half of the budget.
+    from oracle.oracle import lib as orc_lib
+    simd = {2: "AVX-512", 1: "AVX2+FMA", 0: "baseline x86-64"}.get(int(orc_lib().orc_fast_simd_level()), "?")
+    orc.fast_eval()                      # (first call: thread pool, page faults)
+    t0 = time.perf_counter()
+    orc.fast_eval()
+    t_eval = time.perf_counter() - t0
+    iters = int(max(2, min(2000, 0.5 * budget_s / max(t_eval * 1.2, 1e-4))))
+    t0 = time.perf_counter()
+    _, st, swept = orc.fast_minimize(tolerance=0.0, max_iters=iters)
+    dt = time.perf_counter() - t0
+    out = {
+        "value": st.iterations / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+        "implementation": f"tuned port: fp32, {simd} inner loop over cell-sorted neighbours (cells of cutoff / 2, 5x5x5 stencil, "
+                          "every pair from both sides), OpenMP over cells, fp64 reductions, the same liblbfgs control flow; "
+                          "checked against the fp64 restatement (tests/test_oracle.py::test_fast_cpu_baseline_*)",
+        "sample": f"{st.iterations} L-BFGS iterations ({st.evaluations} evaluations, {dt:.1f} s) of the same "
+                  f"{system.n_beads}-bead system from the same start, same cutoff",
+        "evals_per_s": st.evaluations / dt,
+        "lane_pairs_swept_per_s_per_core": swept / dt / max(cores, 1),
+        "openmm": {"available": False, "probe": why,
+                   "note": "the north star's >= 10 x OpenMM-CPU is NOT verified against OpenMM itself (not installable here); "
+                           "`value` is this repository's own tuned CPU evaluation of the same force field"},
+    }
+    budget_left = 0.5 * budget_s
     t0 = time.perf_counter()
     orc.eval()
     t_eval = time.perf_counter() - t0
-    iters = int(max(2, min(50, budget_s / max(t_eval * 1.3, 1e-3))))
+    iters = int(max(2, min(50, budget_left / max(t_eval * 1.3, 1e-3))))
     t0 = time.perf_counter()
     _, st = orc.minimize(tolerance=0.0, max_iters=iters)
     dt = time.perf_counter() - t0
-    return {
-        "value": st.iterations / dt, "unit": "iters/s", "cores": cores, "kind": "port",
-        "sample": f"{st.iterations} L-BFGS iterations ({st.evaluations} evaluations, {dt:.1f} s) of the same "
-                  f"{system.n_beads}-bead system from the same start, fp64 C+OpenMP oracle with the same cutoff",
+    out["restatement_fp64"] = {
+        "value": st.iterations / dt, "unit": "iters/s", "cores": cores,
+        "implementation": "unvectorised fp64 full-shell restatement (oracle/mmx_oracle.c: pow()/exp() per pair, 27-cell sweep per "
+                          "bead): the checker of the parity tests, a reference point of rounds 1-3, not a contender",
+        "sample": f"{st.iterations} L-BFGS iterations ({st.evaluations} evaluations, {dt:.1f} s)",
         "evals_per_s": st.evaluations / dt,
-        "openmm": {"available": False, "probe": why},
     }
+    return out
 
 
 def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress: dict) -> dict:
@@ -470,6 +500,9 @@ def main():
         if os.environ.get("MMX_BENCH_REHEARSAL"):
             out["rehearsal"] = os.environ["MMX_BENCH_REHEARSAL"]
         out["cpu_baseline"] = cpu_baseline(system, args.cpu_seconds) if n_gpus == 1 else None
+        if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
+            # (a reported ratio, not the target's proof: the CPU side is this repository's own code unless kind == "openmm")
+            out["cpu_baseline"]["gpu_over_cpu_iters_per_s"] = out["value"] / out["cpu_baseline"]["value"]
     eng.close()
     if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0 and args.cutoff > 0:
         # what the cutoff changes against the reference's NoCutoff semantics, measured in this run on chr1_50k (BASELINE

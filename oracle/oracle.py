@@ -67,8 +67,8 @@ FORM_NAMES = {
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "mmx_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("mmx_oracle.c", "mmx_cpu_fast.c", "mmx_cpu_fast_sweep.c", "mmx_oracle.h", "Makefile")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", HERE, "-s", "-B" if force else "-s"], check=True)
     return LIB
 
@@ -96,6 +96,11 @@ def lib() -> C.CDLL:
         _lib.orc_md_step_amd.restype = C.c_int
         _lib.orc_md_step_amd.argtypes = [C.POINTER(OrcSystem), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(OrcMdStats)]
+        _lib.orc_fast_eval.restype = C.c_int
+        _lib.orc_fast_eval.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        _lib.orc_fast_minimize.restype = C.c_int
+        _lib.orc_fast_minimize.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_double, C.c_int, C.POINTER(OrcMinStats),
+                                           C.POINTER(C.c_double)]
         assert _lib.orc_sizeof_system() == C.sizeof(OrcSystem), "OrcSystem layout mismatch"
     return _lib
 
@@ -212,6 +217,33 @@ class Oracle:
             raise MemoryError("oracle allocation failed")
         return x, st
 
+
+    # ---- the tuned CPU baseline (mmx_cpu_fast.c): fp32, SIMD, OpenMP; default functional forms, cutoff only ----------
+    def fast_eval(self, positions=None):
+        """(energy_terms, forces [N,3], lane-pairs swept) of the tuned fp32 CPU evaluation; raises NotImplementedError for
+        systems it does not cover (non-default forms, NoCutoff, chromosomal blocks)."""
+        x = self._pos(positions)
+        F = np.zeros_like(x)
+        et = np.zeros(N_TERMS)
+        swept = C.c_double(0.0)
+        rc = lib().orc_fast_eval(C.byref(self.o), x.ctypes.data, F.ctypes.data, et.ctypes.data, C.byref(swept))
+        if rc == -2:
+            raise NotImplementedError("the tuned CPU baseline covers the default functional forms with a cutoff only")
+        if rc != 0:
+            raise MemoryError("allocation failed")
+        return et, F, swept.value
+
+    def fast_minimize(self, tolerance: float = 10.0, max_iters: int = 0, positions=None):
+        """The L-BFGS of ``minimize`` on the tuned evaluation.  Returns (positions, OrcMinStats, lane-pairs swept)."""
+        x = self._pos(positions).copy()
+        st = OrcMinStats()
+        swept = C.c_double(0.0)
+        rc = lib().orc_fast_minimize(C.byref(self.o), x.ctypes.data, float(tolerance), int(max_iters), C.byref(st), C.byref(swept))
+        if rc == -2:
+            raise NotImplementedError("the tuned CPU baseline covers the default functional forms with a cutoff only")
+        if rc != 0:
+            raise MemoryError("allocation failed")
+        return x, st, swept.value
 
     def md_step(self, x, v, n_steps, kind="langevin", dt=0.001, temperature=310.0, friction=0.5,
                 mass=16427.889, seed=0, step0=0, amd_alpha=100.0, amd_e=1000.0):

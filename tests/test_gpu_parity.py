@@ -339,6 +339,7 @@ def test_domain_decomposition_owned_ranges():
     """Multi-GPU ownership logic on one GPU: `world` handles in one process, each evaluating its own bead
     slice against the whole system's positions (no communicator needed for a single evaluation).  Forces
     concatenate to the single-domain result and the per-rank energy shares add up to the total."""
+    from multimm_amd.parallel import slice_of
     from oracle.oracle import Oracle
     s = synthetic_system("gw_200k", n_beads=20000, jitter=0.03, seed=5, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_DE=0.05,
                          **ALL_ON)
@@ -348,7 +349,7 @@ def test_domain_decomposition_owned_ranges():
         parts = []
         for r in range(world):
             with engine_for(s, rank=r, world=world) as eng:
-                assert eng.own_lo == r * ((s.n_beads + world - 1) // world)
+                assert (eng.own_lo, eng.own_lo + eng.n_own) == slice_of(s.n_beads, r, world)   # whole 62-bead segments
                 et, f = eng.compute()
                 assert f.shape == (eng.n_own, 3)
                 et_sum += et

@@ -1,6 +1,8 @@
 """CPU tests of the oracle itself: hand-derivable known answers, finite differences
 of its own energy, C vs numpy restatement, reference index quirks, Hilbert start, L-BFGS restatement.
 The reference holds no golden vectors for this path ("parity unpinned"): these tests are what pins it."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -420,3 +422,42 @@ def test_oracle_cutoff_is_plain_truncation(oracle_lib):
     e_all = Oracle(s, cutoff=0.0, as_float32_inputs=False).eval()[0]
     e_big = Oracle(s, cutoff=big, as_float32_inputs=False).eval()[0]
     assert np.allclose(e_all, e_big, rtol=1e-12, atol=1e-10)
+
+
+# ---- the tuned CPU baseline (oracle/mmx_cpu_fast.c): bench.py's second cpu_baseline, itself checked against the restatement
+def test_fast_cpu_baseline_equals_the_fp64_restatement(oracle_lib):
+    """fp32 / SIMD / OpenMP evaluation of the default force field against the fp64 restatement on the same (fp32-rounded)
+    inputs: every term within 2e-6 of the summed energies, forces within 4e-6 of the largest component -- the tolerances of
+    the GPU parity tests -- on the lattice-dense jittered start, a relaxed state and a sparse one (cells nearly empty)."""
+    from oracle.oracle import Oracle
+    full = dict(SC_USE_SPHERICAL_CONTAINER=True, COB_USE_COMPARTMENT_BLOCKS=True, SCB_USE_SUBCOMPARTMENT_BLOCKS=True,
+                IBL_USE_B_LAMINA_INTERACTION=True, CF_USE_CENTRAL_FORCE=True)
+    for n, jitter, scale in ((6000, 0.03, 1.0), (3000, 0.02, 2.5), (500, 0.05, 9.0)):
+        s = synthetic_system("gw_200k", n_beads=n, jitter=jitter, seed=3, NB_CUTOFF=0.6, **full)
+        s = dataclasses.replace(s, positions=s.positions * scale)      # thinned out: bonds stretched, few pairs inside the cutoff
+        o = Oracle(s)
+        et0, F0 = o.eval()
+        et, F, swept = o.fast_eval()
+        assert np.all(np.abs(et - et0) <= 2e-6 * np.abs(et0).sum() + 1e-3), (n, et, et0)
+        assert np.abs(F - F0).max() <= 4e-6 * np.abs(F0).max() + 2e-3, n
+        assert swept >= n
+    # what it does not cover is refused, not approximated
+    with pytest.raises(NotImplementedError):
+        Oracle(synthetic_system("gw_200k", n_beads=300, NB_CUTOFF=0.0)).fast_eval()
+    with pytest.raises(NotImplementedError):
+        Oracle(synthetic_system("gw_200k", n_beads=300, NB_CUTOFF=0.6, EV_FORCE_TYPE="gaussian_core")).fast_eval()
+
+
+def test_fast_cpu_baseline_minimizes_like_the_restatement(oracle_lib):
+    """The same liblbfgs control flow on the tuned evaluation: identical iteration / evaluation counts on a jittered start
+    over 25 iterations and energies that agree to fp32 trajectory noise."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("gw_200k", n_beads=4000, jitter=0.03, seed=5, NB_CUTOFF=0.6)
+    o = Oracle(s)
+    x0, st0 = o.minimize(10.0, 25)
+    x1, st1, swept = o.fast_minimize(10.0, 25)
+    assert (st1.iterations, st1.status) == (st0.iterations, st0.status) == (25, 1)
+    assert st1.e_initial == pytest.approx(st0.e_initial, rel=2e-6)
+    assert abs(st1.e_final - st0.e_final) <= 2e-2 * abs(st0.e_initial - st0.e_final)
+    assert abs(o.energy(x1) - st1.e_final) <= 2e-6 * abs(st1.e_final) + 1e-2     # the energy it reports is the energy of its point
+    assert swept > 0
