@@ -134,8 +134,10 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
     if budget_s <= 0:
         return None
     from oracle.openmm_probe import probe, openmm_minimize
-    from oracle.oracle import Oracle, max_threads
-    cores = max_threads()
+    from oracle.oracle import Oracle, cpu_share, max_threads, set_threads
+    hw_threads = max_threads()
+    cores = min(hw_threads, cpu_share())      # what the job may use (affinity mask, cgroup quota), not what the box has
+    set_threads(cores)
     mm, why = probe()
     if mm is not None:
         from multimm_amd import synthetic_system
@@ -163,7 +165,7 @@ def cpu_baseline(system, budget_s: float) -> dict | None:
     _, st, swept = orc.fast_minimize(tolerance=0.0, max_iters=iters)
     dt = time.perf_counter() - t0
     out = {
-        "value": st.iterations / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+        "value": st.iterations / dt, "unit": "iters/s", "cores": cores, "hardware_threads_of_the_box": hw_threads, "kind": "port",
         "implementation": f"tuned port: fp32, {simd} inner loop over cell-sorted neighbours (cells of cutoff / 2, 5x5x5 stencil, "
                           "every pair from both sides), OpenMP over cells, fp64 reductions, the same liblbfgs control flow; "
                           "checked against the fp64 restatement (tests/test_oracle.py::test_fast_cpu_baseline_*)",
@@ -290,6 +292,26 @@ def emit(obj: dict) -> None:
         os.write(_JSON_FD, line)
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT initialising the HIP runtime (torch.cuda.device_count() falls through to
+    hipGetDeviceCount on builds without amdsmi): the visibility variables first, else the KFD topology (nodes with SIMDs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        n += 1
+    except OSError:
+        return 0
+    return n
+
+
 def spawn_ranks(args) -> int:
     """`bench.py --gpus N` without a launcher: start N rank processes as ONE child (torch.distributed.run, which starts
     the ranks) before this process has made any GPU call -- it never makes one --, hand their JSON line through and
@@ -300,8 +322,14 @@ def spawn_ranks(args) -> int:
     sites of the decomposed leg run with N ranks.  The line says so; its numbers are not a scaling measurement."""
     import socket
     import subprocess
-    import torch  # device_count() does not initialise the GPU
-    ndev = torch.cuda.device_count()
+    # A process whose GPU runtime is initialised must not start the launcher: under rocprofv3 the profiler's preloaded tool
+    # library has done that before this line runs (the pool forbids such a hop after `--`).  Profile one rank directly.
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    if "rocprof" in preload.lower():
+        print("bench.py --gpus N starts its own rank processes and cannot do that from under rocprofv3; profile a rank "
+              "directly: rocprofv3 ... -- python3 bench.py (one GPU), or give the launcher line to the profiler's child", file=sys.stderr)
+        return 6
+    ndev = visible_gpu_count()   # counted without touching HIP: this parent must never hold the GPU
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if ndev < args.gpus:
@@ -425,12 +453,12 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))["bytes_per_launch"]
                 except Exception:
                     traffic = None
-            # the cell-list path picks its pair kernel per state: name the one that ran, and how often
+            # the cell-list path picks its pair kernel per state (DESIGN_HISTORY.md 5c): name the one that ran, and how often
             n3_share = (eng.get_option("n3_launches") - n3_before) / max(st.kernel_launches[K_NONBONDED], 1)
             kname = ("k_nb_allpairs" if args.cutoff <= 0 else "k_nb_n3" if n3_share > 0.99 else "k_nb_clusters_j" if n3_share < 0.01
                      else f"k_nb_n3 ({100 * n3_share:.0f} % of the launches: the dense phase), then k_nb_clusters_j")
             # what bounds the kernel: VALU issue of the pair arithmetic + culls, and latency (4 waves per SIMD, a third of
-            # the wave cycles waiting: DESIGN.md 5c) -- not HBM.  achieved/peak/frac are the HBM view the metric asks for
+            # the wave cycles waiting: DESIGN_HISTORY.md 5c) -- not HBM.  achieved/peak/frac are the HBM view the metric asks for
             # (algorithmic bytes / launch time against 8 TB/s); valu_view prices the same launch against the fp32 peak.
             roofline = {"bound": "valu+latency", "kernel": kname,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -205,7 +205,7 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     evaluation of a minimization (one event pair: more samples of the dominant kernel) 0
  * "use_graph"         1: replay the minimizer's trial evaluations from a hipGraph ("graph_evals" of them
  *                     per graph, even) instead of launching them one by one; same bits; slower on
- *                     ROCm 7.2 at every size measured, kept for A/B     0
+ *                     ROCm 7.2 at every size measured (DESIGN_HISTORY.md 5b), kept for A/B     0
  * "dd_halo"           decomposed runs with a communicator: 1 = ghost-bead halo exchange (ghosts chosen by the
  *                     peers' need-maps -- coarse-cell occupancy grown by the cutoff --, ncclSend/ncclRecv of the
  *                     listed beads per evaluation); 0 = all-gather of every position per evaluation (round-1 path,
@@ -221,6 +221,14 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     changes nothing); 0: ownership stays the initial index ranges                         1
  * "dd_reassign_first", "dd_reassign_max"   see "dd_spatial"                                                48, 768
  * "dd_reassignments", "dd_reassign_attempts", "dd_segments_moved"   (get only) statistics of it
+ * "cell_edge_auto"    1: once a poll finds fewer than 32 beads per cutoff-sized grid cell (systems of >= 20 000 beads) the grid
+ *                     switches to cells 1.12 x wider (same results: the box tests are exact; the in-cell ordering is a
+ *                     latency chain per cell, fewer and fuller cells take 8-10 us off the cell build for +2 us of pair
+ *                     kernel at 200 000 beads: profiles/r04_cell_edge_cost.txt; chr1_50k +7 %, gw_200k +1.5 % iterations/s
+ *                     from 1 000 iterations on); 0: cells of edge cutoff throughout                              1
+ * "cell_edge_scale"   measurement only: grid cells of edge scale x cutoff (>= 1).  Results are unchanged (the box tests
+ *                     stay exact); the pair kernels see more candidates -- what cells of edge cutoff + skin, the price of
+ *                     keeping the cell structure over several evaluations, would cost them (scripts/cell_edge_cost.py)   1
  * "md_step"           (get only) MD steps integrated so far; after an MMX_ERR_STATE of mmx_md_step on a decomposed run (a ghost
  *                     list went out of date: the steps since the last poll were taken back) it says where to go on from
  * "dd_us_needmap_allgather", "dd_us_halo_exchange", "dd_us_allreduce", "dd_collective_samples"
@@ -236,7 +244,7 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     wire in them; list rebuilds (all / host-synchronous); evaluations voided and repeated;
  *                     polls that resized a message
  * nb_variant bits:    4096 force the half-shell pair kernel, 8192 force the full-shell one (default: chosen by
- *                     system size and cell occupancy); bits 24-30 configure the tail shares of the
+ *                     system size and cell occupancy, DESIGN_HISTORY.md 5c); bits 24-30 configure the tail shares of the
  *                     half-shell kernel (A/B); the other bits select round-1 A/B and diagnosis instances
  * "poll_interval"     evaluations enqueued between host polls of the device state     32
  * "nb_variant"        non-bonded kernel variant (0 = default)                         0

@@ -586,6 +586,8 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "inject_fault") h->inject_fault = (int)value;
     else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
+    else if (k == "cell_edge_auto") { h->cell_edge_auto = value != 0.0; h->edge_auto = 1.f; }
+    else if (k == "cell_edge_scale") { h->cell_edge_scale = (float)std::max(1.0, value); h->grid_ready = false; }
     else if (k == "dd_spatial") h->dd_spatial = value != 0.0;
     else if (k == "dd_reassign_first") h->dd_reassign_first = std::max(1, (int)value);
     else if (k == "dd_reassign_max") h->dd_reassign_max = std::max(1, (int)value);

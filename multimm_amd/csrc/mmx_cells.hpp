@@ -375,7 +375,7 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const ScanArgs a, MinState *
 
 // 12-bit Hilbert index of a position inside its cell (16 sub-cells per axis; Skilling's axes -> transpose, 4 bits).  Eight
 // consecutive beads of a Hilbert-ordered cell form a tighter cluster than eight of a Morton-ordered one (the Z curve
-// jumps): measured on gw_200k states, 53 % of the swept lanes inside the cutoff instead of 48 %.
+// jumps): measured on gw_200k states, 53 % of the swept lanes inside the cutoff instead of 48 % (DESIGN_HISTORY.md 5c).
 __device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00d
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
@@ -696,8 +696,14 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             __threadfence_block();
             __syncthreads();
         }
-        else if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
-        // cells above CAP beads keep arrival order (still correct, not bitwise reproducible)
+        else if (threadIdx.x == 0) {
+            atomicAdd(&st->order_fallbacks, 1);
+            // cells above CAP beads keep arrival order: still correct on a single domain (not bitwise reproducible); on a
+            // decomposed rank the clusters below would mix owned beads and ghosts -- emit_clusters takes the first `no`
+            // entries of the sorted cell for the owned ones -- and the half-shell kernel's per-cluster ownership with them:
+            // the evaluation is void (decomposed handles always run the CAP = 4096 instance: > 4096 beads in one cell)
+            if (count_own) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
+        }
         emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead);
     }
 }

@@ -114,7 +114,8 @@ struct FormParams {
 
 // MinState::kernel_error bits
 enum KernelError { KERR_N3_SPIN = 1,   // k_nb_n3: a wave waited for a unit / flush that never came (protocol bug)
-                   KERR_N3_ITEMS = 2 }; // k_nb_n3's item list is too short for this cell build
+                   KERR_N3_ITEMS = 2,  // k_nb_n3's item list is too short for this cell build
+                   KERR_ORDER_DD = 4 }; // decomposed rank: a cell too large for the in-cell sort would mix owned beads and ghosts
 
 // Device-resident minimizer state; mirrored to pinned host memory when polled.
 struct MinState {

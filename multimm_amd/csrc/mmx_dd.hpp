@@ -100,10 +100,13 @@ __global__ void k_dd_grid(const float *__restrict__ boxes, int world, float reac
         ext = fmaxf(ext, hi[k] - lo[k]);
     }
     DDGrid G;
-    G.edge = fmaxf(0.5f * reach, ext * (1.f / (float)(kDDGridN - 4)));
+    // edge a hair above reach / 2, radius = ceil(reach / edge) with NO tolerance taken off: a map must reach at least `reach`
+    // beyond the cell of an owned bead (round 3 took 1e-4 off before rounding up: with reach / edge in (2, 2.0001] a pair
+    // between edge * 2 and reach apart could lose its ghost)
+    G.edge = fmaxf(0.50005f * reach, ext * (1.f / (float)(kDDGridN - 4)));
     if (!(G.edge > 1e-6f) || !(G.edge < 1e30f)) G.edge = 1.f;
     G.inv_edge = 1.f / G.edge;
-    G.radius = max(1, (int)ceilf(reach * G.inv_edge - 1e-4f));
+    G.radius = max(1, (int)ceilf(reach * G.inv_edge));
     G.ox = lo[0] - 2.f * G.edge;
     G.oy = lo[1] - 2.f * G.edge;
     G.oz = lo[2] - 2.f * G.edge;

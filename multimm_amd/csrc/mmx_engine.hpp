@@ -36,11 +36,16 @@ bool all_pairs(const mmx_handle_s *h) {
 }
 bool has_nb(const mmx_handle_s *h) { return h->P.use_ev || h->P.use_gauss; }
 
+// cells of edge factor x cutoff: the measurement option, else what the polls chose (cell_edge_auto)
+float edge_factor(const mmx_handle_s *h) {
+    if (h->cell_edge_scale > 1.f) return h->cell_edge_scale;
+    return h->cell_edge_auto ? std::max(h->edge_auto, 1.f) : 1.f;
+}
 float hmin_of(const mmx_handle_s *h) {
     float rc = 0.f;
     if (h->P.use_ev) rc = std::max(rc, h->ev_cut);
     if (h->P.use_gauss) rc = std::max(rc, h->g_cut);
-    return rc * 1.001f;
+    return rc * 1.001f * edge_factor(h);
 }
 
 // OPT template bits of the cluster-kernel instance that nb_variant selects (see launch_nb_cells_p).
@@ -116,6 +121,9 @@ void refresh_params(mmx_handle_s *h) {
 }
 
 // choice of the pair kernel: see use_n3
+constexpr double kWideCellsBelow = 32.0; // beads per cutoff-sized cell under which the grid switches to cells kWideCellFactor wider
+constexpr float kWideCellFactor = 1.12f;
+constexpr int kWideCellsFromBeads = 20000;
 constexpr double kN3MinBeadsPerCell = 20.0;
 constexpr int kN3MinBeads = 100000;
 
@@ -623,7 +631,7 @@ bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
 int dd_rebuild(mmx_handle_s *h, bool sync) {
     const int gb = std::max((h->n_own + 255) / 256, 1);
     const size_t W = (size_t)h->world;
-    const float reach = hmin_of(h) / 1.001f + (h->dd_every > 1 ? h->dd_skin_cur : 0.f);
+    const float reach = hmin_of(h) / (1.001f * edge_factor(h)) + (h->dd_every > 1 ? h->dd_skin_cur : 0.f);
     if (sync) {
         hipLaunchKernelGGL(k_dd_bbox, dim3(1), dim3(256), 0, h->stream, h->bbox_part, (h->n_own + 255) / 256,
                            h->dd_boxes + 6 * h->rank);
@@ -759,7 +767,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
         if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
             hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
-                               dd ? hm : 0.f, cur, h->st);
+                               dd ? hm / edge_factor(h) : 0.f, cur, h->st); // (grown by the cutoff, whatever the cell edge)
         const int gl = (h->n_own + h->dd_nghost + 255) / 256; // owned beads + listed ghosts
         if (halo)
             hipLaunchKernelGGL(k_cell_count_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, own_of(h),
@@ -790,7 +798,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                                h->start, h->perm, h->okeys, h->pos4, cur, own_of(h), h->st);
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order; the work items
         // of the half-shell pair kernel are built by extra workgroups of the same launch (k_order_items)
-        const bool small_cells = h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
+        // (decomposed ranks always take the 4096-bead instance: a cell that outgrows the sort is an error there, see cell_order_block)
+        const bool small_cells = !dd && h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
         const int go = small_cells ? 2048 : 1024;
         h->n3_build = use_n3(h); // latched per build: the pair kernel that follows must be the one whose work items exist
         if (h->n3_build) {
@@ -962,14 +971,15 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
 // once per mmx_minimize call and replayed.  The key holds every host-side quantity that shapes the launches; when a
 // poll changes one of them the graph is captured again.
 struct GraphKey {
-    int items, clusters, order_cap, n3, parity;
+    int items, clusters, order_cap, n3, parity, wide;
     bool operator==(const GraphKey &o) const {
-        return items == o.items && clusters == o.clusters && order_cap == o.order_cap && n3 == o.n3 && parity == o.parity;
+        return items == o.items && clusters == o.clusters && order_cap == o.order_cap && n3 == o.n3 && parity == o.parity &&
+               wide == o.wide;
     }
 };
 GraphKey graph_key(const mmx_handle_s *h) {
     return GraphKey{h->last_items, h->last_clusters, (h->last_max_per_cell > 0 && h->last_max_per_cell <= 640) ? 1 : 0,
-                    use_n3(h) ? 1 : 0, h->build_idx & 1};
+                    use_n3(h) ? 1 : 0, h->build_idx & 1, edge_factor(h) > 1.f ? 1 : 0};
 }
 void graph_drop(mmx_handle_s *h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
@@ -1037,7 +1047,16 @@ int pull_state(mmx_handle_s *h) {
     if (h->st_host->n_items > 0) h->last_items = h->st_host->n_items;
     if (h->st_host->n_clusters > 0) h->last_clusters = h->st_host->n_clusters;
     if (h->st_host->max_per_cell > 0) h->last_max_per_cell = h->st_host->max_per_cell;
-    if (h->st_host->ncells > 0) h->last_ncells = h->st_host->ncells;
+    if (h->st_host->ncells > 0) {
+        h->last_ncells = h->st_host->ncells;
+        // beads per cutoff-sized cell of the build just read back (the grid in force may already be the wider one)
+        const double f = edge_factor(h);
+        const double per_cell = (double)local_beads(h) / ((double)h->last_ncells * f * f * f);
+        // wider cells once the structure has thinned out.  Measured (scripts/wide_cells_ab.py, iterations 1000-2000): a fixed
+        // 1.12 gives chr1_50k 11 140 -> 11 970 it/s, gw_200k 4 350 -> 4 415; cells sized for ~40 beads each (up to 1.6 x the
+        // cutoff) are no better (11 870 / 4 400) and cost region_5k 1.4 %, where 1.12 is neutral: small systems keep the cutoff
+        h->edge_auto = (per_cell < kWideCellsBelow && local_beads(h) >= kWideCellsFromBeads) ? kWideCellFactor : 1.f;
+    }
     if (h->comm && g_rccl.CommGetAsyncError && !h->coll_failed) { // errors RCCL found after the call returned
         ncclResult_t ar = ncclSuccess;
         if (g_rccl.CommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
@@ -1059,6 +1078,7 @@ int kernel_error_rc(mmx_handle_s *h) {
     std::string what;
     if (ke & KERR_N3_SPIN) what += " k_nb_n3: a wave waited for a work unit or a window flush that never came;";
     if (ke & KERR_N3_ITEMS) what += " k_nb_n3: the work-item list is too short for this cell build;";
+    if (ke & KERR_ORDER_DD) what += " cell build of a decomposed rank: a cell holds more than 4096 beads, owned beads and ghosts cannot be kept in separate clusters;";
     if ((ke & 0xff) == 0) what += " reported by another rank;";
     return fail(h, MMX_ERR_STATE, "a force kernel could not do its work, the evaluation is void:" + what +
                                   " forces and energies of this call must not be used");

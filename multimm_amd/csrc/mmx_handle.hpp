@@ -268,8 +268,15 @@ struct mmx_handle_s {
     // options
     int deterministic = 0, profile = 0, poll_interval = 32, nb_variant = 0, fused_bonded = 1, overlap_bonded = 1;
     // hipGraph of consecutive minimizer evaluations (captured per mmx_minimize call, see graph_capture).  OFF by default:
-    // on ROCm 7.2 / MI355X replaying loses to launch-by-launch submission at every size measured
+    // on ROCm 7.2 / MI355X replaying loses to launch-by-launch submission at every size measured (DESIGN_HISTORY.md 5b)
     int use_graph = 0, graph_evals = 2; // evaluations per graph (even: the cell grid ping-pongs)
+    // Grid cells wider than the cutoff once the structure has thinned out (set at the polls, see pull_state): below ~32 beads
+    // per cutoff-sized cell the in-cell ordering is a latency chain per cell and 1.12 x wider cells (1.4 x the beads each)
+    // take 8-10 us off the cell build for +2 us of pair kernel at 200 000 beads (profiles/r04_cell_edge_cost.txt); denser
+    // states and systems below 20 000 beads lose or gain nothing.
+    int cell_edge_auto = 1;      // option: 0 = cells of edge cutoff throughout (A/B)
+    float edge_auto = 1.f;       // the factor in force
+    float cell_edge_scale = 1.f; // measurement only (option cell_edge_scale): grid cells of edge scale * cutoff -- what a Verlet skin would cost the pair kernels
     int inject_fault = 0; // tests only: bit 0 = every wait of k_nb_n3 times out at once, bit 1 = its item list holds one item
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;

@@ -51,6 +51,14 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+/* OpenMP threads of the calls that follow (bench.py: the CPU share of the box, not its hardware thread count) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------
  * Hilbert curve: hilbertcurve 2.0.5 HilbertCurve(p, n).point_from_distance (Skilling 2004,

@@ -301,3 +301,30 @@ def backbone_flags_c(n_beads: int, chr_ends) -> np.ndarray:
 
 def max_threads() -> int:
     return int(lib().orc_max_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+def cpu_share() -> int:
+    """Cores this process may actually use: the scheduler affinity mask, cut by the cgroup CPU quota when there is one (a
+    GPU box hands a job 16 of its 128 hardware threads: 128 OpenMP threads on them only get in each other's way)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)

@@ -1,5 +1,5 @@
 """Time of the whole cell-build slot (pack, scan + bonded, fill, in-cell order) at the lattice start of gw_200k; used with builds
-that compile a step of k_cell_order out.  usage: [MMX_LIB=...] cell_build_time.py"""
+that compile a step of k_cell_order out (DESIGN_HISTORY.md 10).  usage: [MMX_LIB=...] cell_build_time.py"""
 import sys
 sys.path.insert(0, '.')
 from multimm_amd import synthetic_system

@@ -17,6 +17,8 @@ s = synthetic_system(name)
 def tail(e, label):
     diag = int(sys.argv[sys.argv.index("--diag") + 1]) if "--diag" in sys.argv else 0
     nbv = 4096 + (int(sys.argv[sys.argv.index("--nbv") + 1]) if "--nbv" in sys.argv else 0)   # e.g. 16384: the DD instance
+    if "--help-min" in sys.argv:      # chunk sharing (profiles/r04_experiments/n3_chunk_sharing.patch applied: option n3_help; 0 = off)
+        e.set_option("n3_help", int(sys.argv[sys.argv.index("--help-min") + 1]))
     cnt = np.zeros(16, np.uint64)
     e.set_option("nb_variant", nbv + ((diag | 128) << 16))        # a counting launch (slow: contended atomics at its end)
     lib.mmx_debug_n3_counters(C.c_void_p(cnt.ctypes.data), 1)

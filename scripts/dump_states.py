@@ -1,5 +1,5 @@
 """Writes the positions of gw_200k after 60 / 400 / 2000 iterations to gpurun_out/pos_<n>.npy (input of offline analyses such as
-the cluster-compactness comparison of DESIGN.md 5c).  usage: dump_states.py"""
+the cluster-compactness comparison of DESIGN_HISTORY.md 5c).  usage: dump_states.py"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np

@@ -356,6 +356,35 @@ def test_segments_are_reassigned_spatially_and_the_minimization_carries_on():
     assert all(np.array_equal(o[7], moved[0][7]) for o in moved)
 
 
+def test_a_cell_too_large_for_the_in_cell_sort_voids_the_evaluation_on_a_decomposed_rank():
+    """More than 4096 beads in one grid cell: the in-cell sort keeps arrival order there.  A single domain lives with that
+    (results to rounding); on a decomposed rank the cell's owned beads and ghosts would no longer form separate clusters
+    and the half-shell kernel's per-cluster ownership -- energy weights, ghost-ghost cull -- would be wrong, silently.  The
+    cell build flags it and the call ends in MMX_ERR_STATE instead (round-3 advisor finding)."""
+    from multimm_amd.engine import MMXError
+    from multimm_amd.system import ChromatinSystem, ForceFieldParams
+    rng = np.random.default_rng(4)
+    n = 12400
+    ff = ForceFieldParams(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+                          COB_USE_COMPARTMENT_BLOCKS=True, NB_CUTOFF=0.6)
+    x = rng.uniform(0.0, 6.0, (n, 3))
+    x[::2] = rng.uniform(2.7, 2.95, (n // 2, 3))          # 6 200 beads inside one 0.6 nm cell, owned by both ranks alike
+    s = ChromatinSystem(n, x, np.array([0, n]), rng.choice(np.array([-2, -1, 0, 1, 2], np.int8), n), ff=ff)
+    with engine_for(s) as eng:
+        et0, _ = eng.compute()                             # one domain: fine
+        assert eng.get_option("order_fallbacks") >= 1
+
+    def job(e):
+        try:
+            e.compute()
+        except MMXError as exc:
+            return exc.code, str(exc)
+        return 0, ""
+
+    for code, text in run_ranks(s, 2, job):
+        assert code == -5 and "4096 beads" in text, (code, text)
+
+
 def test_a_rank_must_own_a_bead():
     """Slices are whole 62-bead segments, ceil(ceil(N / 62) / world) of them: 200 beads (4 segments) on 3 ranks would leave
     the third rank without any (and its launches without a grid).  mmx_create_dd refuses such a decomposition instead of
