@@ -221,6 +221,20 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     changes nothing); 0: ownership stays the initial index ranges                         1
  * "dd_reassign_first", "dd_reassign_max"   see "dd_spatial"                                                48, 768
  * "dd_reassignments", "dd_reassign_attempts", "dd_segments_moved"   (get only) statistics of it
+ * "cell_reuse"        1: single-domain minimizations keep the cell structure of a full build -- membership, cluster composition,
+ *                     work items -- for up to 16 evaluations once the structure has thinned out (the grid is then 1.3 x
+ *                     (half-shell kernel) / 1.45 x (full-shell) the cutoff wide: "cell_reuse_factor"); in between only
+ *                     cluster positions and boxes are refreshed.  Exact while no bead has moved more than half the skin from
+ *                     where it was binned: k_pack checks every evaluation, a violation voids the evaluation, which is
+ *                     repeated after a full build; how long a structure serves follows the displacements read back at the
+ *                     polls.  Iterations 1000-2000: chr1_50k +15 %, gw_200k +4.5 % iterations/s; the first few hundred
+ *                     iterations from the lattice are unaffected (no skin there).  0: a full build per evaluation      1
+ * "cell_builds", "cell_reuses", "cell_stale_halts", "cell_reuse_K"   (get only) statistics of it
+ * "cell_slots"        1: the trial moves of a single-domain minimization write their 64-bit sort keys straight into per-cell
+ *                     slots (a table sized from the last poll's cell count and fullest cell), so the counting sort's fill
+ *                     launch disappears; same keys, same clusters, bitwise the same minimization (+1 % iterations/s).  A
+ *                     state that outgrows the table voids its evaluation, which is repeated with a larger one
+ *                     ("cell_slot_halts"); 0: k_cell_fill after the scan                                          1
  * "cell_edge_auto"    1: once a poll finds fewer than 32 beads per cutoff-sized grid cell (systems of >= 20 000 beads) the grid
  *                     switches to cells 1.12 x wider (same results: the box tests are exact; the in-cell ordering is a
  *                     latency chain per cell, fewer and fuller cells take 8-10 us off the cell build for +2 us of pair
@@ -264,7 +278,8 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
  *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE;
  *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a
- *                     ghost list exercises the halt-and-repeat protocol                                          0
+ *                     ghost list exercises the halt-and-repeat protocol; bit 3 gives a kept cell structure ("cell_reuse")
+ *                     a skin of nothing, so that every evaluation on one is voided and repeated after a full build    0
  */
 int mmx_set_option(mmx_handle h, const char *key, double value);
 int mmx_get_option(mmx_handle h, const char *key, double *value);

@@ -78,6 +78,7 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
         HIPCHK(h, dalloc(&h->g, nv));
         HIPCHK(h, dalloc(&h->gp, nv));
         HIPCHK(h, dalloc(&h->d, nv));
+        if (world == 1) HIPCHK(h, dalloc(&h->cell_xref, nv)); // kept cell structure: where its beads were binned (cell_reuse)
         HIPCHK(h, dalloc(&h->S, nv * MMX_M));
         HIPCHK(h, dalloc(&h->Y, nv * MMX_M));
         HIPCHK(h, dalloc(&h->pos4, (size_t)h->n_all));
@@ -247,7 +248,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
                     (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead,
                     (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
-                    (void *)h->md_snap})
+                    (void *)h->md_snap, (void *)h->cell_xref, (void *)h->slotkeys})
         if (p) (void)hipFree(p);
     if (h->dd_cnt_host) (void)hipHostFree(h->dd_cnt_host);
     if (h->seg_cent_host) (void)hipHostFree(h->seg_cent_host);
@@ -586,6 +587,9 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "inject_fault") h->inject_fault = (int)value;
     else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
+    else if (k == "cell_slots") h->cell_slots = value != 0.0;
+    else if (k == "cell_reuse") { h->cell_reuse = value != 0.0; h->reuse_K = 1; h->struct_valid = false; }
+    else if (k == "cell_reuse_factor") h->reuse_factor = value > 0.0 ? (float)std::max(1.0, value) : 0.f;
     else if (k == "cell_edge_auto") { h->cell_edge_auto = value != 0.0; h->edge_auto = 1.f; }
     else if (k == "cell_edge_scale") { h->cell_edge_scale = (float)std::max(1.0, value); h->grid_ready = false; }
     else if (k == "dd_spatial") h->dd_spatial = value != 0.0;
@@ -633,6 +637,13 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
         *value = h->coll_samples[w] ? h->coll_ns[w] / (double)h->coll_samples[w] / 1e3 : 0.0;
     }
     else if (k == "dd_collective_samples") *value = (double)h->coll_samples[kCollAllreduce];
+    else if (k == "cell_slots") *value = h->cell_slots;
+    else if (k == "cell_slot_halts") *value = (double)h->slot_halts;
+    else if (k == "cell_reuse") *value = h->cell_reuse;
+    else if (k == "cell_builds") *value = (double)h->cell_builds;     // read-only: tracked full builds / evaluations on a kept
+    else if (k == "cell_reuses") *value = (double)h->cell_reuses;     // structure / evaluations voided because it had gone stale
+    else if (k == "cell_stale_halts") *value = (double)h->cell_stale_halts;
+    else if (k == "cell_reuse_K") *value = h->reuse_K;
     else if (k == "md_step") *value = (double)h->md_step; // read-only: MD steps integrated (and not taken back) so far
     else if (k == "dd_spatial") *value = h->dd_spatial;
     else if (k == "dd_reassign_first") *value = h->dd_reassign_first;
@@ -782,6 +793,18 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             }
             // (both policies read the reason k_decide_reduced recorded from the ALL-REDUCED flags: every rank must arrive at the
             // same capacities and the same skin)
+            if (h->st_host->halt_reason & 8) { // the slot table was too small for this state: a larger one for the repeat
+                h->slot_halts++;
+                h->struct_valid = false;
+                h->st_host->cell_stale = 0;
+                if ((rc = ensure_slots(h, true))) return leave(rc);
+            }
+            if (h->st_host->halt_reason & 4) { // the kept cell structure went stale: build anew for the repeat, keep structures for half as long
+                h->cell_stale_halts++;
+                h->struct_valid = false;
+                h->reuse_K = std::max(1, h->reuse_K / 2);
+                h->st_host->cell_stale = 0;
+            }
             if (h->st_host->halt_reason & 2) h->dd_slack_div = std::max(1, h->dd_slack_div / 2); // lists grow faster than assumed
             if (h->st_host->halt_reason & 1) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f); // the skin did not last dd_every evaluations
             ramp = 4; // what follows a halt is polled (and its messages resized) at short intervals again

@@ -10,8 +10,8 @@ namespace mmx {
 // wave instead of one per distinct cell (Hilbert-ordered beads: ~3 distinct cells per wave).  Whole wave must call.
 // count_own (decomposed runs): the cell's OWNED beads are counted separately -- they and the ghosts of a cell form
 // separate clusters (cell_scan_block, emit_clusters).
-__device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count,
-                                          int *__restrict__ count_own = nullptr, bool owned = true) {
+__device__ __forceinline__ int cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count,
+                                         int *__restrict__ count_own = nullptr, bool owned = true) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long own_lanes = count_own ? __ballot(todo && owned) : 0ull;
@@ -30,7 +30,57 @@ __device__ __forceinline__ void cell_rank(bool todo, int c, int i, int *__restri
         if (count_own && (mine & own_lanes)) atomicAdd(&count_own[c], __popcll(mine & own_lanes));
     }
     base = __shfl(base, first, 64);
-    if (todo) rank[i] = base + __popcll(mine & lt);
+    const int r = base + __popcll(mine & lt);
+    if (todo) rank[i] = r;
+    return r;
+}
+
+// 12-bit Hilbert index of a position inside its cell (16 sub-cells per axis; Skilling's axes -> transpose, 4 bits).  Eight
+// consecutive beads of a Hilbert-ordered cell form a tighter cluster than eight of a Morton-ordered one (the Z curve
+// jumps): measured on gw_200k states, 53 % of the swept lanes inside the cutoff instead of 48 % (DESIGN_HISTORY.md 5c).
+__device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00d
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+__device__ __forceinline__ unsigned hilbert12(unsigned x, unsigned y, unsigned z) {
+#pragma unroll
+    for (unsigned q = 8u; q > 1u; q >>= 1) {
+        const unsigned m = q - 1u;
+        if (x & q) x ^= m; // (the step for the first axis exchanges it with itself otherwise)
+        if (y & q) x ^= m;
+        else {
+            const unsigned t = (x ^ y) & m;
+            x ^= t;
+            y ^= t;
+        }
+        if (z & q) x ^= m;
+        else {
+            const unsigned t = (x ^ z) & m;
+            x ^= t;
+            z ^= t;
+        }
+    }
+    y ^= x; // Gray encode
+    z ^= y;
+    unsigned t = 0u;
+#pragma unroll
+    for (unsigned q = 8u; q > 1u; q >>= 1)
+        if (z & q) t ^= q - 1u;
+    x ^= t;
+    y ^= t;
+    z ^= t;
+    return (spread4(x) << 2) | (spread4(y) << 1) | spread4(z);
+}
+__device__ __forceinline__ unsigned long long order_key(const float4 p, const GridParams &G, int cx, int cy, int cz,
+                                                        int bead, const bool is_ghost) {
+    const float fx = ((p.x - G.ox) * G.inv_h - (float)cx) * 16.f;
+    const float fy = ((p.y - G.oy) * G.inv_h - (float)cy) * 16.f;
+    const float fz = ((p.z - G.oz) * G.inv_h - (float)cz) * 16.f;
+    const unsigned qx = (unsigned)min(max((int)fx, 0), 15), qy = (unsigned)min(max((int)fy, 0), 15),
+                   qz = (unsigned)min(max((int)fz, 0), 15);
+    const unsigned m = hilbert12(qx, qy, qz);
+    // owned beads first (multi-GPU: clusters are then all-owned, one mixed, all-ghost), then along the curve, then id
+    const unsigned long long ghost = is_ghost ? 1ull : 0ull;
+    return (ghost << 63) | ((unsigned long long)m << 32) | (unsigned)bead;
 }
 
 // x = xp + step*d (MOVE) or x as given; builds pos4 = {x,y,z, bits((bead<<3)|(label+2))} and the bbox.
@@ -47,6 +97,24 @@ struct DirArgs {
     const float *S, *Y; // [MMX_M] vectors of nv floats
     size_t nv;
 };
+// Kept cell structure ("cell_reuse"): xref = the positions the structure in use was built from.  mode 1: an evaluation that
+// keeps it -- a bead farther than sqrt(thr2) from xref voids the evaluation (st->cell_stale); mode 2: an evaluation that
+// builds anew -- xref <- x (mode 3: the same without a previous reference to measure from).  Modes 1 and 2 record the largest squared displacement (st->disp2_bits) for the host's choice of how
+// many evaluations a structure may serve.
+struct RefArgs {
+    float *xref;
+    int mode;
+    float thr2;
+};
+// Slot table (trial moves of a single-domain minimization): the pack itself writes the bead's 64-bit sort key into its cell's
+// slot -- keys[cell * cap + rank in cell], cap from the largest cell the last poll saw -- which is what k_cell_fill would
+// write into the cell's slice of the counting sort after the scan: that launch disappears (5 us + a dispatch gap per
+// evaluation).  A cell beyond the table or fuller than cap voids the evaluation (st->cell_stale bit 1: PH_HALT, the host
+// enlarges the table and the evaluation is repeated).
+struct SlotArgs {
+    unsigned long long *keys;
+    int cap, cells;
+};
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
 __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *__restrict__ x, float *__restrict__ xp,
@@ -55,7 +123,9 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
                                               const MinState *__restrict__ st,
                                               const GridParams *__restrict__ grid = nullptr,
                                               int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
-                                              int *__restrict__ count = nullptr, const DirArgs D = DirArgs{}) {
+                                              int *__restrict__ count = nullptr, const DirArgs D = DirArgs{},
+                                              const RefArgs R = RefArgs{nullptr, 0, 0.f}, MinState *__restrict__ stw = nullptr,
+                                              const SlotArgs T = SlotArgs{nullptr, 0, 0}) {
     if (st->phase >= PH_DONE) return;
     __shared__ float s_bb[6][4];
     __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
@@ -129,15 +199,42 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         const int w = (bead << 3) | ((int)labels[bead] + 2);
         pos4[bead] = make_float4(px, py, pz, __int_as_float(w));
     }
+    if (R.mode) { // (block-uniform) displacement from where the cell structure in use binned the beads
+        float d2 = 0.f;
+        if (act) {
+            const float dx = px - R.xref[3 * i], dy = py - R.xref[3 * i + 1], dz = pz - R.xref[3 * i + 2];
+            d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            if (!(d2 >= 0.f)) d2 = 3e38f; // NaN: never "within the skin"
+            if (R.mode == 3) d2 = 0.f; // no reference yet: store only
+            if (R.mode >= 2) {
+                R.xref[3 * i] = px;
+                R.xref[3 * i + 1] = py;
+                R.xref[3 * i + 2] = pz;
+            }
+        }
+        const float m = wave_max(d2);
+        if ((threadIdx.x & 63) == 0 && m > 0.f) {
+            if (__float_as_uint(m) > stw->disp2_bits) atomicMax(&stw->disp2_bits, __float_as_uint(m));
+            if (R.mode == 1 && m > R.thr2) atomicOr(&stw->cell_stale, 1);
+        }
+    }
     if (COUNT) { // single-domain handles only: every bead is owned, bead == i
         const GridParams G = *grid;
-        int c = 0;
+        int c = 0, cx = 0, cy = 0, cz = 0;
         if (act) {
-            c = (cell_coord(pz, G.oz, G.inv_h, G.nz) * G.ny + cell_coord(py, G.oy, G.inv_h, G.ny)) * G.nx +
-                cell_coord(px, G.ox, G.inv_h, G.nx);
+            cx = cell_coord(px, G.ox, G.inv_h, G.nx);
+            cy = cell_coord(py, G.oy, G.inv_h, G.ny);
+            cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
+            c = (cz * G.ny + cy) * G.nx + cx;
             cell_of[i] = c;
         }
-        cell_rank(act, c, i, rank, count);
+        const int r = cell_rank(act, c, i, rank, count);
+        if (T.keys && act) {
+            if (c < T.cells && r < T.cap)
+                T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, i, false);
+            else
+                atomicOr(&stw->cell_stale, 2); // the table is too small for this state: the evaluation is void (k_decide halts)
+        }
     }
     // Block bounding box -> bbox_part[k][block] (k = minx,miny,minz,maxx,maxy,maxz); no atomics.
     const float big = 3.0e38f;
@@ -373,54 +470,6 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const ScanArgs a, MinState *
     cell_scan_block<CHUNK>(a, st);
 }
 
-// 12-bit Hilbert index of a position inside its cell (16 sub-cells per axis; Skilling's axes -> transpose, 4 bits).  Eight
-// consecutive beads of a Hilbert-ordered cell form a tighter cluster than eight of a Morton-ordered one (the Z curve
-// jumps): measured on gw_200k states, 53 % of the swept lanes inside the cutoff instead of 48 % (DESIGN_HISTORY.md 5c).
-__device__ __forceinline__ unsigned spread4(unsigned v) { // abcd -> 00a00b00c00d
-    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
-}
-__device__ __forceinline__ unsigned hilbert12(unsigned x, unsigned y, unsigned z) {
-#pragma unroll
-    for (unsigned q = 8u; q > 1u; q >>= 1) {
-        const unsigned m = q - 1u;
-        if (x & q) x ^= m; // (the step for the first axis exchanges it with itself otherwise)
-        if (y & q) x ^= m;
-        else {
-            const unsigned t = (x ^ y) & m;
-            x ^= t;
-            y ^= t;
-        }
-        if (z & q) x ^= m;
-        else {
-            const unsigned t = (x ^ z) & m;
-            x ^= t;
-            z ^= t;
-        }
-    }
-    y ^= x; // Gray encode
-    z ^= y;
-    unsigned t = 0u;
-#pragma unroll
-    for (unsigned q = 8u; q > 1u; q >>= 1)
-        if (z & q) t ^= q - 1u;
-    x ^= t;
-    y ^= t;
-    z ^= t;
-    return (spread4(x) << 2) | (spread4(y) << 1) | spread4(z);
-}
-__device__ __forceinline__ unsigned long long order_key(const float4 p, const GridParams &G, int cx, int cy, int cz,
-                                                        int bead, const bool is_ghost) {
-    const float fx = ((p.x - G.ox) * G.inv_h - (float)cx) * 16.f;
-    const float fy = ((p.y - G.oy) * G.inv_h - (float)cy) * 16.f;
-    const float fz = ((p.z - G.oz) * G.inv_h - (float)cz) * 16.f;
-    const unsigned qx = (unsigned)min(max((int)fx, 0), 15), qy = (unsigned)min(max((int)fy, 0), 15),
-                   qz = (unsigned)min(max((int)fz, 0), 15);
-    const unsigned m = hilbert12(qx, qy, qz);
-    // owned beads first (multi-GPU: clusters are then all-owned, one mixed, all-ghost), then along the curve, then id
-    const unsigned long long ghost = is_ghost ? 1ull : 0ull;
-    return (ghost << 63) | ((unsigned long long)m << 32) | (unsigned)bead;
-}
-
 // Scatter bead ids AND their 64-bit sort keys into their cell's slice (arrival order; k_cell_order makes it
 // canonical).  Writing the key here -- where the position is read coalesced by bead -- takes the perm -> pos4 gather
 // out of the latency chain of the per-cell sort.
@@ -493,6 +542,41 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
             // then fetched by two back-to-back 16-byte loads from one address)
             cl_lo[2 * (cb + (e >> 3))] = make_float4(lx, ly, lz, __int_as_float(c));
             cl_lo[2 * (cb + (e >> 3)) + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | nreal));
+        }
+    }
+}
+
+// Kept cell structure: cluster positions and boxes from the current pos4 -- membership, cluster composition, cluster
+// order and work items stay as the last full build left them (cells of edge cutoff + skin make that exact while no bead has
+// moved more than skin / 2 from where it was binned: k_pack checks).  One thread per cluster slot.
+__global__ __launch_bounds__(256) void k_refresh_clusters(const int *__restrict__ sbead, const float4 *__restrict__ pos4,
+                                                          float4 *__restrict__ spos4, float4 *__restrict__ cl_lo,
+                                                          const MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    const int nsl = st->n_clusters * 8;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nsl; e += gridDim.x * 256) { // (nsl is a multiple of 8: whole clusters per octet)
+        const int b = sbead[e];
+        const bool real = b >= 0;
+        float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8));
+        if (real) p = pos4[b];
+        spos4[e] = p;
+        const float big = 3.0e38f;
+        float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
+        float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            lx = fminf(lx, __shfl_xor(lx, o, 64));
+            ly = fminf(ly, __shfl_xor(ly, o, 64));
+            lz = fminf(lz, __shfl_xor(lz, o, 64));
+            hx = fmaxf(hx, __shfl_xor(hx, o, 64));
+            hy = fmaxf(hy, __shfl_xor(hy, o, 64));
+            hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+        }
+        if ((e & 7) == 0) { // lo.w (cell id) and hi.w (bead counts) are what the build wrote
+            const int c = e >> 3;
+            const float cw = cl_lo[2 * c].w, nw = cl_lo[2 * c + 1].w;
+            cl_lo[2 * c] = make_float4(lx, ly, lz, cw);
+            cl_lo[2 * c + 1] = make_float4(hx, hy, hz, nw);
         }
     }
 }
@@ -584,7 +668,9 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  const unsigned long long *__restrict__ okeys,
                                                  const int *__restrict__ biglist,
                                                  MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
-                                                 int *__restrict__ sbead = nullptr) {
+                                                 int *__restrict__ sbead = nullptr, const int slot_cap = 0,
+                                                 const int slot_cells = 0) {
+    // slot_cap > 0: `okeys` is the slot table the pack wrote (keys of cell c at c * slot_cap), not the counting sort's slices
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridParams G = *grid;
@@ -601,6 +687,8 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
     for (int c = (bid - nB) * 4 + wave; bid >= nB && c < ncells; c += (nblk - nB) * 4) {
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt > 64) continue;
+        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
+        const size_t kb = slot_cap ? (size_t)c * slot_cap : (size_t)s;
         const int no = count_own ? count_own[c] : cnt;
         if (lane == 0) {
             count[c] = 0;
@@ -608,16 +696,18 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         }
         if (cnt == 0) continue;
         if (lane == 0) items[istart[c]] = make_int2(c, 0);
-        if (cnt > 1) {
+        if (cnt > 1 || slot_cap) { // (slot table: perm has no fill behind it, a single bead is written here too)
             unsigned long long v = kmax;
-            if (lane < cnt) v = okeys[s + lane];
+            if (lane < cnt) v = okeys[kb + lane];
+            if (cnt > 1) {
 #pragma unroll
-            for (int k = 2; k <= 64; k <<= 1) {
+                for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const unsigned long long o = __shfl_xor(v, j, 64);
-                    const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-                    v = keep_min ? (v < o ? v : o) : (v < o ? o : v);
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        const unsigned long long o = __shfl_xor(v, j, 64);
+                        const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                        v = keep_min ? (v < o ? v : o) : (v < o ? o : v);
+                    }
                 }
             }
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
@@ -632,6 +722,8 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         const int c = biglist[bi];
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt <= 64) continue; // (cannot happen; block-uniform)
+        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
+        const size_t kb = slot_cap ? (size_t)c * slot_cap : (size_t)s;
         const int no = count_own ? count_own[c] : cnt;
         __syncthreads(); // every thread has read count_own[c]
         if (threadIdx.x == 0) {
@@ -644,9 +736,9 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
             __syncthreads(); // s_buf free (emit of the previous cell has read it)
-            if (n2 <= 256) block_sort_regs<1>(s_buf, okeys + s, cnt, n2);
-            else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + s, cnt, n2);
-            else block_sort_regs<4>(s_buf, okeys + s, cnt, n2);
+            if (n2 <= 256) block_sort_regs<1>(s_buf, okeys + kb, cnt, n2);
+            else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + kb, cnt, n2);
+            else block_sort_regs<4>(s_buf, okeys + kb, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
             emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead);
             continue;
@@ -656,7 +748,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             while (n2 < cnt) n2 <<= 1;
             __syncthreads(); // s_buf free
             for (int q = threadIdx.x; q < n2; q += 256) {
-                s_buf[q] = q < cnt ? okeys[s + q] : kmax;
+                s_buf[q] = q < cnt ? okeys[kb + q] : kmax;
             }
             __syncthreads();
             // bitonic network; stages with j < 128 stay inside 128-element segments, each owned by one wave
@@ -696,6 +788,12 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             __threadfence_block();
             __syncthreads();
         }
+        else if (slot_cap) { // above CAP: arrival order -- which, without a fill, has to be written out first
+            for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(okeys[kb + q] & 0xffffffffull);
+            __threadfence_block();
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
+        }
         else if (threadIdx.x == 0) {
             atomicAdd(&st->order_fallbacks, 1);
             // cells above CAP beads keep arrival order: still correct on a single domain (not bitwise reproducible); on a
@@ -718,10 +816,12 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi,
                                                     const Own own, const unsigned long long *__restrict__ okeys,
                                                     const int *__restrict__ biglist,
-                                                    MinState *__restrict__ st, int *__restrict__ count_own = nullptr) {
+                                                    MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
+                                                    int *__restrict__ sbead = nullptr, const int slot_cap = 0,
+                                                    const int slot_cells = 0) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own);
+                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells);
 }
 
 } // namespace mmx

@@ -134,11 +134,16 @@ struct MinState {
     int n3_queue;        // ... and the head of their queue (persistent workgroups pull from it)
     int dd_stale;        // decomposed runs: an owned bead has moved more than half the skin since the ghost lists were built
     int halt_phase;      // phase to return to after PH_HALT
-    int halt_reason;     // why (bit 0: a list went stale, bit 1: a list outgrew its message) -- from the all-reduced flags, so the
+    int halt_reason;     // why (bit 0: a list went stale, bit 1: a list outgrew its message, bit 2: the kept cell structure went
+                         // stale) -- bits 0-1 from the all-reduced flags, so the
                          // same on every rank; kept until the host has read it (the evaluations behind a halt zero the sums)
     int kernel_error;    // a force kernel could not do its work (KERR_*): the evaluation is void, the controller ends the
                          // call with status MMX_MIN_KERNEL instead of deciding on partial sums
     int dd_overflow;     // decomposed runs: a ghost list built on the stream outgrew its message (capacity known to the host)
+    int cell_stale;      // kept cell structure (mmx_engine.hpp, "cell_reuse"): a bead has moved more than half the skin since it was
+                         // binned -- the evaluation is void (PH_HALT, halt_reason bit 2) and is repeated after a full build
+    unsigned disp2_bits; // largest squared displacement of a bead from where it was binned, as float bits (non-negative floats
+                         // order like unsigned ints), over the evaluations since the host last cleared it
     double fx;      // energy at the last accepted point
     double ftrial;  // energy of the last evaluation
     double finit, dginit, step, epsilon;

@@ -123,6 +123,7 @@ void refresh_params(mmx_handle_s *h) {
 // choice of the pair kernel: see use_n3
 constexpr double kWideCellsBelow = 32.0; // beads per cutoff-sized cell under which the grid switches to cells kWideCellFactor wider
 constexpr float kWideCellFactor = 1.12f;
+constexpr int kReuseMax = 16;            // evaluations a kept cell structure serves at most
 constexpr int kWideCellsFromBeads = 20000;
 constexpr double kN3MinBeadsPerCell = 20.0;
 constexpr int kN3MinBeads = 100000;
@@ -695,6 +696,29 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
     const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h);
+    // kept cell structure (see mmx_handle_s::cell_reuse): trial moves of a single-domain minimization only
+    // (and only on grids wider than the cutoff: without a skin there is nothing to keep, and the reference costs 24 B / bead)
+    const bool tracked = fuse_count && mode == PACK_MOVE && h->cell_reuse && !h->capturing && !h->use_graph && h->cell_xref &&
+                         h->grid_factor[h->build_idx & 1] > 1.f;
+    const float rcut = hmin_of(h) / (1.001f * edge_factor(h));
+    const float half_skin = 0.5f * (h->struct_factor - 1.f) * rcut;
+    const bool reuse = tracked && h->struct_valid && h->reuse_K > 1 && h->struct_evals < h->reuse_K && half_skin > 0.f &&
+                       h->last_clusters > 0;
+    if (reuse) {
+        // (option inject_fault bit 3, tests: a skin of nothing -- every evaluation on a kept structure finds it stale)
+        const RefArgs R{h->cell_xref, 1, (h->inject_fault & 8) ? 1e-16f : half_skin * half_skin};
+        hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
+                           h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h), R, h->st);
+        if (bonded) enqueue_bonded(h, *bonded, false);
+        const int gu = std::max(64, std::min((h->last_clusters * 8 + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_refresh_clusters, dim3(gu), dim3(256), 0, h->stream, h->sbead, h->pos4, h->spos4, h->cl_lo, h->st);
+        h->struct_evals++;
+        h->cell_reuses++;
+        return; // gcur, n3_build, the work items and the cluster list are those of the structure's full build
+    }
+    if (!tracked) h->struct_valid = false; // whatever is built below is not tracked by cell_xref
+    h->slots_now = false;
     if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
         MdParams M = h->md;
         M.step_lo = (uint32_t)h->md_step;
@@ -716,10 +740,23 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
 #undef MDP
     } else if (fuse_count) { // single GPU, cell list in use, grid already known: pack + cell count in one launch
         GridParams *cur = h->grid + (h->build_idx & 1);
-        if (mode == PACK_MOVE) // trial move of the minimizer: also forms the new direction after an accepted step
+        if (mode == PACK_MOVE) { // trial move of the minimizer: also forms the new direction after an accepted step
+            // (tracked: cell_xref <- the positions this build bins; the displacement from the previous structure's reference
+            //  is recorded on the way -- what the host sizes reuse_K by)
+            const RefArgs R{h->cell_xref, tracked ? (h->struct_valid ? 2 : 3) : 0, 0.f};
+            // sort keys straight into the slot table: no k_cell_fill below
+            h->slots_now = h->cell_slots && h->slotkeys && !h->capturing && !h->use_graph;
+            const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
-                               h->count, dir_args(h));
+                               h->count, dir_args(h), R, h->st, T);
+            if (tracked) {
+                h->struct_valid = true;
+                h->struct_evals = 1;
+                h->struct_factor = h->grid_factor[h->build_idx & 1];
+                h->cell_builds++;
+            }
+        }
         else
             hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp,
                                h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
@@ -765,6 +802,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     if (has_nb(h) && !all_pairs(h)) {
         const float hm = hmin_of(h);
         GridParams *cur = h->grid + (h->build_idx & 1), *next = h->grid + ((h->build_idx + 1) & 1);
+        h->grid_factor[(h->build_idx + 1) & 1] = edge_factor(h); // the grid this build's scan lays out for the next one
+        if (init || dd) h->grid_factor[h->build_idx & 1] = edge_factor(h);
         if (init || dd) // multi-GPU: exact box of the owned beads grown by the cutoff, every build
             hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(256), 0, h->stream, h->bbox_part, gb, hm, h->maxcells,
                                dd ? hm / edge_factor(h) : 0.f, cur, h->st); // (grown by the cutoff, whatever the cell edge)
@@ -793,9 +832,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         if (halo)
             hipLaunchKernelGGL(k_cell_fill_dd, dim3(std::max(gl, 1)), dim3(256), 0, h->stream, h->n_own, own_of(h), h->dd_nghost,
                                h->dd_ghost_ids, h->cell_of, h->rank_in_cell, h->start, h->perm, h->okeys, h->pos4, cur, h->st);
-        else
+        else if (!h->slots_now)
             hipLaunchKernelGGL(k_cell_fill, dim3(ga), dim3(256), 0, h->stream, h->n_all, h->cell_of, h->rank_in_cell,
                                h->start, h->perm, h->okeys, h->pos4, cur, own_of(h), h->st);
+        const unsigned long long *keys = h->slots_now ? h->slotkeys : h->okeys;
+        const int scap = h->slots_now ? h->slot_cap : 0, scells = h->slots_now ? h->slot_cells : 0;
         // in-LDS sort capacity from the largest cell of the last poll (60 % headroom), see k_cell_order; the work items
         // of the half-shell pair kernel are built by extra workgroups of the same launch (k_order_items)
         // (decomposed ranks always take the 4096-bead instance: a cell that outgrows the sort is an error there, see cell_order_block)
@@ -806,23 +847,23 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             if (small_cells)
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, own_of(h), h->okeys, h->biglist, h->n3_items,
+                                   h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0);
+                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
-                                   h->cl_hi, own_of(h), h->okeys, h->biglist, h->n3_items,
+                                   h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0);
+                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               own_of(h), h->okeys, h->biglist, h->st, h->count_own);
+                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               own_of(h), h->okeys, h->biglist, h->st, h->count_own);
+                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells);
         h->gcur = cur;
         h->build_idx++;
         h->grid_ready = true;
@@ -1031,6 +1072,8 @@ bool graph_replay(mmx_handle_s *h) {
     return true;
 }
 
+int ensure_slots(mmx_handle_s *h, bool grow);
+
 int push_state(mmx_handle_s *h) {
     HIPCHK(h, hipMemcpyAsync(h->st, h->st_host, sizeof(MinState), hipMemcpyHostToDevice, h->stream));
     return MMX_OK;
@@ -1055,7 +1098,31 @@ int pull_state(mmx_handle_s *h) {
         // wider cells once the structure has thinned out.  Measured (scripts/wide_cells_ab.py, iterations 1000-2000): a fixed
         // 1.12 gives chr1_50k 11 140 -> 11 970 it/s, gw_200k 4 350 -> 4 415; cells sized for ~40 beads each (up to 1.6 x the
         // cutoff) are no better (11 870 / 4 400) and cost region_5k 1.4 %, where 1.12 is neutral: small systems keep the cutoff
-        h->edge_auto = (per_cell < kWideCellsBelow && local_beads(h) >= kWideCellsFromBeads) ? kWideCellFactor : 1.f;
+        // (single-domain handles that keep cell structures take a wider skin: the structure then serves more evaluations)
+        // -- measured, iterations 1000-2000 against a build per evaluation: gw_200k (half-shell kernel) +4.5 % at 1.3, -0.6 % at
+        // 1.45; chr1_50k (full-shell kernel, indifferent to the cell size) +15 % at 1.3, +15.6 % at 1.45
+        const float rf = h->reuse_factor > 0.f ? h->reuse_factor : use_n3(h) ? 1.3f : 1.45f;
+        const float wide = (h->cell_reuse && h->cell_xref) ? std::max(rf, kWideCellFactor) : kWideCellFactor;
+        h->edge_auto = (per_cell < kWideCellsBelow && local_beads(h) >= kWideCellsFromBeads) ? wide : 1.f;
+    }
+    {
+        const int rc_slots = ensure_slots(h, false);
+        if (rc_slots) return rc_slots;
+    }
+    // kept cell structure: how many evaluations may a structure serve?  disp2_bits = the largest displacement of a bead from
+    // where its structure binned it, over the evaluations since the last poll (structures of up to reuse_K evaluations);
+    // a structure holds while that stays below half the skin of the grid in force.  70 % of the room is used, the figure
+    // at most doubles per poll, and a stale halt halves it (mmx_minimize).
+    if (h->cell_reuse && h->cell_xref && h->st_host->disp2_bits != 0u) {
+        float d2;
+        std::memcpy(&d2, &h->st_host->disp2_bits, 4);
+        const float per_eval = std::sqrt(d2) / (float)std::max(1, h->reuse_K);
+        const float rcut = hmin_of(h) / (1.001f * edge_factor(h));
+        const float allowed = 0.5f * (edge_factor(h) - 1.f) * rcut;
+        int K = per_eval > 0.f ? (int)(0.7f * allowed / per_eval) : kReuseMax;
+        K = std::max(1, std::min(K, kReuseMax));
+        h->reuse_K = std::min(K, std::max(2 * h->reuse_K, 2));
+        HIPCHK(h, hipMemsetAsync(&h->st->disp2_bits, 0, sizeof(unsigned), h->stream));
     }
     if (h->comm && g_rccl.CommGetAsyncError && !h->coll_failed) { // errors RCCL found after the call returned
         ncclResult_t ar = ncclSuccess;
@@ -1082,6 +1149,33 @@ int kernel_error_rc(mmx_handle_s *h) {
     if ((ke & 0xff) == 0) what += " reported by another rank;";
     return fail(h, MMX_ERR_STATE, "a force kernel could not do its work, the evaluation is void:" + what +
                                   " forces and energies of this call must not be used");
+}
+
+// Slot table of the trial moves: room for 1.5 x the cells and 1.6 x the fullest cell of the last poll (the grid follows the
+// bounding box from build to build).  Called with the stream idle.  grow: after an evaluation that did not fit.
+int ensure_slots(mmx_handle_s *h, bool grow) {
+    if (!h->cell_slots || h->world > 1 || h->n_own != h->n || h->last_ncells <= 0 || h->last_max_per_cell <= 0) return MMX_OK;
+    int cap = 64;
+    while (cap < (int)(1.6 * h->last_max_per_cell) + 16) cap <<= 1;
+    int cells = (int)(1.5 * h->last_ncells) + 1024;
+    if (grow) {
+        cap = std::max(cap, 2 * h->slot_cap);
+        cells = std::max(cells, h->slot_cells + h->slot_cells / 2);
+    }
+    if (cap <= h->slot_cap && cells <= h->slot_cells) return MMX_OK;
+    cap = std::max(cap, h->slot_cap);
+    cells = std::max(cells, h->slot_cells);
+    if ((double)cap * (double)cells * 8.0 > 4e9) { // a pathological state (one huge cell): the counting sort's fill stays
+        h->cell_slots = 0;
+        return MMX_OK;
+    }
+    if (h->slotkeys) (void)hipFree(h->slotkeys);
+    h->slotkeys = nullptr;
+    h->slot_cap = h->slot_cells = 0;
+    HIPCHK(h, dalloc(&h->slotkeys, (size_t)cap * (size_t)cells));
+    h->slot_cap = cap;
+    h->slot_cells = cells;
+    return MMX_OK;
 }
 
 int ensure_allpairs_scratch(mmx_handle_s *h) {
@@ -1392,6 +1486,7 @@ int prepare(mmx_handle_s *h) {
     if (!h->have_pos) return fail(h, MMX_ERR_STATE, "positions not set (mmx_set_positions)");
     HIPCHK(h, hipSetDevice(h->device));
     refresh_params(h);
+    h->struct_valid = false; // a kept cell structure does not outlive the call that built it
     if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
         return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
     if (has_nb(h) && !all_pairs(h) && h->n_all > (1 << 24)) // the cluster kernel addresses spos4 with 32-bit offsets

@@ -274,6 +274,27 @@ struct mmx_handle_s {
     // per cutoff-sized cell the in-cell ordering is a latency chain per cell and 1.12 x wider cells (1.4 x the beads each)
     // take 8-10 us off the cell build for +2 us of pair kernel at 200 000 beads (profiles/r04_cell_edge_cost.txt); denser
     // states and systems below 20 000 beads lose or gain nothing.
+    // Kept cell structure (option "cell_reuse", single-domain minimizations): membership, cluster composition, cluster order
+    // and work items of a full build serve up to reuse_K evaluations; in between only the cluster positions and boxes are
+    // refreshed (k_refresh_clusters) -- exact while no bead has moved more than half the skin (cell edge - cutoff) from
+    // where it was binned, which k_pack checks; a violation voids the evaluation (PH_HALT) and it is repeated after a full
+    // build.  reuse_K follows the displacements the polls read back (pull_state).
+    // Slot table (SlotArgs, mmx_cells.hpp): trial moves write their sort keys straight into per-cell slots, no k_cell_fill
+    int cell_slots = 1;           // option
+    unsigned long long *slotkeys = nullptr;
+    int slot_cap = 0, slot_cells = 0;
+    bool slots_now = false;       // the build being enqueued uses the table
+    long long slot_halts = 0;
+    int cell_reuse = 1;
+    float reuse_factor = 0.f;     // cell edge / cutoff once the structure has thinned out and structures are kept; 0: by pair kernel
+                                  // (1.3 half shell, 1.45 full shell: scripts/cell_reuse_ab.py); option cell_reuse_factor
+    int reuse_K = 1;              // evaluations a structure may serve (1: a full build per evaluation)
+    int struct_evals = 0;         // evaluations the structure in use has served
+    bool struct_valid = false;    // ... and cell_xref holds the positions it was built from
+    float struct_factor = 1.f;    // cell edge / cutoff of the grid it was built on
+    float grid_factor[2] = {1.f, 1.f}; // ... of the two ping-pong grids
+    float *cell_xref = nullptr;   // [3 n_own]
+    long long cell_builds = 0, cell_reuses = 0, cell_stale_halts = 0; // statistics
     int cell_edge_auto = 1;      // option: 0 = cells of edge cutoff throughout (A/B)
     float edge_auto = 1.f;       // the factor in force
     float cell_edge_scale = 1.f; // measurement only (option cell_edge_scale): grid cells of edge scale * cutoff -- what a Verlet skin would cost the pair kernels

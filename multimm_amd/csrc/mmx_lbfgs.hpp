@@ -437,13 +437,23 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
     if (threadIdx.x < MMX_M) s_ys[threadIdx.x] = yval;
     rows_finish<MMX_NROWSUM>(acc, s_rows); // ends with a barrier: s_G is complete too
     if (threadIdx.x == 0) {
-        double sums[P_NSLOTS];
+        if (st->cell_stale && !st->kernel_error) {
+            // the kept cell structure was out of date for this evaluation (k_pack): it never happened.  Nothing is decided;
+            // every kernel of the evaluations already in the stream returns at once, the host builds anew and repeats it.
+            st->halt_phase = st->phase;
+            st->halt_reason = ((st->cell_stale & 1) ? 4 : 0) | ((st->cell_stale & 2) ? 8 : 0); // stale structure / slot table too small
+            st->phase = PH_HALT;
+            st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
+            s_accepted = 0;
+        } else {
+            double sums[P_NSLOTS];
 #pragma unroll
-        for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
-        dots_from_rows(sums, s_rows);
-        controller_decide(st, sums, st->kernel_error != 0);
-        s_accepted = st->accepted;
-        if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
+            for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
+            dots_from_rows(sums, s_rows);
+            controller_decide(st, sums, st->kernel_error != 0);
+            s_accepted = st->accepted;
+            if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
+        }
     }
     __syncthreads();
     if (s_accepted && threadIdx.x < MMX_NBASIS * MMX_NBASIS) st->gram[threadIdx.x] = s_G[threadIdx.x];

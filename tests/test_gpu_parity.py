@@ -691,6 +691,42 @@ def test_ensemble_loop_like_the_reference(tmp_path):
         assert (a.iterations, a.evaluations, a.e_initial, a.e_final) == (b.iterations, b.evaluations, b.e_initial, b.e_final)
 
 
+def test_kept_cell_structure_is_exact_and_falls_back_when_it_goes_stale():
+    """Option cell_reuse (default on): once the structure has thinned out, a single-domain minimization keeps the cell
+    structure of a full build -- membership, clusters, work items -- for several evaluations and only refreshes cluster
+    positions and boxes; k_pack checks every evaluation that no bead has moved more than half the skin (cell edge -
+    cutoff) from where it was binned.  Exactness: the energy the minimizer reports for its last point, found on a kept
+    structure, is the energy a fresh build -- and the oracle -- give for that point.  A structure that does
+    go stale (inject_fault bit 3: a skin of nothing) voids its evaluation, which is repeated after a full build: same
+    iteration count, an end point of the same depth.  Runs with the same options repeat bit for bit."""
+    from oracle.oracle import Oracle
+    s = synthetic_system("chr1_50k", n_beads=30000)
+    runs = {}
+    for name, opts in (("rebuild", dict(cell_reuse=0)), ("keep", dict()), ("keep again", dict()), ("stale", dict(inject_fault=8))):
+        with engine_for(s) as eng:
+            eng.set_option("deterministic", 1)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            st = eng.minimize(tolerance=0.0, max_iters=1500)
+            stats = {k: eng.get_option(k) for k in ("cell_builds", "cell_reuses", "cell_stale_halts")}
+            x = eng.get_positions()
+            et, F = eng.compute()
+            runs[name] = (st.iterations, st.status, st.e_initial, st.e_final, stats, x, et, F)
+    it, status, e0, e1, stats, x, et, F = runs["keep"]
+    assert runs["rebuild"][4]["cell_reuses"] == 0
+    assert stats["cell_reuses"] > 300 and stats["cell_stale_halts"] <= 3, stats      # most late evaluations ran on a kept structure
+    assert abs(et.sum() - e1) <= 2e-6 * abs(e1)                                      # ... and found every pair
+    et_ref, _ = Oracle(s).eval(x)                                                    # ... as the oracle counts them
+    assert np.all(np.abs(et - et_ref) <= E_RTOL * np.abs(et_ref).sum() + E_ATOL)
+    assert runs["keep again"][:4] == runs["keep"][:4] and np.array_equal(runs["keep again"][5], x)     # reproducible
+    for other in ("rebuild", "stale"):
+        o_it, o_status, o_e0, o_e1 = runs[other][:4]
+        assert (o_it, o_status) == (it, status) == (1500, 1) and o_e0 == e0
+        assert abs(o_e1 - e1) <= 2e-2 * abs(e0 - e1), (other, o_e1, e1)          # other summation orders: chaotic drift only
+    assert runs["stale"][4]["cell_stale_halts"] >= 5, runs["stale"][4]
+    assert abs(runs["stale"][6].sum() - runs["stale"][3]) <= 2e-6 * abs(runs["stale"][3])
+
+
 def test_extreme_compartment_radius():
     """A tiny r_comp (here POL_HARMONIC_BOND_R0 = 1e-4 nm => r_comp = 1.5e-4 nm): the Gaussian's exponent constant
     -log2(e) / (2 r_comp^2) = -3.2e7 nm^-2 underflows every pair to zero without producing anything non-finite."""
