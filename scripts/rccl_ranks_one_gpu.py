@@ -24,7 +24,8 @@ def worker(rank, world, port, n_beads, iters, q):
         s = synthetic_system("gw_200k", n_beads=n_beads, jitter=0.02, seed=3)
         eng = engine_for(s, device=0, rank=rank, world=world)
         eng.set_option("nb_variant", float(os.environ.get("MMX_NB_VARIANT", "0")))
-        for key, env in (("dd_rebuild_every", "MMX_DD_EVERY"), ("dd_skin", "MMX_DD_SKIN"), ("inject_fault", "MMX_INJECT")):
+        for key, env in (("dd_rebuild_every", "MMX_DD_EVERY"), ("dd_skin", "MMX_DD_SKIN"), ("inject_fault", "MMX_INJECT"),
+                         ("dd_reassign_first", "MMX_DD_REASSIGN_FIRST"), ("dd_reassign_max", "MMX_DD_REASSIGN_MAX")):
             if os.environ.get(env):
                 eng.set_option(key, float(os.environ[env]))
         uid = broadcast_bytes(Engine.comm_unique_id() if rank == 0 else None, 128)
@@ -37,8 +38,12 @@ def worker(rank, world, port, n_beads, iters, q):
         ids = eng.owned_beads()
         st = eng.minimize(tolerance=0.0, max_iters=iters)
         x = eng.get_positions()
-        stats = {k: eng.get_option(k) for k in ("dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_halts", "dd_sync_rebuilds")}
-        q.put((rank, "ok", et, f, ids, len(ids), (st.iterations, st.status, st.e_initial, st.e_final), x, stats))
+        stats = {k: eng.get_option(k) for k in ("dd_ghosts", "dd_exchanges", "dd_bytes_sent", "dd_halts", "dd_sync_rebuilds",
+                                                "dd_reassignments", "dd_segments_moved")}
+        # after a re-assignment of the segments the forces of the owned beads must still be the single-domain ones
+        et2, f2 = eng.compute()
+        ids2 = eng.owned_beads()
+        q.put((rank, "ok", et, f, ids, len(ids), (st.iterations, st.status, st.e_initial, st.e_final), x, stats, et2, f2, ids2))
         eng.close()
     except Exception as e:  # noqa: BLE001
         q.put((rank, "error", repr(e)))
@@ -80,6 +85,16 @@ if __name__ == "__main__":
           f"{all(np.array_equal(r[2], res[0][2]) for r in res)}; max |dE| vs one domain {np.abs(res[0][2] - et0).max():.3g}; "
           f"max |dF| / max |F| {np.abs(F - F0).max() / np.abs(F0).max():.3g}; minimization {res[0][6]} vs {(st0.iterations, st0.status, st0.e_initial, st0.e_final)}; "
           f"positions equal on every rank: {all(np.array_equal(r[7], res[0][7]) for r in res)}; rank 0 halo: {res[0][8]}")
+    with engine_for(s) as eng:      # forces at the END of the decomposed run, against one domain at those positions
+        eng.set_positions(res[0][7])
+        et1, F1 = eng.compute()
+    F2 = np.zeros_like(F1)
+    for r in res:
+        F2[r[11]] = r[10]
+    cover = sorted(np.concatenate([r[11] for r in res]).tolist()) == list(range(n_beads))
+    print(f"after the run: ranks partition the beads: {cover}; segment re-assignments {res[0][8]['dd_reassignments']:.0f} "
+          f"({res[0][8]['dd_segments_moved']:.0f} segments moved); max |dF| / max |F| at the end {np.abs(F2 - F1).max() / np.abs(F1).max():.3g}; "
+          f"max |dE| {np.abs(res[0][9] - et1).max():.3g}")
     ok = (np.abs(F - F0).max() <= 1e-5 * np.abs(F0).max() and all(r[6] == res[0][6] for r in res)
-          and all(np.array_equal(r[7], res[0][7]) for r in res))
+          and all(np.array_equal(r[7], res[0][7]) for r in res) and cover and np.abs(F2 - F1).max() <= 1e-5 * np.abs(F1).max())
     sys.exit(0 if ok else 2)

@@ -39,3 +39,12 @@ def test_rccl_three_ranks_half_shell_kernel_and_voided_evaluations():
 def test_rccl_four_ranks_lists_older_than_one_evaluation():
     out = _run(4, 30000, 25, MMX_DD_EVERY=3, MMX_DD_SKIN=0.3)
     assert "positions equal on every rank: True" in out
+
+
+def test_rccl_three_ranks_segments_migrate():
+    """Spatial re-assignment over RCCL: the centroid all-gather, the block-wise all-gathers of the 17 optimizer vectors and the
+    synchronous list rebuild that follows, with three ranks and attempts after 8, 24, 56 ... evaluations; at the end the ranks
+    partition the beads in other pieces and their forces are the single-domain ones."""
+    out = _run(3, 30000, 100, MMX_DD_REASSIGN_FIRST=8, MMX_DD_REASSIGN_MAX=32)
+    assert "positions equal on every rank: True" in out and "ranks partition the beads: True" in out
+    assert "segment re-assignments 0 " not in out
