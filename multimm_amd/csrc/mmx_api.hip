@@ -588,6 +588,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
     else if (k == "cell_slots") h->cell_slots = value != 0.0;
+    else if (k == "dd_split") h->dd_split = value != 0.0;
     else if (k == "cell_reuse") { h->cell_reuse = value != 0.0; h->reuse_K = 1; h->struct_valid = false; }
     else if (k == "cell_reuse_factor") h->reuse_factor = value > 0.0 ? (float)std::max(1.0, value) : 0.f;
     else if (k == "cell_edge_auto") { h->cell_edge_auto = value != 0.0; h->edge_auto = 1.f; }
@@ -638,6 +639,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     }
     else if (k == "dd_collective_samples") *value = (double)h->coll_samples[kCollAllreduce];
     else if (k == "cell_slots") *value = h->cell_slots;
+    else if (k == "dd_split") *value = h->dd_split;
     else if (k == "cell_slot_halts") *value = (double)h->slot_halts;
     else if (k == "cell_reuse") *value = h->cell_reuse;
     else if (k == "cell_builds") *value = (double)h->cell_builds;     // read-only: tracked full builds / evaluations on a kept

@@ -356,6 +356,10 @@ struct ScanArgs {
     const GridParams *grid;
     GridParams *grid_next;
     const int *count_own; // decomposed runs: owned beads per cell (nullptr: every bead is owned)
+    int split;            // decomposed ranks running the half-shell kernel: the clusters of owned beads come first in the cluster
+                          // list (cstart: their offsets per cell), the ghosts' clusters behind them (istart: THEIR offsets per
+                          // cell, counted from the first ghost cluster) -- every owned-ghost pair is then taken from the owned
+                          // side and ghost clusters are never i-clusters (mmx_nonbonded_n3.hpp)
 };
 template <int CHUNK>
 __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__restrict__ st) {
@@ -378,9 +382,10 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
     int sa = 0, sb = 0, sc = 0, sd = 0, mx = 0; // beads, 64-bead chunks, clusters, cells of > 64 beads
     for (int c = c0; c < c1; ++c) {
         const int k = count[c];
+        const int ko = count_own ? count_own[c] : k;
         sa += k;
-        sb += (k + CHUNK - 1) / CHUNK;
-        sc += cell_clusters(k, count_own ? count_own[c] : k);
+        sb += a.split ? ((k - ko + 7) >> 3) : (k + CHUNK - 1) / CHUNK;
+        sc += a.split ? ((ko + 7) >> 3) : cell_clusters(k, ko);
         sd += k > 64 ? 1 : 0;
         mx = max(mx, k);
     }
@@ -443,15 +448,17 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
         istart[c] = rb;
         cstart[c] = rcl;
         if (k > 64) biglist[rd++] = c; // cells the order kernel sorts with a whole block, one per block
+        const int ko = count_own ? count_own[c] : k;
         ra += k;
-        rb += (k + CHUNK - 1) / CHUNK;
-        rcl += cell_clusters(k, count_own ? count_own[c] : k);
+        rb += a.split ? ((k - ko + 7) >> 3) : (k + CHUNK - 1) / CHUNK;
+        rcl += a.split ? ((ko + 7) >> 3) : cell_clusters(k, ko);
     }
     if (t == 1023) {
         start[G.ncells] = tot_a;
         istart[G.ncells] = tot_b;
         cstart[G.ncells] = tot_c;
-        st->n_clusters = tot_c;
+        st->n_clusters = a.split ? tot_c + tot_b : tot_c;
+        st->n_clusters_own = tot_c;
         st->n_big = tot_d;
         st->n3_items = 0; // k_n3_items (next in the stream) counts them
         st->n3_queue = 0;
@@ -501,7 +508,8 @@ __global__ __launch_bounds__(256) void k_cell_fill(int n_all, const int *__restr
 // padded cluster positions + boxes of one sorted cell; `nthr` cooperating threads, thread index `tid`
 // `no`: owned beads of the cell (they come first in the sorted order: order_key); the ghosts start a new cluster, so that
 // a cluster is all-owned or all-ghost (the half-shell kernel weights energies and drops reactions per cluster).
-__device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int cb, const int *__restrict__ perm,
+// cbg: first cluster of the cell's ghosts (split layout), or -1: right behind the owned ones.
+__device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int cb, const int cbg, const int *__restrict__ perm,
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, const Own &own,
@@ -520,8 +528,10 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
             nown = own.owns(b) ? 1 : 0;
             bead = b;
         }
-        spos4[(size_t)cb * 8 + e] = p;
-        if (sbead) sbead[(size_t)cb * 8 + e] = bead; // slot -> bead (k_nb_n3_unsort reads 4 bytes per slot, not a float4)
+        // slot of entry e: the owned clusters at cb, the ghosts' either right behind them or in their own region
+        const size_t sl = (cbg < 0 || e < o8) ? (size_t)cb * 8 + e : (size_t)cbg * 8 + (e - o8);
+        spos4[sl] = p;
+        if (sbead) sbead[sl] = bead; // slot -> bead (k_nb_n3_unsort reads 4 bytes per slot, not a float4)
         const float big = 3.0e38f;
         float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
         float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
@@ -540,8 +550,9 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
         if ((e & 7) == 0) { // lo.w = cell id, hi.w = (owned beads << 8) | beads of the cluster
             // one 32-byte record per cluster: {lo, hi} interleaved in cl_lo (cl_hi is unused: both halves of a box are
             // then fetched by two back-to-back 16-byte loads from one address)
-            cl_lo[2 * (cb + (e >> 3))] = make_float4(lx, ly, lz, __int_as_float(c));
-            cl_lo[2 * (cb + (e >> 3)) + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | nreal));
+            const size_t cl = sl >> 3;
+            cl_lo[2 * cl] = make_float4(lx, ly, lz, __int_as_float(c));
+            cl_lo[2 * cl + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | nreal));
         }
     }
 }
@@ -669,7 +680,9 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  const int *__restrict__ biglist,
                                                  MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
                                                  int *__restrict__ sbead = nullptr, const int slot_cap = 0,
-                                                 const int slot_cells = 0) {
+                                                 const int slot_cells = 0, const int split = 0) {
+    // split: the ghosts' clusters of cell c start at n_clusters_own + istart[c] (ScanArgs::split)
+    const int gbase = split ? st->n_clusters_own : 0;
     // slot_cap > 0: `okeys` is the slot table the pack wrote (keys of cell c at c * slot_cap), not the counting sort's slices
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -695,7 +708,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (count_own) count_own[c] = 0;
         }
         if (cnt == 0) continue;
-        if (lane == 0) items[istart[c]] = make_int2(c, 0);
+        if (lane == 0 && !split) items[istart[c]] = make_int2(c, 0);
         if (cnt > 1 || slot_cap) { // (slot table: perm has no fill behind it, a single bead is written here too)
             unsigned long long v = kmax;
             if (lane < cnt) v = okeys[kb + lane];
@@ -713,7 +726,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own, nullptr, sbead);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -731,7 +744,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (count_own) count_own[c] = 0;
         }
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
-        for (int k = threadIdx.x; k < nchunk; k += 256) items[ib + k] = make_int2(c, k);
+        for (int k = threadIdx.x; k < nchunk && !split; k += 256) items[ib + k] = make_int2(c, k);
         if (cnt <= 1024) { // keys in registers, <= 3 exchanges through LDS
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
@@ -740,7 +753,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + kb, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + kb, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead);
+            emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -802,7 +815,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             // the evaluation is void (decomposed handles always run the CAP = 4096 instance: > 4096 beads in one cell)
             if (count_own) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
         }
-        emit_clusters(c, s, cnt, no, cstart[c], perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead);
     }
 }
 
@@ -821,7 +834,7 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const int slot_cells = 0) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells);
+                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, 0);
 }
 
 } // namespace mmx

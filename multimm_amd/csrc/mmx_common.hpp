@@ -128,6 +128,8 @@ struct MinState {
     int ncells, max_per_cell;
     int nan_seen;
     int n_clusters; // 8-bead clusters of the last cell build
+    int n_clusters_own; // ... of them clusters of owned beads, listed FIRST when the build keeps the ghosts' clusters in a region
+                        // of their own (decomposed ranks running the half-shell kernel: cell_scan_block, `split`); else = n_clusters
     int order_fallbacks; // cells too large for the in-LDS sort since the state was pushed (arrival order kept)
     int n_big;           // cells of > 64 beads in the last cell build (sorted by a whole block each)
     int n3_items;        // work items of the half-shell pair kernel (k_n3_items, after every cell scan)

@@ -816,8 +816,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             hipLaunchKernelGGL(k_cell_count, dim3(ga), dim3(256), 0, h->stream, h->n_all, own_of(h), h->pos4,
                                cur, h->cell_of, h->rank_in_cell, h->count, h->st, h->count_own);
         // (count_own: decomposed handles only -- a cell's owned beads and its ghosts form separate clusters)
+        h->n3_build = use_n3(h); // latched per build: the pair kernel that follows must be the one whose work items exist
+        // decomposed ranks on the half-shell kernel: the ghosts' clusters in a region of their own behind the owned ones
+        const int split = (dd && h->n3_build && h->count_own && h->dd_split) ? 1 : 0;
         const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next,
-                          h->count_own};
+                          h->count_own, split};
         if (in_scan) { // block 0 scans, the others are the bonded pass (four virtual 256-thread blocks each)
             const int nvb = grid_beads(h->n_own);
             const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
@@ -842,20 +845,19 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         // (decomposed ranks always take the 4096-bead instance: a cell that outgrows the sort is an error there, see cell_order_block)
         const bool small_cells = !dd && h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
         const int go = small_cells ? 2048 : 1024;
-        h->n3_build = use_n3(h); // latched per build: the pair kernel that follows must be the one whose work items exist
         if (h->n3_build) {
             if (small_cells)
                 hipLaunchKernelGGL((k_order_items<kChunk, 1024>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells);
+                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells, split);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells);
+                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells, split);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,

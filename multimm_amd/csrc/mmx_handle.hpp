@@ -281,6 +281,8 @@ struct mmx_handle_s {
     // build.  reuse_K follows the displacements the polls read back (pull_state).
     // Slot table (SlotArgs, mmx_cells.hpp): trial moves write their sort keys straight into per-cell slots, no k_cell_fill
     int cell_slots = 1;           // option
+    int dd_split = 1;             // option: decomposed ranks on the half-shell kernel keep the ghosts' clusters in a region of their own
+                                  // (ghost clusters are never i-clusters: ScanArgs::split); 0 = interleaved per cell, for the A/B
     unsigned long long *slotkeys = nullptr;
     int slot_cap = 0, slot_cells = 0;
     bool slots_now = false;       // the build being enqueued uses the table

@@ -82,13 +82,21 @@ constexpr float kN3Fix = 8192.f;
 constexpr float kN3FixLim = (float)(2147483648.0 / 32) * 0.999f; // 2^26 units = 8192 kJ/mol/nm: items of up to 32 clusters
 static_assert(n3_item_shape(true).dense_run <= 32 && kN3ItemClusters <= 32, "a window slot must not overflow");
 
-struct N3Item { // 64 bytes
+struct N3Item { // 128 bytes; a single-domain launch reads the first 64 only
     int a, n;          // i-clusters [a, a + n)
     int T;             // length of the concatenated candidate runs
     int pad0;
-    int rlo[5], rn[5]; // the runs: clusters [rlo, rlo + rn)
+    int rlo[5], rn[5]; // the half-shell runs: clusters [rlo, rlo + rn)
     int pad1[2];
+    // decomposed ranks (split cluster list: the ghosts' clusters in a region of their own behind the owned ones): the ghost
+    // clusters of the 3 x 3 rows around the item, cells xa - 1 .. xb + 1 -- the FULL stencil, because ghost clusters are never
+    // i-clusters: every owned-ghost pair is taken from the owned side
+    int grlo[9];
+    unsigned short grn[10];
+    int pad2[2];
 };
+static_assert(sizeof(N3Item) == 128, "N3Item is two 64-byte halves");
+constexpr int kN3Runs = 5, kN3GhostRuns = 9;
 
 // dynamic LDS of k_nb_n3 for windows of `cap` clusters: two force windows, two box buffers, four id buffers
 constexpr size_t n3_lds_bytes(int cap) {
@@ -118,6 +126,24 @@ constexpr int kN3SpinLimit = 1 << 22; // s_sleep rounds before a waiting wave gi
 struct N3Row {
     const int *cstart;
     int nx, base[5]; // cell index of x = 0 in the five candidate rows (-1: the row does not exist)
+    const int *gstart; // split layout: ghost-cluster offsets per cell (nullptr: no ghost runs), gbase: id of the first ghost cluster
+    int gbase, gb[9];  // cell index of x = 0 in the nine rows around the item (-1: outside the grid)
+    __device__ __forceinline__ int TG(int xa, int xb, int *grlo, unsigned short *grn) const {
+        const int x0 = max(xa - 1, 0), x1 = min(xb + 1, nx - 1);
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            grlo[r] = 0;
+            grn[r] = 0;
+            if (gstart && gb[r] >= 0) {
+                const int lo = gstart[gb[r] + x0], len = gstart[gb[r] + x1 + 1] - lo;
+                grlo[r] = gbase + lo;
+                grn[r] = (unsigned short)min(len, 65535);
+                t += (int)grn[r];
+            }
+        }
+        return t;
+    }
     // candidate runs of i-clusters [a, ...) that live in cells xa..xb of row base[0]; returns T
     __device__ __forceinline__ int T(int a, int xa, int xb, int *rlo, int *rn) const {
         const int x0 = max(xa - 1, 0), x1 = min(xb + 1, nx - 1);
@@ -181,7 +207,8 @@ __device__ __forceinline__ N3Cell n3_cell(const N3ItemShape S, const int *__rest
 // `bid` of `nblk` workgroups of 256 threads
 __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
                                                const int *__restrict__ cstart, N3Item *__restrict__ items, int max_items,
-                                               MinState *__restrict__ st, const bool long_items) {
+                                               MinState *__restrict__ st, const bool long_items,
+                                               const int *__restrict__ gstart = nullptr) {
     const GridParams G = *grid;
     const N3ItemShape S = n3_item_shape(long_items);
     const int nrows = G.ny * G.nz, nx = G.nx;
@@ -191,6 +218,13 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         R.cstart = cstart;
         R.nx = nx;
         const int y = row % G.ny, z = row / G.ny;
+        R.gstart = gstart;
+        R.gbase = gstart ? st->n_clusters_own : 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
+            R.gb[r] = (gstart && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) ? (zz * G.ny + yy) * nx : -1;
+        }
         R.base[0] = row * nx;
         R.base[1] = y + 1 < G.ny ? (row + 1) * nx : -1;
 #pragma unroll
@@ -250,9 +284,11 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
                 N3Item it;
                 it.a = a;
                 it.n = n;
-                it.T = R.T(a, x, xb, it.rlo, it.rn);
+                it.T = R.T(a, x, xb, it.rlo, it.rn) + R.TG(x, xb, it.grlo, it.grn);
                 it.pad0 = 0;
                 it.pad1[0] = it.pad1[1] = 0;
+                it.grn[9] = 0;
+                it.pad2[0] = it.pad2[1] = 0;
                 items[at + j] = it;
             }
             first += chunk_total;
@@ -277,15 +313,16 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
                                                      MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
                                                      int *__restrict__ sbead = nullptr, const int n3_long_items = 0,
-                                                     const int slot_cap = 0, const int slot_cells = 0) {
+                                                     const int slot_cap = 0, const int slot_cells = 0, const int split = 0) {
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
-        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st, n3_long_items != 0);
+        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st, n3_long_items != 0,
+                       split ? istart : nullptr);
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells);
+                                 spos4, cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, split);
 }
 
 #ifdef MMX_N3_TIMING
@@ -327,12 +364,16 @@ __device__ __forceinline__ int cvt_nearest(float v) {
 
 // fsort: force (not gradient) per cluster slot, SoA [3][fstride]; zero on entry, k_nb_n3_unsort zeroes it again.
 //
-// DD (decomposed runs: the cell list holds this rank's owned beads AND its ghosts, in separate clusters -- emit_clusters):
-// every pair with at least one owned bead is still evaluated once, by the cluster with the lower id, whichever side owns
-// what; pairs of two ghosts are not evaluated at all (an all-ghost i-cluster culls all-ghost candidates).  Forces that
-// land on ghost slots -- the i side of a ghost cluster, the reaction on a ghost j bead -- are dropped by
-// k_nb_n3_unsort: the ghost's owner computes them itself.  Energies are weighted 1/2 (own_i + own_j): each rank books
-// half of every cross-rank pair, all of every pair it owns both beads of.
+// DD (decomposed runs: the cell list holds this rank's owned beads AND its ghosts, in separate clusters -- emit_clusters).
+// Split layout (default, ScanArgs::split): the owned clusters come first in the cluster list, the ghosts' behind them; work
+// items are cut from the owned clusters only, and an item's window is its five half-shell runs of owned clusters followed by
+// nine runs of ghost clusters -- the FULL 3 x 3 rows around it -- so that every owned-ghost pair is taken from the owned side
+// and a ghost cluster is never an i-cluster (no visit, no cull, no flush for it: its window sums are dropped in LDS).
+// Interleaved layout (option dd_split = 0, and what a single domain forced onto this instance sees): every pair with at
+// least one owned bead is evaluated once, by the cluster with the lower id, whichever side owns what; an all-ghost
+// i-cluster culls all-ghost candidates, and forces that land on ghost slots are dropped by k_nb_n3_unsort.
+// Either way pairs of two ghosts are never evaluated and energies are weighted 1/2 (own_i + own_j): each rank books half of
+// every cross-rank pair, all of every pair it owns both beads of.  (A/B of the two layouts: profiles/r04_dd_split_ab.txt.)
 template <int PMODE, bool EV, bool GAUSS, bool NOENERGY, bool DD = false>
 __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const float4 *__restrict__ spos4,
                                                           const float4 *__restrict__ cl_box,
@@ -359,7 +400,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     __shared__ __attribute__((aligned(32))) float s_tab[5 * 8];
     __shared__ float s_arow[kN3Waves][kCl * 8];
     __shared__ double s_e[2][kN3Waves];
-    __shared__ int s_desc[2][16]; // unit descriptors: a, n, T, wlo, rlo[5], rn[5], id buffer, share | log2(shares) << 8
+    __shared__ int s_desc[2][DD ? 40 : 16]; // unit descriptors: a, n, T, wlo, rlo[5], rn[5], id buffer, share | log2(shares) << 8
+                                            // (decomposed ranks: + the nine ghost runs, grlo at 16, grn at 25)
     __shared__ N3Ctl ctl;
     // the wave index in a scalar register: hipcc cannot prove threadIdx.x >> 6 uniform and would otherwise keep the
     // scalar i beads in vector registers
@@ -373,6 +415,9 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     int *const box0 = s_f + 2 * 3 * fstr;           // box buffers
     int *const ids0 = box0 + 2 * 8 * (cap + 1);     // id buffers
     const int far_cl = P.n_all; // a resident all-padding cluster (8 beads at -1e18)
+    // decomposed ranks: clusters from here on are ghosts' (the split cluster list of cell_scan_block): what lands on their
+    // slots is nobody's business on this rank -- the flush and the large-sum bypass skip them, the unsort never reads them
+    const int n_own_cl = DD ? st->n_clusters_own : 0x7fffffff;
     const Own own = P.own();
     const int n_items = st->n3_items;
     if (threadIdx.x < 40) {
@@ -447,7 +492,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                     wx[e] = 0;
                     wy[e] = 0;
                     wz[e] = 0;
-                    if (!(diag & 1)) {
+                    if (!(diag & 1) && jcs[e >> 3] < n_own_cl) {
                         const int gs = jcs[e >> 3] * kCl + (e & 7);
                         atomicAdd(fsort + gs, unfix * (float)vx);
                         atomicAdd(fsort + fstride + gs, unfix * (float)vy);
@@ -470,7 +515,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // window -- candidate k of the concatenated runs -> cluster id, box -- and writes its descriptor.  One wave.
     auto stage_unit = [&](int v) {
         const int p = v & 1, ib = v & 3;
-        int a = 0, n = 0, T = 0, wlo = 0, rlo[5], rn[5], shr = 0;
+        constexpr int NR = DD ? kN3Runs + kN3GhostRuns : kN3Runs; // candidate runs of an item (decomposed ranks: + the ghosts')
+        int a = 0, n = 0, T = 0, wlo = 0, rlo[NR], rn[NR], shr = 0;
         bool fetch = true;
         if (v > 0) { // unit v - 1 sits in the other parity
             const int *pd = s_desc[p ^ 1];
@@ -486,6 +532,13 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 for (int r = 0; r < 5; ++r) {
                     rlo[r] = __builtin_amdgcn_readfirstlane(pd[4 + r]);
                     rn[r] = __builtin_amdgcn_readfirstlane(pd[9 + r]);
+                }
+                if (DD) {
+#pragma unroll
+                    for (int r = 0; r < kN3GhostRuns; ++r) {
+                        rlo[(DD ? 5 : 0) + r] = __builtin_amdgcn_readfirstlane(pd[(DD ? 16 : 0) + r]);
+                        rn[(DD ? 5 : 0) + r] = __builtin_amdgcn_readfirstlane(pd[(DD ? 25 : 0) + r]);
+                    }
                 }
             }
         }
@@ -534,21 +587,30 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 rn[2] = __builtin_amdgcn_readfirstlane(v2.w);
                 rn[3] = __builtin_amdgcn_readfirstlane(v3.x);
                 rn[4] = __builtin_amdgcn_readfirstlane(v3.y);
+                if (DD) { // second half of the record: the ghost runs (ints 16..24: first clusters, 25..29: nine 16-bit lengths)
+                    const int4 g0 = pi[4], g1 = pi[5], g2 = pi[6], g3 = pi[7];
+                    const int gw[14] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y};
+#pragma unroll
+                    for (int r = 0; r < kN3GhostRuns; ++r) {
+                        rlo[(DD ? 5 : 0) + r] = __builtin_amdgcn_readfirstlane(gw[r]);
+                        rn[(DD ? 5 : 0) + r] = (__builtin_amdgcn_readfirstlane(gw[9 + (r >> 1)]) >> ((r & 1) * 16)) & 0xffff;
+                    }
+                }
             }
         }
         if (n > 0) {
             float4 *box = reinterpret_cast<float4 *>(box0 + p * 8 * (cap + 1));
             int *jcs = ids0 + ib * (cap + 8);
             const int nwin = min(T, wlo + cap) - wlo;
-            int woff[5];
+            int woff[NR];
             woff[0] = 0;
 #pragma unroll
-            for (int r = 1; r < 5; ++r) woff[r] = woff[r - 1] + rn[r - 1];
+            for (int r = 1; r < NR; ++r) woff[r] = woff[r - 1] + rn[r - 1];
             for (int k = lane; k < nwin; k += 64) {
                 const int kk = wlo + k;
                 int jc = rlo[0] + kk;
 #pragma unroll
-                for (int r = 1; r < 5; ++r) jc = kk >= woff[r] ? rlo[r] + (kk - woff[r]) : jc;
+                for (int r = 1; r < NR; ++r) jc = kk >= woff[r] ? rlo[r] + (kk - woff[r]) : jc;
                 jcs[k] = jc;
                 box[2 * k] = cl_box[2 * jc];
                 box[2 * k + 1] = cl_box[2 * jc + 1];
@@ -560,7 +622,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
             if (wlo > 0) atomicAdd(&g_n3_t[blockIdx.x * 20 + 18], 1ull);
         }
 #endif
-        if (lane < 16) {
+        if (lane < (DD ? 40 : 16)) {
             int val = 0;
             if (n > 0) {
                 val = lane == 0 ? a : lane == 1 ? n : lane == 2 ? T : lane == 3 ? wlo : lane == 14 ? ib : lane == 15 ? shr : 0;
@@ -568,6 +630,13 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 for (int r = 0; r < 5; ++r) {
                     val = lane == 4 + r ? rlo[r] : val;
                     val = lane == 9 + r ? rn[r] : val;
+                }
+                if (DD) {
+#pragma unroll
+                    for (int r = 0; r < kN3GhostRuns; ++r) {
+                        val = lane == 16 + r ? rlo[(DD ? 5 : 0) + r] : val;
+                        val = lane == 25 + r ? rn[(DD ? 5 : 0) + r] : val;
+                    }
                 }
             }
             s_desc[p][lane] = val;
@@ -831,7 +900,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                                 if (GAUSS) eg = fmaf(self ? gb + arow[(jslot & 7) * 8 + lj] : gb, (self ? 0.5f : 1.f) * wl, eg);
                             }
                             if (!(diag & 2)) {
-                                if (big && !self) { // rare (overlapping beads): straight to global memory
+                                if (big && !self && s_jc[jslot >> 3] < n_own_cl) { // rare (overlapping beads): straight to global memory
                                     const int gs = s_jc[jslot >> 3] * kCl + (jslot & 7);
                                     atomicAdd(fsort + gs, -pscale * fjx);
                                     atomicAdd(fsort + fstride + gs, -pscale * fjy);
@@ -964,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_nb_n3_unsort(const int *__restrict__ sb
                                                       MinState *__restrict__ st, const Own own) {
     if (st->phase >= PH_DONE) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->n3_queue = 0;
-    const int nsl = st->n_clusters * kCl;
+    const int nsl = st->n_clusters_own * kCl; // (decomposed ranks: the ghosts' clusters lie behind and are never written)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nsl; i += gridDim.x * 256) {
         const int bead = sbead[i];
         const float fx = fsort[i], fy = fsort[fstride + i], fz = fsort[2 * fstride + i];
