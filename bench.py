@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--n-beads", type=int, default=0, help="rescale the workload (parity/debug only)")
     ap.add_argument("--cutoff", type=float, default=0.6, help="pair cutoff in nm; <=0 = NoCutoff all-pairs")
     ap.add_argument("--jitter", type=float, default=0.0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg; 0 disables")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg; 0 disables")
     ap.add_argument("--profile-every", type=int, default=16,
                     help="HIP-event time every kernel slot of every k-th evaluation inside the timed region "
                          "(an event pair costs ~10 us of stream time: 16 keeps the perturbation < 1 %%)")
