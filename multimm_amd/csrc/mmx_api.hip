@@ -114,7 +114,9 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
             HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
             h->n3_cap = n3_configure(kN3MaxCap);
-            // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16
+            // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16 (<= n_all /
+            // 128 + cells / 16) runs; a run is one record per window pass over its candidates: the rest of n_all / 16 is theirs
+            // (a list that overflows all the same voids the evaluation: KERR_N3_ITEMS)
             h->n3_max_items = std::min(h->maxcells, h->n_all) + h->n_all / 16 + 64;
             HIPCHK(h, dalloc(&h->n3_items, (size_t)h->n3_max_items));
             h->n_cus = prop.multiProcessorCount;
@@ -585,10 +587,12 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else if (k == "inject_fault") h->inject_fault = (int)value;
-    else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value != 0.0;
+    else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value == 2.0 ? 2 : value != 0.0;
     else if (k == "dd_freeze") h->dd_frozen = value != 0.0;
     else if (k == "cell_slots") h->cell_slots = value != 0.0;
     else if (k == "dd_split") h->dd_split = value != 0.0;
+    else if (k == "n3_pass_records") h->n3_pass_records = value != 0.0;
+    else if (k == "n3_slice_cap") h->n3_slice_cap = std::max(0, std::min((int)value, (int)kN3MaxCap));
     else if (k == "cell_reuse") { h->cell_reuse = value != 0.0; h->reuse_K = 1; h->struct_valid = false; }
     else if (k == "cell_reuse_factor") h->reuse_factor = value > 0.0 ? (float)std::max(1.0, value) : 0.f;
     else if (k == "cell_edge_auto") { h->cell_edge_auto = value != 0.0; h->edge_auto = 1.f; }
@@ -640,6 +644,8 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_collective_samples") *value = (double)h->coll_samples[kCollAllreduce];
     else if (k == "cell_slots") *value = h->cell_slots;
     else if (k == "dd_split") *value = h->dd_split;
+    else if (k == "n3_pass_records") *value = h->n3_pass_records;
+    else if (k == "n3_slice_cap") *value = h->n3_slice_cap;
     else if (k == "cell_slot_halts") *value = (double)h->slot_halts;
     else if (k == "cell_reuse") *value = h->cell_reuse;
     else if (k == "cell_builds") *value = (double)h->cell_builds;     // read-only: tracked full builds / evaluations on a kept

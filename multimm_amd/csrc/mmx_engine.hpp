@@ -851,13 +851,13 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells, split);
+                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0, scap, scells, split);
+                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,

@@ -281,6 +281,8 @@ struct mmx_handle_s {
     // build.  reuse_K follows the displacements the polls read back (pull_state).
     // Slot table (SlotArgs, mmx_cells.hpp): trial moves write their sort keys straight into per-cell slots, no k_cell_fill
     int cell_slots = 1;           // option
+    int n3_slice_cap = 0;         // option: longest window slice of a record, in clusters (0: the LDS window, kN3MaxCap)
+    int n3_pass_records = 1;      // option: a run's window passes are records of the item list of their own (N3Item::w0); 0: for the A/B
     int dd_split = 1;             // option: decomposed ranks on the half-shell kernel keep the ghosts' clusters in a region of their own
                                   // (ghost clusters are never i-clusters: ScanArgs::split); 0 = interleaved per cell, for the A/B
     unsigned long long *slotkeys = nullptr;

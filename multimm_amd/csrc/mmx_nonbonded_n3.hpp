@@ -20,7 +20,8 @@
 // are i-clusters themselves and take the pair from their side; its own id = the self tile) that the box-box test
 // accepts; candidates of cells that are not adjacent to the i-cluster's cell are at least one cell edge >= cutoff
 // away, so geometry alone keeps the half shell exact.  A run whose candidates do not fit the window is processed in
-// several passes over slices of the index space (only the densest cells, e.g. the lattice start).
+// several passes over equal slices of the index space; every pass is a record of the item list of its own (N3Item::w0), so
+// the passes of a run are taken by different workgroups at about the same time.
 //
 // Execution: ONE persistent workgroup of 16 waves per CU pulls items from a global queue (from its far end: descending
 // rows).  A unit = (item, slice of its candidate index space).  Two units are in flight per workgroup, each with its own
@@ -71,8 +72,8 @@ struct N3ItemShape {
     int dense;     // a cell of at least this many clusters is cut by itself (fewer still fit one window across a cell boundary)
     int dense_run; // ... into equal runs of at most this many clusters: 14 n candidates must fit the window
 };
-__host__ __device__ constexpr N3ItemShape n3_item_shape(bool long_items) {
-    return long_items ? N3ItemShape{kN3ItemClusters, 17, 30} : N3ItemShape{kN3ItemClustersSmall, 22, 16};
+__host__ __device__ constexpr N3ItemShape n3_item_shape(int long_items) { // 0 short, 1 long, 2 (measurement) two visits per wave
+    return long_items == 2 ? N3ItemShape{32, 22, 32} : long_items ? N3ItemShape{kN3ItemClusters, 17, 30} : N3ItemShape{kN3ItemClustersSmall, 22, 16};
 }
 constexpr int kN3List = 192;        // accepted j-clusters buffered per wave before a sweep (culled 128 candidates at a time)
 constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two windows in flight: 160 KB of LDS, all of it)
@@ -80,12 +81,14 @@ constexpr int kN3MaxCap = 424;      // largest LDS window, in clusters (two wind
 // overflow; a larger one (overlapping beads) bypasses LDS with a global float atomic.
 constexpr float kN3Fix = 8192.f;
 constexpr float kN3FixLim = (float)(2147483648.0 / 32) * 0.999f; // 2^26 units = 8192 kJ/mol/nm: items of up to 32 clusters
-static_assert(n3_item_shape(true).dense_run <= 32 && kN3ItemClusters <= 32, "a window slot must not overflow");
+static_assert(n3_item_shape(1).dense_run <= 32 && n3_item_shape(2).dense_run <= 32 && kN3ItemClusters <= 32, "a window slot must not overflow");
 
 struct N3Item { // 128 bytes; a single-domain launch reads the first 64 only
     int a, n;          // i-clusters [a, a + n)
-    int T;             // length of the concatenated candidate runs
-    int pad0;
+    int T;             // END of this record's slice of the concatenated candidate runs (see w0)
+    int w0;            // START of the slice.  A run whose candidates do not fit one LDS window is emitted as several records,
+                       // one per window pass, with slices of equal length: the passes are queue entries of their own (any
+                       // workgroup takes them, at the same time) instead of consecutive units of one workgroup
     int rlo[5], rn[5]; // the half-shell runs: clusters [rlo, rlo + rn)
     int pad1[2];
     // decomposed ranks (split cluster list: the ghosts' clusters in a region of their own behind the owned ones): the ghost
@@ -207,8 +210,9 @@ __device__ __forceinline__ N3Cell n3_cell(const N3ItemShape S, const int *__rest
 // `bid` of `nblk` workgroups of 256 threads
 __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
                                                const int *__restrict__ cstart, N3Item *__restrict__ items, int max_items,
-                                               MinState *__restrict__ st, const bool long_items,
-                                               const int *__restrict__ gstart = nullptr) {
+                                               MinState *__restrict__ st, const int long_items,
+                                               const int *__restrict__ gstart = nullptr, const bool pass_records = true,
+                                               const int slice_cap = kN3MaxCap) {
     const GridParams G = *grid;
     const N3ItemShape S = n3_item_shape(long_items);
     const int nrows = G.ny * G.nz, nx = G.nx;
@@ -233,12 +237,43 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         const int *cs = cstart + R.base[0];
         const int c_hi = cs[nx];
         if (c_hi == cs[0]) continue; // empty row
-        // pass 1: runs of the row
+        // geometry of run j of a cell: i-clusters [a, a + n) in cells x..xb of the row
+        auto run_of = [&](const N3Cell &C, int x, int j, int &a, int &n, int &xb) {
+            xb = x;
+            if (C.dense) { // runs of equal length (27 clusters: 14 + 13, not 16 + 11)
+                a = C.c0 + (int)(((long long)C.n * j) / C.runs);
+                n = C.c0 + (int)(((long long)C.n * (j + 1)) / C.runs) - a;
+            } else {
+                const int m0 = (C.p + S.run - 1) / S.run * S.run; // first run start at or after p
+                a = C.c0 + (m0 - C.p) + j * S.run;
+                n = min(S.run, c_hi - a);
+                while (a + n > cs[xb + 1]) { // the run goes on into the next cell, unless that one is dense
+                    if (cs[xb + 2] - cs[xb + 1] >= S.dense) {
+                        n = cs[xb + 1] - a;
+                        break;
+                    }
+                    ++xb;
+                }
+            }
+        };
+        // records of a lane's runs: one per window pass
+        auto records_of = [&](const N3Cell &C, int x) {
+            int cnt = 0;
+            for (int j = 0; j < C.runs; ++j) {
+                int a, n, xb, rlo[5], rn[5], grlo[9];
+                unsigned short grn[9];
+                run_of(C, x, j, a, n, xb);
+                const int T = R.T(a, x, xb, rlo, rn) + R.TG(x, xb, grlo, grn);
+                cnt += pass_records ? max(1, (T + slice_cap - 1) / slice_cap) : 1;
+            }
+            return cnt;
+        };
+        // pass 1: records of the row
         int total = 0, carry_p = 0;
         bool carry_dense = true; // the row start opens a segment
         for (int xc = 0; xc < nx; xc += 64) {
             const N3Cell C = n3_cell(S, cs, nx, xc + lane, lane, carry_p, carry_dense);
-            int r = C.runs;
+            int r = records_of(C, xc + lane);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
             total += r;
@@ -246,7 +281,7 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         int first = 0;
         if (lane == 0) first = atomicAdd(&st->n3_items, total);
         first = __builtin_amdgcn_readfirstlane(first);
-        if (first + total > max_items) { // cannot happen (the list has room for a run per cell plus one per 16 clusters)
+        if (first + total > max_items) { // cannot happen (the list has room for a run per cell plus one per 8 beads)
             if (lane == 0) atomicOr(&st->kernel_error, (int)KERR_N3_ITEMS); // the controller voids the evaluation
             continue;
         }
@@ -256,40 +291,32 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
         for (int xc = 0; xc < nx; xc += 64) {
             const int x = xc + lane;
             const N3Cell C = n3_cell(S, cs, nx, x, lane, carry_p, carry_dense);
-            int inc = C.runs; // inclusive scan of the run counts: where my runs go
+            const int mine = records_of(C, x);
+            int inc = mine; // inclusive scan of the record counts: where my records go
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int u = __shfl_up(inc, o, 64);
                 if (lane >= o) inc += u;
             }
             const int chunk_total = __shfl(inc, 63, 64);
-            const int at = first + inc - C.runs;
+            int at = first + inc - mine;
             for (int j = 0; j < C.runs; ++j) {
-                int a, n, xb = x;
-                if (C.dense) { // runs of equal length (27 clusters: 14 + 13, not 16 + 11)
-                    a = C.c0 + (int)(((long long)C.n * j) / C.runs);
-                    n = C.c0 + (int)(((long long)C.n * (j + 1)) / C.runs) - a;
-                } else {
-                    const int m0 = (C.p + S.run - 1) / S.run * S.run; // first run start at or after p
-                    a = C.c0 + (m0 - C.p) + j * S.run;
-                    n = min(S.run, c_hi - a);
-                    while (a + n > cs[xb + 1]) { // the run goes on into the next cell, unless that one is dense
-                        if (cs[xb + 2] - cs[xb + 1] >= S.dense) {
-                            n = cs[xb + 1] - a;
-                            break;
-                        }
-                        ++xb;
-                    }
-                }
+                int a, n, xb;
+                run_of(C, x, j, a, n, xb);
                 N3Item it;
                 it.a = a;
                 it.n = n;
-                it.T = R.T(a, x, xb, it.rlo, it.rn) + R.TG(x, xb, it.grlo, it.grn);
-                it.pad0 = 0;
+                const int T = R.T(a, x, xb, it.rlo, it.rn) + R.TG(x, xb, it.grlo, it.grn);
                 it.pad1[0] = it.pad1[1] = 0;
                 it.grn[9] = 0;
                 it.pad2[0] = it.pad2[1] = 0;
-                items[at + j] = it;
+                // (option n3_pass_records = 0, for the A/B: one record per run, the workgroup that takes it walks the passes itself)
+                const int np = pass_records ? max(1, (T + slice_cap - 1) / slice_cap) : 1;
+                for (int q = 0; q < np; ++q) { // slices of equal length (<= the window)
+                    it.w0 = (int)(((long long)T * q) / np);
+                    it.T = (int)(((long long)T * (q + 1)) / np);
+                    items[at++] = it;
+                }
             }
             first += chunk_total;
         }
@@ -317,8 +344,9 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
-        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st, n3_long_items != 0,
-                       split ? istart : nullptr);
+        n3_items_block((int)blockIdx.x, n_items_blocks, grid, cstart, n3_items, n3_max_items, st, (n3_long_items & 4) ? 2 : (n3_long_items & 1),
+                       split ? istart : nullptr, !(n3_long_items & 2),
+                       (n3_long_items >> 8) > 0 ? min(n3_long_items >> 8, kN3MaxCap) : kN3MaxCap);
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
@@ -418,7 +446,6 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // decomposed ranks: clusters from here on are ghosts' (the split cluster list of cell_scan_block): what lands on their
     // slots is nobody's business on this rank -- the flush and the large-sum bypass skip them, the unsort never reads them
     const int n_own_cl = DD ? st->n_clusters_own : 0x7fffffff;
-    const Own own = P.own();
     const int n_items = st->n3_items;
     if (threadIdx.x < 40) {
         const bool in5 = (threadIdx.x & 7) < 5;
@@ -577,6 +604,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 a = __builtin_amdgcn_readfirstlane(v0.x);
                 n = __builtin_amdgcn_readfirstlane(v0.y);
                 T = __builtin_amdgcn_readfirstlane(v0.z);
+                wlo = __builtin_amdgcn_readfirstlane(v0.w); // the record's slice of the candidate index space: [w0, T)
                 rlo[0] = __builtin_amdgcn_readfirstlane(v1.x);
                 rlo[1] = __builtin_amdgcn_readfirstlane(v1.y);
                 rlo[2] = __builtin_amdgcn_readfirstlane(v1.z);
@@ -756,24 +784,34 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                 for (int g = (k0 >> sh) & ~63; (g << sh) < nwin; g += 128) {
                     // ---- cull: 128 candidate clusters of the window per step (two independent box reads in flight: the LDS
                     // round trip is what a step waits for), boxes from LDS
-                    bool ok[2];
+                    bool ok[2], jown[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int k = ((g + 64 * h + lane) << sh) + share;
                         ok[h] = false;
+                        jown[h] = false;
                         if (k >= k0 && k < nwin) {
                             const float4 lo_j = s_box[2 * k], hi_j = s_box[2 * k + 1];
                             const float dx = fmaxf(fmaxf(lo_j.x - hi_i.x, lo_i.x - hi_j.x), 0.f);
                             const float dy = fmaxf(fmaxf(lo_j.y - hi_i.y, lo_i.y - hi_j.y), 0.f);
                             const float dz = fmaxf(fmaxf(lo_j.z - hi_i.z, lo_i.z - hi_j.z), 0.f);
                             ok[h] = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < rc2;
-                            if (DD) ok[h] = ok[h] && (i_own || (__float_as_int(hi_j.w) >> 8) != 0); // never ghosts against ghosts
+                            // decomposed runs: a cluster is all-owned or all-ghost; never ghosts against ghosts.  Which of the
+                            // two the candidate is rides in bit 15 of its list entry (window indices stay below 2^9): the sweep
+                            // needs it per j bead for the energy weight, and a look-up in the ownership tables there would be a
+                            // dependent global load in every step of the stream
+                            if (DD) {
+                                jown[h] = (__float_as_int(hi_j.w) >> 8) != 0;
+                                ok[h] = ok[h] && (i_own || jown[h]);
+                            }
                         }
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const unsigned long long mask = __ballot(ok[h]);
-                        if (ok[h]) list[nlist + prefix_count(mask)] = (unsigned short)(((g + 64 * h + lane) << sh) + share);
+                        if (ok[h])
+                            list[nlist + prefix_count(mask)] =
+                                (unsigned short)((((g + 64 * h + lane) << sh) + share) | ((DD && jown[h]) ? 0x8000 : 0));
                         nlist += __builtin_amdgcn_readfirstlane(__popcll(mask));
                     }
                     const bool last = ((g + 128) << sh) >= nwin;
@@ -792,10 +830,11 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                     const unsigned long long tsw0 = wall_clock64();
 #endif
                     // ---- sweep: 8 j-clusters (64 j beads) per step; ids two steps ahead, positions one
+                    constexpr int kIdx = DD ? 0x7fff : 0xffff; // (list entry: window index | owned-cluster flag, see the cull)
                     int ln = list[sub];
-                    float4 qn = spos4[(unsigned)s_jc[ln] * kCl + slot];
+                    float4 qn = spos4[(unsigned)s_jc[ln & kIdx] * kCl + slot];
                     int ln2 = nsteps > 1 ? list[8 + sub] : cap;
-                    int jn = s_jc[ln2];
+                    int jn = s_jc[ln2 & kIdx];
                     for (int t = 0; t < nsteps; ++t) {
                         float4 q = qn;
                         const int lq = ln;
@@ -803,7 +842,7 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             qn = spos4[(unsigned)jn * kCl + slot];
                             ln = ln2;
                             ln2 = t + 2 < nsteps ? list[(t + 2) * 8 + sub] : cap;
-                            jn = s_jc[ln2];
+                            jn = s_jc[ln2 & kIdx];
                         }
                         // per-bead cull against the i box; survivors are compacted through the ring with their LDS slot
                         {
@@ -813,8 +852,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
                             const bool okb = fmaf(bx, bx, fmaf(by, by, bz * bz)) < rc2;
                             const unsigned long long mb = __ballot(okb);
                             if (okb) {
-                                int wj = (((lq << 3) | slot) << 3) | (__float_as_int(q.w) & 7);
-                                if (DD) wj |= own.owns(__float_as_int(q.w) >> 3) ? 1 << 15 : 0;
+                                // window slot (< 2^12) << 3 | label, bit 15: the j bead is owned
+                                const int wj = ((((lq & kIdx) << 3) | slot) << 3) | (__float_as_int(q.w) & 7) | (DD ? lq & 0x8000 : 0);
                                 q.w = __int_as_float(wj);
                                 ring[(rhead + rcount + prefix_count(mb)) & 127] = q;
                             }
