@@ -58,6 +58,8 @@ enum {
     MMX_K_LBFGS = 5,      /* K6: history pass of an evaluation ((s,y) candidate, Gram rows, g.d, x.x) */
     MMX_K_REDUCE = 6,     /* fold of the partials + line-search controller (+ direction coefficients) */
     MMX_K_CHB = 7,        /* chromosomal blocks: all pairs inside each chromosome */
+    MMX_K_FORCES = 100,   /* mmx_time_kernel only: every launch of ONE force evaluation as the minimizer enqueues them (pack,
+                             cell build with the bonded pass riding in the scan launch, pair kernel, unsort), no fold */
     MMX_N_KERNELS = 8
 };
 
@@ -347,7 +349,8 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out);
 /* ---- measurement ------------------------------------------------------------------------------
  * Launches kernel slot `kernel` (MMX_K_*) `reps` times back to back at the current positions on the
  * handle's stream between two HIP events and returns the mean duration per launch and the
- * algorithmic bytes one launch moves (DESIGN.md "Kernels").  Results of the launches are discarded. */
+ * algorithmic bytes one launch moves (DESIGN.md "Kernels").  Results of the launches are discarded.
+ * Slots 0..4 and MMX_K_FORCES; slots 2..4 as standalone launches (inside an evaluation they ride in the cell scan's launch). */
 int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes);
 /* Diagnostics of the last cell build: n_cells, max beads per cell, cell edge (nm), pair-candidate
  * count (bead x stencil occupancy) and pairs inside the cutoff; any pointer may be NULL. */

@@ -1109,8 +1109,8 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
 int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) try {
     if (!h || reps < 1 || !mean_us) return fail(h, MMX_ERR_BAD_ARG, "bad arguments");
     h->md_forces_valid = false;
-    if (kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE)
-        return fail(h, MMX_ERR_BAD_ARG, "mmx_time_kernel covers slots 0..4; L-BFGS slots are timed live (option profile)");
+    if ((kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE) && kernel != MMX_K_FORCES)
+        return fail(h, MMX_ERR_BAD_ARG, "mmx_time_kernel covers slots 0..4 and MMX_K_FORCES; L-BFGS slots are timed live (option profile)");
     int rc = prepare(h);
     if (rc) return rc;
     std::memset(h->st_host, 0, sizeof(MinState));
@@ -1173,6 +1173,10 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             hipLaunchKernelGGL(k_confine, dim3(gb), dim3(256), 0, h->stream, h->P, h->pos4, h->cf_w, h->g, h->part,
                                h->st, h->Q.lam_form, h->Q.cf_form);
             bytes = 25.0 * h->n;
+            break;
+        case MMX_K_FORCES: // the force evaluation as the minimizer launches it
+            enqueue_eval(h, PACK_PLAIN, FOLD_NONE);
+            bytes = (56.0 + 32.0 + 25.0 + 25.0) * h->n + 64.0 * h->n_loops;
             break;
         }
     }
