@@ -210,6 +210,35 @@ def test_half_shell_kernel_dense_cells_and_overlapping_beads():
     _check(ChromatinSystem(3000, gas, np.array([0, 3000]), labels[:3000], ff=ff), 0.6, "sparse gas", e_atol=0.1)
 
 
+def test_half_shell_window_passes_are_records_of_their_own():
+    """A run of i-clusters whose candidates exceed the LDS window (424 clusters) is emitted as one record of the item list per
+    window pass, slices of equal length (N3Item::w0; mmx_nonbonded_n3.hpp), instead of one work item whose passes a single
+    workgroup walks: more records, the same forces.  A collapsed globule (every run needs several passes) and the lattice start
+    (two passes), against the full-shell kernel and against the one-record-per-run layout (option n3_pass_records = 0)."""
+    from multimm_amd.system import ChromatinSystem, ForceFieldParams
+    rng = np.random.default_rng(12)
+    ff = ForceFieldParams(POL_USE_HARMONIC_BOND=False, POL_USE_HARMONIC_ANGLE=False, LE_USE_HARMONIC_BOND=False,
+                          COB_USE_COMPARTMENT_BLOCKS=True, NB_CUTOFF=0.6)
+    n = 8000
+    labels = rng.choice(np.array([-2, -1, 0, 1, 2], np.int8), n)
+    blob = ChromatinSystem(n, rng.normal(0.0, 0.4, (n, 3)), np.array([0, n]), labels, ff=ff)
+    for label, s in (("globule", blob), ("lattice", synthetic_system("gw_200k", n_beads=30000, **ALL_ON))):
+        with engine_for(s) as eng:
+            eng.set_option("nb_variant", 8192)
+            e0, F0 = eng.compute()
+            fmax = np.abs(F0).max()
+            eng.set_option("nb_variant", 4096)
+            out = {}
+            for rec in (0, 1):
+                eng.set_option("n3_pass_records", rec)
+                e, F = eng.compute()
+                out[rec] = (int(eng.get_option("n3_items")), e, F)
+                assert np.abs(F - F0).max() <= 2e-5 * fmax, (label, rec, np.abs(F - F0).max() / fmax)
+                assert np.all(np.abs(e - e0) <= 2e-6 * np.abs(e0).sum() + 1e-2), (label, rec, e, e0)
+            assert out[1][0] > out[0][0], (label, out[0][0], out[1][0])      # the passes became records
+            assert np.abs(out[1][2] - out[0][2]).max() <= 2e-5 * fmax
+
+
 def test_pair_kernel_choice_follows_size_and_cell_occupancy():
     """Default options (use_n3 in mmx_engine.hpp): systems below 100 000 beads always take the full-shell kernel, larger ones
     the half-shell kernel as long as the last poll saw >= 20 beads per grid cell.  Whatever is picked, a minimization ends
