@@ -216,7 +216,9 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
     const GridParams G = *grid;
     const N3ItemShape S = n3_item_shape(long_items);
     const int nrows = G.ny * G.nz, nx = G.nx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index in a scalar register: everything that depends on the row only -- N3Row -- then lives in SGPRs; this
+    //  function shares a kernel with the in-cell order, whose occupancy its registers set)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int row = bid * 4 + wave; row < nrows; row += nblk * 4) {
         N3Row R;
         R.cstart = cstart;
@@ -256,42 +258,37 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
                 }
             }
         };
-        // records of a lane's runs: one per window pass
-        auto records_of = [&](const N3Cell &C, int x) {
-            int cnt = 0;
-            for (int j = 0; j < C.runs; ++j) {
-                int a, n, xb, rlo[5], rn[5], grlo[9];
-                unsigned short grn[9];
-                run_of(C, x, j, a, n, xb);
-                const int T = R.T(a, x, xb, rlo, rn) + R.TG(x, xb, grlo, grn);
-                cnt += pass_records ? max(1, (T + slice_cap - 1) / slice_cap) : 1;
-            }
-            return cnt;
+        // run j of a cell as a record (slice not yet set); returns the length of its candidate index space
+        auto build = [&](const N3Cell &C, int x, int j, N3Item &it) {
+            int xb;
+            run_of(C, x, j, it.a, it.n, xb);
+            it.pad1[0] = it.pad1[1] = 0;
+            it.grn[9] = 0;
+            it.pad2[0] = it.pad2[1] = 0;
+            return R.T(it.a, x, xb, it.rlo, it.rn) + R.TG(x, xb, it.grlo, it.grn);
         };
-        // pass 1: records of the row
-        int total = 0, carry_p = 0;
+        // one record per window pass (option n3_pass_records = 0, for the A/B: one record per run, the workgroup that takes it
+        // walks the passes itself)
+        auto passes = [&](int T) { return pass_records ? max(1, (T + slice_cap - 1) / slice_cap) : 1; };
+        auto emit = [&](N3Item &it, int T, int np, int &at) {
+            for (int q = 0; q < np; ++q) { // slices of equal length (<= the window)
+                it.w0 = (int)(((long long)T * q) / np);
+                it.T = (int)(((long long)T * (q + 1)) / np);
+                items[at++] = it;
+            }
+        };
+        // One pass per 64-cell chunk of the row: the records a lane will write are counted first (the length of its first run's
+        // index space -- nearly always its only run -- is kept), the chunk's records are reserved with one atomic, then written.
+        int carry_p = 0;
         bool carry_dense = true; // the row start opens a segment
-        for (int xc = 0; xc < nx; xc += 64) {
-            const N3Cell C = n3_cell(S, cs, nx, xc + lane, lane, carry_p, carry_dense);
-            int r = records_of(C, xc + lane);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-            total += r;
-        }
-        int first = 0;
-        if (lane == 0) first = atomicAdd(&st->n3_items, total);
-        first = __builtin_amdgcn_readfirstlane(first);
-        if (first + total > max_items) { // cannot happen (the list has room for a run per cell plus one per 8 beads)
-            if (lane == 0) atomicOr(&st->kernel_error, (int)KERR_N3_ITEMS); // the controller voids the evaluation
-            continue;
-        }
-        // pass 2: emit
-        carry_p = 0;
-        carry_dense = true;
         for (int xc = 0; xc < nx; xc += 64) {
             const int x = xc + lane;
             const N3Cell C = n3_cell(S, cs, nx, x, lane, carry_p, carry_dense);
-            const int mine = records_of(C, x);
+            int mine = 0;
+            for (int j = 0; j < C.runs; ++j) {
+                N3Item t;
+                mine += passes(build(C, x, j, t));
+            }
             int inc = mine; // inclusive scan of the record counts: where my records go
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -299,26 +296,21 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
                 if (lane >= o) inc += u;
             }
             const int chunk_total = __shfl(inc, 63, 64);
+            if (chunk_total == 0) continue;
+            int first = 0;
+            if (lane == 0) first = atomicAdd(&st->n3_items, chunk_total);
+            first = __builtin_amdgcn_readfirstlane(first);
+            if (first + chunk_total > max_items) { // cannot happen (see the allocation: a run per cell plus one per 16 clusters,
+                                                   // and room for their window passes)
+                if (lane == 0) atomicOr(&st->kernel_error, (int)KERR_N3_ITEMS); // the controller voids the evaluation
+                break;
+            }
             int at = first + inc - mine;
             for (int j = 0; j < C.runs; ++j) {
-                int a, n, xb;
-                run_of(C, x, j, a, n, xb);
-                N3Item it;
-                it.a = a;
-                it.n = n;
-                const int T = R.T(a, x, xb, it.rlo, it.rn) + R.TG(x, xb, it.grlo, it.grn);
-                it.pad1[0] = it.pad1[1] = 0;
-                it.grn[9] = 0;
-                it.pad2[0] = it.pad2[1] = 0;
-                // (option n3_pass_records = 0, for the A/B: one record per run, the workgroup that takes it walks the passes itself)
-                const int np = pass_records ? max(1, (T + slice_cap - 1) / slice_cap) : 1;
-                for (int q = 0; q < np; ++q) { // slices of equal length (<= the window)
-                    it.w0 = (int)(((long long)T * q) / np);
-                    it.T = (int)(((long long)T * (q + 1)) / np);
-                    items[at++] = it;
-                }
+                N3Item t;
+                const int T = build(C, x, j, t);
+                emit(t, T, passes(T), at);
             }
-            first += chunk_total;
         }
     }
 }
@@ -446,7 +438,8 @@ __global__ __launch_bounds__(kN3Threads, 4) void k_nb_n3(const FFParams P, const
     // decomposed ranks: clusters from here on are ghosts' (the split cluster list of cell_scan_block): what lands on their
     // slots is nobody's business on this rank -- the flush and the large-sum bypass skip them, the unsort never reads them
     const int n_own_cl = DD ? st->n_clusters_own : 0x7fffffff;
-    const int n_items = st->n3_items;
+    // (an item list that overflowed -- the evaluation is void already -- is not walked: its count runs past the buffer)
+    const int n_items = (st->kernel_error & (int)KERR_N3_ITEMS) ? 0 : st->n3_items;
     if (threadIdx.x < 40) {
         const bool in5 = (threadIdx.x & 7) < 5;
         s_tab[threadIdx.x] = in5 ? P.table[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.f;
