@@ -274,7 +274,14 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     more -- ghost lists and the ghost positions last received stay, sums are not all-reduced -- so
  *                     that mmx_time_kernel can time ONE rank's kernels on exactly the beads it holds in the run   0
  * "n3_long_items"     work items of the half-shell pair kernel: -1 = by size (24 clusters from 150 000 local beads,
- *                     16 below), 0 / 1 = short / long forced (tests, A/B)                                        -1
+ *                     16 below), 0 / 1 = short / long forced (tests, A/B), 2 = 32 clusters (measurement)          -1
+ * "n3_pass_records"   1: a run of i-clusters whose candidates exceed the LDS window is emitted as one record of the item list
+ *                     per window pass (equal slices; any workgroup takes them); 0: one record per run, the workgroup that
+ *                     takes it walks the passes (A/B, tests)                                                      1
+ * "n3_slice_cap"      measurement: longest slice of such a record in clusters (0 = the LDS window, 424)            0
+ * "dd_split"          decomposed ranks on the half-shell kernel: 1 = the ghosts' clusters in a region of their own behind the
+ *                     owned ones, never i-clusters (owned clusters sweep the ghost clusters of their full 3 x 3 x 3
+ *                     neighbourhood); 0 = ghost clusters interleaved per cell and taking part as i-clusters (A/B)    1
  * "n_clusters", "n_cells", "n3_items"  (get only) 8-bead clusters, grid cells and half-shell work items of the last
  *                     cell build, as of the last poll
  * "inject_fault"      tests only: bit 0 makes every wait of the half-shell pair kernel's unit protocol time out at
