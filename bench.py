@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--separate-bonded", action="store_true",
                     help="run backbone / loops / confinement as three kernels (per-kernel timing) instead of the "
                          "fused default")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option set before the warm-up (A/B runs; repeatable), e.g. --option cell_slots=0")
     ap.add_argument("--nb-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the pair kernel from a separate rocprofv3 --pmc run "
                          "(profiles/): copied into roofline.traffic")
@@ -401,6 +403,9 @@ def main():
     else:
         eng = engine_for(system, device=local_rank)
     eng.set_option("profile", 0)
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        eng.set_option(k.strip(), float(v))
     eng.set_option("fused_bonded", 0 if args.separate_bonded else 1)
     if args.serial_bonded:
         eng.set_option("overlap_bonded", 0)

@@ -233,10 +233,11 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     iterations from the lattice are unaffected (no skin there).  0: a full build per evaluation      1
  * "cell_builds", "cell_reuses", "cell_stale_halts", "cell_reuse_K"   (get only) statistics of it
  * "cell_slots"        1: the trial moves of a single-domain minimization write their 64-bit sort keys straight into per-cell
- *                     slots (a table sized from the last poll's cell count and fullest cell), so the counting sort's fill
- *                     launch disappears; same keys, same clusters, bitwise the same minimization (+1 % iterations/s).  A
- *                     state that outgrows the table voids its evaluation, which is repeated with a larger one
- *                     ("cell_slot_halts"); 0: k_cell_fill after the scan                                          1
+ *                     rows of a slot table (ONE allocation of 256 B per bead, cut at every poll into rows of twice the
+ *                     fullest cell), so the counting sort's fill launch disappears; same keys, same clusters, bitwise the
+ *                     same minimization (+1-2 % iterations/s).  A cell that outgrows its row voids the evaluation, which
+ *                     is repeated with longer rows ("cell_slot_halts"; the repeat bins on another grid: from there on
+ *                     the run differs from the fill path by rounding); 0: k_cell_fill after the scan               1
  * "cell_edge_auto"    1: once a poll finds fewer than 32 beads per cutoff-sized grid cell (systems of >= 20 000 beads) the grid
  *                     switches to cells 1.12 x wider (same results: the box tests are exact; the in-cell ordering is a
  *                     latency chain per cell, fewer and fuller cells take 8-10 us off the cell build for +2 us of pair
@@ -288,7 +289,8 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     once, bit 1 shrinks its work-item list to one entry -- both must surface as MMX_ERR_STATE;
  *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a
  *                     ghost list exercises the halt-and-repeat protocol; bit 3 gives a kept cell structure ("cell_reuse")
- *                     a skin of nothing, so that every evaluation on one is voided and repeated after a full build    0
+ *                     a skin of nothing, so that every evaluation on one is voided and repeated after a full build; bit 4 cuts the
+ *                     slot table ("cell_slots") in rows of 64 slots at every poll: crowded cells overflow, halt, repeat    0
  */
 int mmx_set_option(mmx_handle h, const char *key, double value);
 int mmx_get_option(mmx_handle h, const char *key, double *value);

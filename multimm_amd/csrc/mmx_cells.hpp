@@ -700,13 +700,13 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
     for (int c = (bid - nB) * 4 + wave; bid >= nB && c < ncells; c += (nblk - nB) * 4) {
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt > 64) continue;
-        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
         const size_t kb = slot_cap ? (size_t)c * slot_cap : (size_t)s;
         const int no = count_own ? count_own[c] : cnt;
-        if (lane == 0) {
+        if (lane == 0) { // (also for a cell that is skipped below: the next build counts from zero)
             count[c] = 0;
             if (count_own) count_own[c] = 0;
         }
+        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
         if (cnt == 0) continue;
         if (lane == 0 && !split) items[istart[c]] = make_int2(c, 0);
         if (cnt > 1 || slot_cap) { // (slot table: perm has no fill behind it, a single bead is written here too)
@@ -735,14 +735,14 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
         const int c = biglist[bi];
         const int s = start[c], cnt = start[c + 1] - s;
         if (cnt <= 64) continue; // (cannot happen; block-uniform)
-        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
         const size_t kb = slot_cap ? (size_t)c * slot_cap : (size_t)s;
         const int no = count_own ? count_own[c] : cnt;
         __syncthreads(); // every thread has read count_own[c]
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0) { // (also for a cell that is skipped below: the next build counts from zero)
             count[c] = 0;
             if (count_own) count_own[c] = 0;
         }
+        if (slot_cap && (c >= slot_cells || cnt > slot_cap)) continue; // (a void evaluation: k_pack flagged it)
         const int nchunk = (cnt + CHUNK - 1) / CHUNK, ib = istart[c];
         for (int k = threadIdx.x; k < nchunk && !split; k += 256) items[ib + k] = make_int2(c, k);
         if (cnt <= 1024) { // keys in registers, <= 3 exchanges through LDS

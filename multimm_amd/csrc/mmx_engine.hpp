@@ -745,7 +745,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             //  is recorded on the way -- what the host sizes reuse_K by)
             const RefArgs R{h->cell_xref, tracked ? (h->struct_valid ? 2 : 3) : 0, 0.f};
             // sort keys straight into the slot table: no k_cell_fill below
-            h->slots_now = h->cell_slots && h->slotkeys && !h->capturing && !h->use_graph;
+            h->slots_now = h->cell_slots && h->slotkeys && h->slot_cap > 0 && !h->capturing && !h->use_graph;
             const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
@@ -1153,30 +1153,42 @@ int kernel_error_rc(mmx_handle_s *h) {
                                   " forces and energies of this call must not be used");
 }
 
-// Slot table of the trial moves: room for 1.5 x the cells and 1.6 x the fullest cell of the last poll (the grid follows the
-// bounding box from build to build).  Called with the stream idle.  grow: after an evaluation that did not fit.
+// Slot table of the trial moves: ONE allocation of kSlotsPerBead key slots per bead (256 B / bead), made when the first poll
+// knows a cell count, and never again -- hipFree / hipMalloc inside a call cost a twentieth of the driver's 20-iteration
+// window when the table followed the polls (measured: 3 058 against 3 228 iterations/s).  What follows the polls is how the
+// buffer is CUT: rows of 2 x the fullest cell (+ 32, rounded up to 64 slots), as many rows as fit; rows are only valid for the build
+// that wrote them, so a new cut needs no clearing.  A state the buffer cannot hold with 25 % of spare rows keeps the counting
+// sort's fill until a later poll.  Called with the stream idle.  grow: after an evaluation that did not fit its cut.
+constexpr int kSlotsPerBead = 32;
 int ensure_slots(mmx_handle_s *h, bool grow) {
     if (!h->cell_slots || h->world > 1 || h->n_own != h->n || h->last_ncells <= 0 || h->last_max_per_cell <= 0) return MMX_OK;
-    int cap = 64;
-    while (cap < (int)(1.6 * h->last_max_per_cell) + 16) cap <<= 1;
-    int cells = (int)(1.5 * h->last_ncells) + 1024;
-    if (grow) {
-        cap = std::max(cap, 2 * h->slot_cap);
-        cells = std::max(cells, h->slot_cells + h->slot_cells / 2);
+    if (!h->slotkeys) {
+        h->slot_total = (size_t)kSlotsPerBead * (size_t)std::max(h->n_all, 4096);
+        if (h->slot_total * 8 > ((size_t)1 << 33)) { // (16.7 M beads: 4.3 GB -- fine on this part; beyond: the fill stays)
+            h->cell_slots = 0;
+            return MMX_OK;
+        }
+        HIPCHK(h, dalloc(&h->slotkeys, h->slot_total));
     }
-    if (cap <= h->slot_cap && cells <= h->slot_cells) return MMX_OK;
-    cap = std::max(cap, h->slot_cap);
-    cells = std::max(cells, h->slot_cells);
-    if ((double)cap * (double)cells * 8.0 > 4e9) { // a pathological state (one huge cell): the counting sort's fill stays
-        h->cell_slots = 0;
+    // (the fullest cell of the last poll was counted on the grid of the last build; the grids of the builds to come may be wider
+    //  -- the poll that has just run switches the wide cells on and off: beads per cell follow the cube of the edge)
+    const float f_last = std::max(h->grid_factor[(h->build_idx + 1) & 1], 1.f);
+    const float f_next = std::max(std::max(h->grid_factor[h->build_idx & 1], edge_factor(h)), f_last);
+    const double widen = (double)(f_next / f_last) * (f_next / f_last) * (f_next / f_last);
+    int cap = (((int)(2.0 * widen * h->last_max_per_cell) + 32 + 63) / 64) * 64; // (whole 512-byte lines per row)
+    if ((h->inject_fault & 16) && !grow) cap = 64; // tests: rows that every crowded cell outgrows -- halt, larger rows, repeat
+    if (grow) cap = std::max(cap, 2 * std::max(h->slot_cap, 32)); // the fullest cell outgrew its row (or the grid its rows: below)
+    const size_t rows = h->slot_total / (size_t)cap;
+    // (... and narrower: cells then multiply by the cube of the ratio)
+    const float f_min = std::max(std::min(std::min(h->grid_factor[h->build_idx & 1], edge_factor(h)), f_last), 1.f);
+    const double narrow = (double)(f_last / f_min) * (f_last / f_min) * (f_last / f_min);
+    const size_t need = (size_t)(1.25 * narrow * h->last_ncells) + 512 + (grow ? (size_t)h->slot_cells / 2 : 0);
+    if (rows < need || rows > (size_t)0x7fffffff) { // does not fit: no slot table until a poll finds a state that does
+        h->slot_cap = h->slot_cells = 0;
         return MMX_OK;
     }
-    if (h->slotkeys) (void)hipFree(h->slotkeys);
-    h->slotkeys = nullptr;
-    h->slot_cap = h->slot_cells = 0;
-    HIPCHK(h, dalloc(&h->slotkeys, (size_t)cap * (size_t)cells));
     h->slot_cap = cap;
-    h->slot_cells = cells;
+    h->slot_cells = (int)rows;
     return MMX_OK;
 }
 

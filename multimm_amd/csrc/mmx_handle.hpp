@@ -287,6 +287,7 @@ struct mmx_handle_s {
                                   // (ghost clusters are never i-clusters: ScanArgs::split); 0 = interleaved per cell, for the A/B
     unsigned long long *slotkeys = nullptr;
     int slot_cap = 0, slot_cells = 0;
+    size_t slot_total = 0;        // key slots of the one allocation (ensure_slots cuts it into slot_cells rows of slot_cap)
     bool slots_now = false;       // the build being enqueued uses the table
     long long slot_halts = 0;
     int cell_reuse = 1;

@@ -41,3 +41,28 @@ def test_pair_kernel_failure_surfaces_from_every_entry_point(fault):
         assert np.abs(f1 - f0).max() <= 1e-5 * np.abs(f0).max()
         st = eng.minimize(tolerance=0.0, max_iters=5)
         assert st.iterations == 5 and st.status == 1
+
+
+@pytest.mark.parametrize("name, n", [("chr1_50k", 30000), ("gw_200k", 100000)])
+def test_slot_table_rows_that_overflow_void_the_evaluation_and_are_enlarged(name, n):
+    """Trial moves write their sort keys into per-cell rows of a slot table (option cell_slots) cut from the last poll's
+    fullest cell; a cell that outgrows its row voids the evaluation (PH_HALT, reason 8), the host cuts longer rows and repeats
+    it.  inject_fault bit 4 cuts rows of 64 slots at every poll, so the crowded cells of a collapse from the lattice overflow
+    again and again: the minimization must end where the counting sort's fill path ends, with the halts counted -- and without
+    the cell counters of the skipped cells leaking into the repeat (they once did: counts doubled, offsets ran past the
+    arrays).  Without overflows the slot path is bitwise the fill path (`deterministic`); a repeated evaluation bins on the
+    grid its void twin laid out, not on its predecessor's, so clusters -- and roundings -- differ from there on: 1e-6."""
+    s = synthetic_system(name, n_beads=n)
+    ends = {}
+    for label, slots, fault in (("fill", 0, 0), ("slots", 1, 0), ("rows of 64", 1, 16)):
+        with engine_for(s) as eng:
+            eng.set_option("deterministic", 1)
+            eng.set_option("cell_slots", slots)
+            eng.set_option("inject_fault", fault)
+            st = eng.minimize(tolerance=0.0, max_iters=150)
+            ends[label] = (st.e_final, eng.get_positions(), eng.get_option("cell_slot_halts"), st.iterations)
+    assert ends["rows of 64"][2] > 0 and ends["fill"][2] == 0
+    assert ends["slots"][3] == ends["rows of 64"][3] == ends["fill"][3] == 150
+    assert ends["slots"][0] == ends["fill"][0] and np.array_equal(ends["slots"][1], ends["fill"][1])
+    assert abs(ends["rows of 64"][0] - ends["fill"][0]) <= 1e-6 * abs(ends["fill"][0])
+    assert np.abs(ends["rows of 64"][1] - ends["fill"][1]).max() < 0.05   # nm, after 150 iterations
