@@ -1,5 +1,9 @@
 #!/bin/bash
-# usage: ab_r3.sh "<bench flags>"  -- round-3 tree against the current tree, interleaved, same box
+# Same-box comparison of a WHOLE earlier tree (library + bench.py + Python side) with the working tree, interleaved, three rounds.
+# The earlier tree is an export of its commit beside the working tree, built here, so that it travels to the GPU box:
+#   mkdir -p scripts/ubench/bin/r3tree && git archive <commit> | tar -x -C scripts/ubench/bin/r3tree
+#   (cd scripts/ubench/bin/r3tree && rm -rf profiles tests/golden && python -m multimm_amd.build)
+# usage (on the GPU box): ab_r3.sh "<bench flags>"
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 F=$1
 for i in 1 2 3; do for v in r3 now; do
