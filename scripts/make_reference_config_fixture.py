@@ -1,0 +1,31 @@
+"""Defaults table of the reference's ini schema as DATA: the fields of `SimulationConfig` (`/root/reference/src/multimm/config.py:94-312`)
+read from the source TEXT with `ast` -- nothing of the reference is imported or executed (its module needs OpenMM at import) --
+name, annotation and the literal `default=` of every `Field(...)`.  Build container only; the output,
+tests/golden/ref_config_defaults.json, is what tests/test_reference_fixtures.py compares `multimm_amd.config` with.
+usage: python scripts/make_reference_config_fixture.py [/root/reference]"""
+import ast, json, os, sys
+root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+src_path = os.path.join(root, "src", "multimm", "config.py")
+tree = ast.parse(open(src_path).read())
+fields = []
+for node in tree.body:
+    if isinstance(node, ast.ClassDef) and node.name == "SimulationConfig":
+        for st in node.body:
+            if not (isinstance(st, ast.AnnAssign) and isinstance(st.target, ast.Name) and isinstance(st.value, ast.Call)):
+                continue
+            if getattr(st.value.func, "id", None) != "Field":
+                continue
+            entry = {"name": st.target.id, "annotation": ast.unparse(st.annotation), "line": st.lineno}
+            for kw in st.value.keywords:
+                if kw.arg == "default":
+                    try:
+                        entry["default"] = ast.literal_eval(kw.value)
+                        entry["literal"] = True
+                    except ValueError:
+                        entry["default"] = ast.unparse(kw.value)      # a name or an enum member: kept as source text
+                        entry["literal"] = False
+            fields.append(entry)
+out = {"source": "src/multimm/config.py (SimulationConfig), read as text with ast; line = line of the field", "fields": fields}
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_config_defaults.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(len(fields), "fields ->", dst)

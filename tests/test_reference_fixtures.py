@@ -94,3 +94,47 @@ def test_multimm_writes_the_init_structure_in_the_files_unit(tmp_path):
     ref = open(os.path.join(GOLD, "ref_cif", "init_helix_257.cif"), "rb").read()
     assert got == ref
     assert b" 465.812\n" in got
+
+
+def test_config_defaults_equal_the_reference_schema():
+    """Every ini key this engine reads has the reference's default (`config.py:94-312`, read as text by
+    scripts/make_reference_config_fixture.py: name, annotation, literal default of every `Field`): quantities such as
+    '300000.0 kilojoules_per_mole/nanometer**2' or '1 femtosecond' reduce to the engine's nm / kJ/mol / rad / ps floats through
+    the same `parse_quantity` the ini reader uses.  Keys that differ on purpose are listed with the reason; keys of the
+    reference that this path does not read (plots, nucleosomes, ATAC, force-field xml ...) are listed too, so that a new key in
+    either table fails the test until someone decides where it belongs."""
+    import dataclasses
+    from multimm_amd.config import SimulationConfig, parse_quantity
+    from multimm_amd.system import ForceFieldParams
+    ref = {f["name"]: f for f in json.load(open(os.path.join(GOLD, "ref_config_defaults.json")))["fields"]}
+    ours = {f.name: f.default for f in dataclasses.fields(SimulationConfig) if f.name != "ff"}
+    ours.update({f.name: f.default for f in dataclasses.fields(ForceFieldParams)})
+    on_purpose = {
+        "PLATFORM": "the new value this engine adds (reference: CPU)",
+        "DEVICE": "an int device index here, OpenMM's DeviceIndex string there",
+        "INITIAL_STRUCTURE_TYPE": "an enum member there (InitialStructureType.HILBERT), its value 'hilbert' here",
+        "INITIAL_STRUCTURE_PATH": "'' there, None here: both mean 'not given'",
+        "GENE_TSV": "the reference ships a default table (a path inside its package); none travels here",
+        "GENE_NAME": "'' there, None here", "GENE_ID": "'' there, None here",
+    }
+    engine_only = {"DETERMINISTIC_FORCES", "NB_CUTOFF_AUTO", "NB_CUTOFF", "MIN_TOLERANCE", "MIN_MAX_ITERATIONS"}
+    not_read = {"CPU_THREADS", "FORCEFIELD_PATH", "ATACSEQ_PATH", "SAVE_PLOTS", "SC_RADIUS1", "SC_RADIUS2", "COB_DISTANCE",
+                "SCB_DISTANCE", "NUC_DO_INTERPOLATION", "MAX_NUCS_PER_BEAD", "NUC_RADIUS", "POINTS_PER_NUC", "PHI_NORM",
+                "SIM_ERROR_TOLERANCE", "SIM_SET_INITIAL_VELOCITIES"}
+    assert set(ours) - set(ref) == engine_only
+    assert set(ref) - set(ours) == not_read
+    checked = 0
+    for name, f in ref.items():
+        if name in not_read or name in on_purpose:
+            continue
+        want = f["default"]
+        if "OpenMMQuantity" in f["annotation"] and want is not None:
+            want = parse_quantity(want)
+        got = ours[name]
+        if isinstance(want, float) or isinstance(got, float):
+            assert float(got) == float(want), (name, got, want)
+        else:
+            assert got == want, (name, got, want)
+        checked += 1
+    assert checked >= 60
+    assert ours["INITIAL_STRUCTURE_TYPE"] == "hilbert" and ref["INITIAL_STRUCTURE_TYPE"]["default"].endswith(".HILBERT")
