@@ -18,6 +18,7 @@ of whose bodies reaches a placeholder:
         (-> compute_init_struct :256-289 -> polymer_circle / helix_structure / spiral_structure / trefoil_knot_structure)
     initial_structure_tools.write_mmcif_chrom (:417-458)
     initial_structure_tools.compute_init_struct for those four curves (the raw float64 arrays)
+    utils.get_coordinates_cif on the init files its own writer produced (the reader of model.py:1001,1083)
 
 NOT pinned here (needs the absent packages): the Hilbert start (hilbertcurve 2.0.5) and every energy / force / minimizer
 number (OpenMM 8.5.1).  Those rows stay "parity unpinned" ("Oracle").
@@ -183,6 +184,8 @@ def main():
         seg = pts[ends[0]:ends[1]]
         dstc = os.path.join(cif_dir, f"chrom_{tag}.cif")
         ist.write_mmcif_chrom(coords=seg, path=dstc)
+        # the reference's reader (utils.py:168-205, what model.py:1001,1083 load structures with) on its own writer's file
+        curves["read_" + tag] = np.asarray(utils.get_coordinates_cif(dst), dtype=np.float64)
         manifest["cif"].append({"curve": curve, "n": n, "chrom_ends": ends, "init": os.path.basename(dst),
                                 "chrom": os.path.basename(dstc), "chrom_slice": [ends[0], ends[1]]})
         print(f"cif {tag}: {os.path.getsize(dst)} + {os.path.getsize(dstc)} bytes")

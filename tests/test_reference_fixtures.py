@@ -77,6 +77,12 @@ def test_start_curves_and_mmcif_writers_equal_the_reference(entry, tmp_path):
     cif.write_chromosome_angstrom(str(outc), pts[lo:hi])
     refc = open(os.path.join(GOLD, "ref_cif", entry["chrom"]), "rb").read()
     assert outc.read_bytes() == refc                                                       # write_mmcif_chrom
+    # the reader: the reference's get_coordinates_cif (utils.py:168-205; Angstrom, ATOM rows only) on its own writer's file
+    # against cif.read_positions (nm; every ATOM / HETATM row: SURVEY.md appendix A.12) on the rows both keep
+    path = os.path.join(GOLD, "ref_cif", entry["init"])
+    is_atom = np.array([ln.startswith("ATOM") for ln in open(path) if ln.startswith(("ATOM", "HETATM"))])
+    ours = cif.read_positions(path)
+    assert len(ours) == n and np.array_equal(ours[is_atom], CURVES[f"read_{curve}_{n}"] * 0.1)
 
 
 def test_multimm_writes_the_init_structure_in_the_files_unit(tmp_path):
