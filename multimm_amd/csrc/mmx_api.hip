@@ -698,6 +698,7 @@ int mmx_compute(mmx_handle h, float *forces_out, double *energy_terms_out) try {
 int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *out) try {
     if (!h || max_iters < 0 || !(tolerance >= 0.0)) return fail(h, MMX_ERR_BAD_ARG, "bad minimize arguments");
     h->md_forces_valid = false;
+    h->md_active = false;
     // A minimization from the lattice adds 10-25 % of ghosts within its first ten iterations: decomposed runs start
     // with roomier messages (1/4) and short intervals between the polls that resize them (4, 8, 16, ... evaluations)
     h->dd_slack_div = 4;
@@ -976,6 +977,7 @@ int mmx_get_velocities(mmx_handle h, float *vel) try {
 int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     if (!h || n_steps < 0) return fail(h, MMX_ERR_BAD_ARG, "bad step count");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
+    h->md_active = true;
     int rc = prepare(h);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();

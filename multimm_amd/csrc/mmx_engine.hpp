@@ -1106,6 +1106,12 @@ int pull_state(mmx_handle_s *h) {
         const float rf = h->reuse_factor > 0.f ? h->reuse_factor : use_n3(h) ? 1.3f : 1.45f;
         const float wide = (h->cell_reuse && h->cell_xref) ? std::max(rf, kWideCellFactor) : kWideCellFactor;
         h->edge_auto = (per_cell < kWideCellsBelow && local_beads(h) >= kWideCellsFromBeads) ? wide : 1.f;
+        // MD keeps no cell structure (every step is a full build): there the wider edge only pays through beads per cell, and the
+        // fixed factors above overshoot on a structure that is still dense (chr1_50k after 200 iterations, 26 beads per
+        // cutoff-sized cell: 64.7 us per step at the cutoff, 65.8 at 1.12 x, 70.2 at 1.45 x; after 1 500 iterations, 7 per cell:
+        // 65.5 against 52.6 at 1.45 x -- scripts/md_options_ab.py).  Under MD the edge aims at ~30 beads per cell.
+        if (h->md_active && h->edge_auto > 1.f)
+            h->edge_auto = std::min(std::max((float)std::cbrt(30.0 / std::max(per_cell, 1.0)), 1.f), 1.45f);
     }
     {
         const int rc_slots = ensure_slots(h, false);
