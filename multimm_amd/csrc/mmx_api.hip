@@ -595,6 +595,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "n3_slice_cap") h->n3_slice_cap = std::max(0, std::min((int)value, (int)kN3MaxCap));
     else if (k == "cell_reuse") { h->cell_reuse = value != 0.0; h->reuse_K = 1; h->struct_valid = false; }
     else if (k == "cell_reuse_factor") h->reuse_factor = value > 0.0 ? (float)std::max(1.0, value) : 0.f;
+    else if (k == "cell_wide_below") h->wide_below = std::max(0.0, value);
     else if (k == "cell_edge_auto") { h->cell_edge_auto = value != 0.0; h->edge_auto = 1.f; }
     else if (k == "cell_edge_scale") { h->cell_edge_scale = (float)std::max(1.0, value); h->grid_ready = false; }
     else if (k == "dd_spatial") h->dd_spatial = value != 0.0;

@@ -1105,7 +1105,7 @@ int pull_state(mmx_handle_s *h) {
         // 1.45; chr1_50k (full-shell kernel, indifferent to the cell size) +15 % at 1.3, +15.6 % at 1.45
         const float rf = h->reuse_factor > 0.f ? h->reuse_factor : use_n3(h) ? 1.3f : 1.45f;
         const float wide = (h->cell_reuse && h->cell_xref) ? std::max(rf, kWideCellFactor) : kWideCellFactor;
-        h->edge_auto = (per_cell < kWideCellsBelow && local_beads(h) >= kWideCellsFromBeads) ? wide : 1.f;
+        h->edge_auto = (per_cell < (h->wide_below > 0.0 ? h->wide_below : kWideCellsBelow) && local_beads(h) >= kWideCellsFromBeads) ? wide : 1.f;
         // MD keeps no cell structure (every step is a full build): there the wider edge only pays through beads per cell, and the
         // fixed factors above overshoot on a structure that is still dense (chr1_50k after 200 iterations, 26 beads per
         // cutoff-sized cell: 64.7 us per step at the cutoff, 65.8 at 1.12 x, 70.2 at 1.45 x; after 1 500 iterations, 7 per cell:

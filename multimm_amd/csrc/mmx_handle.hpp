@@ -286,6 +286,7 @@ struct mmx_handle_s {
     int dd_split = 1;             // option: decomposed ranks on the half-shell kernel keep the ghosts' clusters in a region of their own
                                   // (ghost clusters are never i-clusters: ScanArgs::split); 0 = interleaved per cell, for the A/B
     unsigned long long *slotkeys = nullptr;
+    double wide_below = 0.0;      // option cell_wide_below (measurement): beads per cutoff-sized cell under which the wide grid is used (0: 32)
     bool md_active = false;       // the call in progress is mmx_md_step (the polls' cell-edge policy differs: pull_state)
     int slot_cap = 0, slot_cells = 0;
     size_t slot_total = 0;        // key slots of the one allocation (ensure_slots cuts it into slot_cells rows of slot_cap)
