@@ -58,6 +58,9 @@ enum {
     MMX_K_LBFGS = 5,      /* K6: history pass of an evaluation ((s,y) candidate, Gram rows, g.d, x.x) */
     MMX_K_REDUCE = 6,     /* fold of the partials + line-search controller (+ direction coefficients) */
     MMX_K_CHB = 7,        /* chromosomal blocks: all pairs inside each chromosome */
+    MMX_K_DD_LISTS = 101, /* mmx_time_kernel only, decomposed handles: what a rank computes per evaluation for its halo besides the force
+                             kernels -- occupancy map, dilation, send lists, message pack and unpack -- on the maps and messages
+                             last received, no collective */
     MMX_K_FORCES = 100,   /* mmx_time_kernel only: every launch of ONE force evaluation as the minimizer enqueues them (pack,
                              cell build with the bonded pass riding in the scan launch, pair kernel, unsort), no fold */
     MMX_N_KERNELS = 8

@@ -1112,7 +1112,7 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
 int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us, double *algorithmic_bytes) try {
     if (!h || reps < 1 || !mean_us) return fail(h, MMX_ERR_BAD_ARG, "bad arguments");
     h->md_forces_valid = false;
-    if ((kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE) && kernel != MMX_K_FORCES)
+    if ((kernel < MMX_K_CELL_BUILD || kernel > MMX_K_CONFINE) && kernel != MMX_K_FORCES && kernel != MMX_K_DD_LISTS)
         return fail(h, MMX_ERR_BAD_ARG, "mmx_time_kernel covers slots 0..4 and MMX_K_FORCES; L-BFGS slots are timed live (option profile)");
     int rc = prepare(h);
     if (rc) return rc;
@@ -1177,6 +1177,27 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
                                h->st, h->Q.lam_form, h->Q.cf_form);
             bytes = 25.0 * h->n;
             break;
+        case MMX_K_DD_LISTS: { // the halo's own kernels of one evaluation (dd_rebuild on the stream + message pack / unpack)
+            if (!use_halo(h) || !h->dd_lists_valid) break;
+            const int gbl = std::max((h->n_own + 255) / 256, 1);
+            HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
+            hipLaunchKernelGGL(k_dd_occupancy, dim3(gbl), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
+            hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
+                               h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
+            HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * (size_t)h->world, h->stream));
+            hipLaunchKernelGGL(k_dd_build_lists, dim3(gbl), dim3(256), 0, h->stream, h->n_own, own_of(h), h->rank, h->world, h->x,
+                               h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, h->dd_scap, h->st,
+                               h->dd_cntmat);
+            int mx = 1;
+            for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scap.cap[q], h->dd_rcap.cap[q]));
+            const dim3 gq(std::min((mx + 255) / 256, 256), h->world);
+            hipLaunchKernelGGL(k_dd_pack, gq, dim3(256), 0, h->stream, h->dd_send_ids, h->dd_send_cnt, h->slice, h->pos4,
+                               h->dd_sendbuf, h->dd_scap, h->st);
+            hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
+                               h->dd_ghost_ids, h->n_all, h->st);
+            bytes = 16.0 * (double)h->dd_nghost;
+            break;
+        }
         case MMX_K_FORCES: // the force evaluation as the minimizer launches it
             enqueue_eval(h, PACK_PLAIN, FOLD_NONE);
             bytes = (56.0 + 32.0 + 25.0 + 25.0) * h->n + 64.0 * h->n_loops;

@@ -21,6 +21,7 @@ TERM_NAMES = ("ev", "gauss", "bond", "angle", "loop", "container", "lamina", "ce
 KERNEL_NAMES = ("cell_build", "nonbonded", "backbone", "loops", "confine", "lbfgs", "reduce", "chb")
 K_CELL_BUILD, K_NONBONDED, K_BACKBONE, K_LOOPS, K_CONFINE, K_LBFGS, K_REDUCE = range(7)
 K_FORCES = 100   # time_kernel only: one whole force evaluation as the minimizer launches it
+K_DD_LISTS = 101  # time_kernel only, decomposed handles: the halo's own kernels of one evaluation (no collective)
 COMP_COB, COMP_SCB = 0, 1
 
 # MMX_LIB: A/B timing of two builds of the library on the same box (scripts/); not a fallback mechanism

@@ -9,7 +9,7 @@ import sys, threading
 sys.path.insert(0, '.')
 import numpy as np
 from multimm_amd import synthetic_system
-from multimm_amd.engine import Engine, engine_for, K_NONBONDED, K_CELL_BUILD, K_BACKBONE, K_LOOPS, K_CONFINE, K_FORCES
+from multimm_amd.engine import Engine, engine_for, K_NONBONDED, K_CELL_BUILD, K_BACKBONE, K_LOOPS, K_CONFINE, K_FORCES, K_DD_LISTS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "gw_1m"
 relax = int(sys.argv[2]) if len(sys.argv) > 2 else 150
@@ -38,7 +38,8 @@ for world in (1, 2, 4, 8):
         for r, e in enumerate(engines):     # one rank at a time, alone on the GPU
             e.set_option("dd_freeze", 1)
             t = {k: e.time_kernel(kk, 10)[0] for k, kk in SLOTS}
-            rows.append((r, e.n_own, e.get_option("dd_ghosts"), t, e.get_option("n3_launches") > 0, e.time_kernel(K_FORCES, 10)[0]))
+            rows.append((r, e.n_own, e.get_option("dd_ghosts"), t, e.get_option("n3_launches") > 0,
+                         e.time_kernel(K_FORCES, 10)[0] + e.time_kernel(K_DD_LISTS, 10)[0]))
         for e in engines:
             e.close()
     worst = worst_w = 0.0
