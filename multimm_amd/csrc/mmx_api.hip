@@ -1180,8 +1180,8 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
         case MMX_K_DD_LISTS: { // the halo's own kernels of one evaluation (dd_rebuild on the stream + message pack / unpack)
             if (!use_halo(h) || !h->dd_lists_valid) break;
             const int gbl = std::max((h->n_own + 255) / 256, 1);
+            // (the occupancy map itself is marked by the evaluation's k_pack: enqueue_build, occ_in_pack)
             HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
-            hipLaunchKernelGGL(k_dd_occupancy, dim3(gbl), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
             hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
                                h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
             HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * (size_t)h->world, h->stream));

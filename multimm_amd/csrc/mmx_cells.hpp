@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
                                               int *__restrict__ cell_of = nullptr, int *__restrict__ rank = nullptr,
                                               int *__restrict__ count = nullptr, const DirArgs D = DirArgs{},
                                               const RefArgs R = RefArgs{nullptr, 0, 0.f}, MinState *__restrict__ stw = nullptr,
-                                              const SlotArgs T = SlotArgs{nullptr, 0, 0}) {
+                                              const SlotArgs T = SlotArgs{nullptr, 0, 0},
+                                              const DDGrid *__restrict__ ddgrid = nullptr,
+                                              unsigned long long *__restrict__ ddocc = nullptr) {
     if (st->phase >= PH_DONE) return;
     __shared__ float s_bb[6][4];
     __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
                 atomicOr(&stw->cell_stale, 2); // the table is too small for this state: the evaluation is void (k_decide halts)
         }
     }
+    // decomposed ranks, list rebuild on the stream: the occupancy of the need-map from the positions just formed (k_dd_occupancy's job)
+    if (ddocc) dd_mark(*ddgrid, ddocc, act, px, py, pz);
     // Block bounding box -> bbox_part[k][block] (k = minx,miny,minz,maxx,maxy,maxz); no atomics.
     const float big = 3.0e38f;
     const float fin = (act && fabsf(px) < big && fabsf(py) < big && fabsf(pz) < big) ? 1.f : 0.f;

@@ -266,6 +266,40 @@ __device__ __forceinline__ GridParams grid_from_box(float lox, float loy, float 
     return G;
 }
 
+// ---- coarse grid of a decomposed run's need-maps (mmx_dd.hpp; here because k_pack marks the occupancy on the way) ----
+constexpr int kDDGridN = 64; // coarse cells per axis (x = the bit of a 64-bit word)
+// Coarse grid of the need-maps (device; written by k_dd_grid at a synchronous rebuild, read by the rebuilds on the stream)
+struct DDGrid {
+    float ox, oy, oz, inv_edge, edge;
+    int radius; // cells a map is grown by: ceil(reach / edge)
+};
+
+// coarse cell of a position: word index (z, y) and x bit; indices wrap, so any finite position has a cell
+__device__ __forceinline__ void dd_cell(const DDGrid &G, float px, float py, float pz, int &word, int &bit) {
+    const int cx = (int)floorf((px - G.ox) * G.inv_edge) & (kDDGridN - 1);
+    const int cy = (int)floorf((py - G.oy) * G.inv_edge) & (kDDGridN - 1);
+    const int cz = (int)floorf((pz - G.oz) * G.inv_edge) & (kDDGridN - 1);
+    word = cz * kDDGridN + cy;
+    bit = cx;
+}
+
+// occ |= the coarse cell of this lane's position.  Whole waves call; consecutive beads mostly share a cell: lanes of a wave with
+// the same cell issue one atomic.
+__device__ __forceinline__ void dd_mark(const DDGrid &G, unsigned long long *__restrict__ occ, bool act, float px, float py, float pz) {
+    int word = 0, bit = 0;
+    if (act) dd_cell(G, px, py, pz, word, bit);
+    const int key = word * kDDGridN + bit;
+    unsigned long long pending = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(act && key == k0);
+        if (lane == leader) atomicOr(&occ[word], 1ull << bit);
+        pending &= ~same;
+    }
+}
+
 __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) {
     int c = (int)floorf((p - o) * inv_h);
     return min(max(c, 0), n - 1);

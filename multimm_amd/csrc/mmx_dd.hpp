@@ -37,7 +37,6 @@
 namespace mmx {
 
 constexpr int kDDMaxWorld = 64;                          // static partner masks are one bit per rank
-constexpr int kDDGridN = 64;                             // coarse cells per axis (x = the bit of a 64-bit word)
 constexpr int kDDWords = kDDGridN * kDDGridN;            // words of a need-map: [z][y]
 constexpr int kDDPayload = kDDWords + kDDMaxWorld / 2;   // ... + the rank's send-list lengths (kDDMaxWorld ints)
 
@@ -47,12 +46,6 @@ struct DDOffsets {
 struct DDCaps {
     int cap[kDDMaxWorld]; // entries per message (to / from rank q)
 };
-// Coarse grid of the need-maps (device; written by k_dd_grid at a synchronous rebuild, read by the rebuilds on the stream)
-struct DDGrid {
-    float ox, oy, oz, inv_edge, edge;
-    int radius; // cells a map is grown by: ceil(reach / edge)
-};
-
 // owned bounding box of this rank from k_pack's per-block boxes -> out6 = {lo x y z, hi x y z}; one block
 __global__ __launch_bounds__(256) void k_dd_bbox(const float *__restrict__ bbox_part, int nblk, float *__restrict__ out6) {
     __shared__ float s_red[6][4];
@@ -113,35 +106,15 @@ __global__ void k_dd_grid(const float *__restrict__ boxes, int world, float reac
     *out = G;
 }
 
-// coarse cell of a position: word index (z, y) and x bit; indices wrap, so any finite position has a cell
-__device__ __forceinline__ void dd_cell(const DDGrid &G, float px, float py, float pz, int &word, int &bit) {
-    const int cx = (int)floorf((px - G.ox) * G.inv_edge) & (kDDGridN - 1);
-    const int cy = (int)floorf((py - G.oy) * G.inv_edge) & (kDDGridN - 1);
-    const int cz = (int)floorf((pz - G.oz) * G.inv_edge) & (kDDGridN - 1);
-    word = cz * kDDGridN + cy;
-    bit = cx;
-}
-
-// occ |= the coarse cells of the owned beads.  Consecutive beads mostly share a cell: lanes of a wave with the same cell
-// issue one atomic.
+// occ |= the coarse cells of the owned beads (dd_mark, mmx_common.hpp).  The rebuilds on the stream do this inside k_pack, which
+// has the new positions in registers; this kernel serves the synchronous rebuild and MD.
 __global__ __launch_bounds__(256) void k_dd_occupancy(int n_own, const float *__restrict__ x, const DDGrid *__restrict__ grid,
                                                       unsigned long long *__restrict__ occ, const MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) return;
     const DDGrid G = *grid;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < n_own;
-    int word = 0, bit = 0;
-    if (act) dd_cell(G, x[3 * i], x[3 * i + 1], x[3 * i + 2], word, bit);
-    const int key = word * kDDGridN + bit;
-    unsigned long long pending = __ballot(act);
-    const int lane = threadIdx.x & 63;
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int k0 = __shfl(key, leader, 64);
-        const unsigned long long same = __ballot(act && key == k0);
-        if (lane == leader) atomicOr(&occ[word], 1ull << bit);
-        pending &= ~same;
-    }
+    dd_mark(G, occ, act, act ? x[3 * i] : 0.f, act ? x[3 * i + 1] : 0.f, act ? x[3 * i + 2] : 0.f);
 }
 
 // need = occ grown by `radius` cells in every direction (indices wrap) -> this rank's part of the payload; the last

@@ -629,7 +629,7 @@ bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
 // `sync` (start of every API call, repeat of a halted evaluation): before that the coarse grid is laid over the
 // all-gathered owned boxes, the lists are unbounded, and afterwards the matrix of list lengths is all-gathered and read
 // by the host: fresh capacities.
-int dd_rebuild(mmx_handle_s *h, bool sync) {
+int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done: the pack has marked the occupancy already
     const int gb = std::max((h->n_own + 255) / 256, 1);
     const size_t W = (size_t)h->world;
     const float reach = hmin_of(h) / (1.001f * edge_factor(h)) + (h->dd_every > 1 ? h->dd_skin_cur : 0.f);
@@ -639,8 +639,10 @@ int dd_rebuild(mmx_handle_s *h, bool sync) {
         coll_allgather_small(h, h->dd_boxes, 6 * sizeof(float), [](mmx_handle_s *o) { return (void *)o->dd_boxes; });
         hipLaunchKernelGGL(k_dd_grid, dim3(1), dim3(64), 0, h->stream, h->dd_boxes, h->world, reach, h->dd_grid);
     }
-    HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
-    hipLaunchKernelGGL(k_dd_occupancy, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
+    if (!occ_done) {
+        HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
+        hipLaunchKernelGGL(k_dd_occupancy, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
+    }
     hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
                        h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
     {
@@ -696,6 +698,13 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     const int ga = (h->n_all + 255) / 256;  // blocks over every bead of pos4
     const bool dd = h->world > 1 || h->n_own != h->n;
     const bool fuse_count = !dd && !init && has_nb(h) && !all_pairs(h);
+    // decomposed ranks, ghost lists rebuilt on the stream (redecomp 2): the occupancy of the need-map is marked by the pack, which
+    // has the new positions in registers (one launch and one pass over x less per evaluation)
+    const bool occ_in_pack = dd && redecomp == 2 && use_halo(h) && !h->dd_frozen && h->dd_occ && h->dd_grid &&
+                             (mode == PACK_MOVE || mode == PACK_PLAIN);
+    if (occ_in_pack) (void)hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream);
+    const DDGrid *const ddg = occ_in_pack ? h->dd_grid : nullptr;
+    unsigned long long *const ddo = occ_in_pack ? h->dd_occ : nullptr;
     // kept cell structure (see mmx_handle_s::cell_reuse): trial moves of a single-domain minimization only
     // (and only on grids wider than the cutoff: without a skin there is nothing to keep, and the reference costs 24 B / bead)
     const bool tracked = fuse_count && mode == PACK_MOVE && h->cell_reuse && !h->capturing && !h->use_graph && h->cell_xref &&
@@ -763,14 +772,17 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     } else if (mode == PACK_MOVE)
         hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
-                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h));
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h), RefArgs{nullptr, 0, 0.f},
+                           (MinState *)nullptr, SlotArgs{nullptr, 0, 0}, ddg, ddo);
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp, h->d,
-                           h->labels, h->pos4, h->bbox_part, h->st);
+                           h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr, (int *)nullptr,
+                           (int *)nullptr, (int *)nullptr, DirArgs{}, RefArgs{nullptr, 0, 0.f}, (MinState *)nullptr,
+                           SlotArgs{nullptr, 0, 0}, ddg, ddo);
     // dd_frozen (measurement: scripts/dd_projection.py): no collective is issued -- the ghost lists and the ghost positions
     // last received stay, so one rank's kernels can be timed alone on exactly the beads it holds in a real run
     if (redecomp && use_halo(h) && !h->dd_frozen) { // fresh ghost lists from the positions the pack has just written
-        const int rc = dd_rebuild(h, redecomp == 1);
+        const int rc = dd_rebuild(h, redecomp == 1, occ_in_pack);
         if (rc != MMX_OK && h->dd_rc == MMX_OK) h->dd_rc = rc;
     }
     const bool halo = use_halo(h) && h->dd_lists_valid;
