@@ -25,7 +25,12 @@ for node in tree.body:
                         entry["default"] = ast.unparse(kw.value)      # a name or an enum member: kept as source text
                         entry["literal"] = False
             fields.append(entry)
-out = {"source": "src/multimm/config.py (SimulationConfig), read as text with ast; line = line of the field", "fields": fields}
+# the values INITIAL_STRUCTURE_TYPE may take: members of enums.py:InitialStructureType, read the same way
+enum_tree = ast.parse(open(os.path.join(root, "src", "multimm", "enums.py")).read())
+kinds = [ast.literal_eval(st.value) for node in enum_tree.body if isinstance(node, ast.ClassDef) and node.name == "InitialStructureType"
+         for st in node.body if isinstance(st, ast.Assign)]
+out = {"source": "src/multimm/config.py (SimulationConfig), read as text with ast; line = line of the field", "fields": fields,
+       "initial_structure_types": kinds}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_config_defaults.json")
 json.dump(out, open(dst, "w"), indent=1)
 print(len(fields), "fields ->", dst)

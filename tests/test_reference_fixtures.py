@@ -144,3 +144,16 @@ def test_config_defaults_equal_the_reference_schema():
         checked += 1
     assert checked >= 60
     assert ours["INITIAL_STRUCTURE_TYPE"] == "hilbert" and ref["INITIAL_STRUCTURE_TYPE"]["default"].endswith(".HILBERT")
+
+
+def test_initial_structure_types_are_the_reference_enum():
+    """INITIAL_STRUCTURE_TYPE takes exactly the values of the reference's `enums.py:InitialStructureType` (read as text): each
+    builds a structure, anything else raises with the same list of choices (initial_structure_tools.py:256-289)."""
+    kinds = json.load(open(os.path.join(GOLD, "ref_config_defaults.json")))["initial_structure_types"]
+    assert len(kinds) == 9 and "hilbert" in kinds
+    for k in kinds:
+        pts = compute_init_struct(64, k)
+        assert pts.shape == (64, 3) and np.isfinite(pts).all(), k
+    with pytest.raises(ValueError) as exc:
+        compute_init_struct(64, "lattice")
+    assert all(k in str(exc.value) for k in kinds)
