@@ -29,8 +29,29 @@ for node in tree.body:
 enum_tree = ast.parse(open(os.path.join(root, "src", "multimm", "enums.py")).read())
 kinds = [ast.literal_eval(st.value) for node in enum_tree.body if isinstance(node, ast.ClassDef) and node.name == "InitialStructureType"
          for st in node.body if isinstance(st, ast.Assign)]
+# the names each *_FORCE_TYPE key may take: in model.py every force builder reads `mode = getattr(self.args, "<KEY>", "<default>")`
+# and branches on `mode == "<name>"` (model.py:173-215, 229-292, 305-382, 395-449, 479-544, 557-615, 648-...)
+forms = {}
+for fn in ast.walk(ast.parse(open(os.path.join(root, "src", "multimm", "model.py")).read())):
+    if not isinstance(fn, ast.FunctionDef):
+        continue
+    key = default = None
+    for n in ast.walk(fn):
+        if (isinstance(n, ast.Assign) and isinstance(n.value, ast.Call) and getattr(n.value.func, "id", "") == "getattr"
+                and len(n.value.args) == 3 and isinstance(n.value.args[1], ast.Constant)
+                and str(n.value.args[1].value).endswith("FORCE_TYPE") and getattr(n.targets[0], "id", "") == "mode"):
+            key, default = n.value.args[1].value, ast.literal_eval(n.value.args[2])
+    if key is None:
+        continue
+    names = []
+    for n in ast.walk(fn):
+        if isinstance(n, ast.Compare) and getattr(n.left, "id", "") == "mode":
+            for c in n.comparators:
+                if isinstance(c, ast.Constant) and isinstance(c.value, str) and c.value not in names:
+                    names.append(c.value)
+    forms[key] = {"default": default, "names": names, "function": fn.name, "line": fn.lineno}
 out = {"source": "src/multimm/config.py (SimulationConfig), read as text with ast; line = line of the field", "fields": fields,
-       "initial_structure_types": kinds}
+       "initial_structure_types": kinds, "force_types": forms}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_config_defaults.json")
 json.dump(out, open(dst, "w"), indent=1)
 print(len(fields), "fields ->", dst)

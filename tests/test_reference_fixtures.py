@@ -157,3 +157,15 @@ def test_initial_structure_types_are_the_reference_enum():
     with pytest.raises(ValueError) as exc:
         compute_init_struct(64, "lattice")
     assert all(k in str(exc.value) for k in kinds)
+
+
+def test_functional_form_names_are_the_reference_branches():
+    """Every `*_FORCE_TYPE` key accepts exactly the names the reference's force builders branch on (`mode == "<name>"` in
+    model.py's add_* methods, read as text), the default being the getattr default there: `system.FORM_NAMES` lists them in
+    the order of `mmx_set_functional_form`'s form index, default first."""
+    from multimm_amd.system import FORM_NAMES
+    ref = json.load(open(os.path.join(GOLD, "ref_config_defaults.json")))["force_types"]
+    assert set(ref) == set(FORM_NAMES)
+    for key, entry in ref.items():
+        assert FORM_NAMES[key][0] == entry["default"], key
+        assert sorted(FORM_NAMES[key]) == sorted(entry["names"]), key
