@@ -114,6 +114,7 @@ class SimulationConfig:
             ff.IBL_USE_B_LAMINA_INTERACTION = ff.CF_USE_CENTRAL_FORCE = False
             self.SHUFFLE_CHROMS = False  # run.py:152
             self.SIM_RUN_MD = True
+            self.SIM_N_STEPS = 10000     # run.py:154 (every preset overwrites the step count)
         elif level in ("region", "loc", "chromosome", "chrom"):
             self.N_BEADS = 5000 if level in ("region", "loc") else 20000
             ff.SC_USE_SPHERICAL_CONTAINER = ff.CHB_USE_CHROMOSOMAL_BLOCKS = False
@@ -121,6 +122,7 @@ class SimulationConfig:
             ff.COB_USE_COMPARTMENT_BLOCKS = has_comp
             ff.IBL_USE_B_LAMINA_INTERACTION = ff.CF_USE_CENTRAL_FORCE = False
             self.SIM_RUN_MD = True
+            self.SIM_N_STEPS = 10000     # run.py:172, 190
         elif level in ("gw", "genome"):
             self.N_BEADS = 200000
             ff.SC_USE_SPHERICAL_CONTAINER = True
@@ -129,6 +131,7 @@ class SimulationConfig:
             ff.IBL_USE_B_LAMINA_INTERACTION = has_comp
             ff.CF_USE_CENTRAL_FORCE = False
             self.SIM_RUN_MD = False
+            self.SIM_N_STEPS = 10000     # run.py:211
         elif level:
             raise ValueError(f"unknown MODELLING_LEVEL {self.MODELLING_LEVEL!r}")
 

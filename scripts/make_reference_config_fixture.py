@@ -50,8 +50,36 @@ for fn in ast.walk(ast.parse(open(os.path.join(root, "src", "multimm", "model.py
                 if isinstance(c, ast.Constant) and isinstance(c.value, str) and c.value not in names:
                     names.append(c.value)
     forms[key] = {"default": default, "names": names, "function": fn.name, "line": fn.lineno}
+# the MODELLING_LEVEL presets: run.py's ArgumentChanger.convenient_argument_changer is an if / elif chain on `level` whose branches
+# call self.set_arg("<KEY>", <value>); values are literals, bool(self.args.COMPARTMENT_PATH) ("has_compartments") or expressions
+# on the chromosome sizes (kept as source text)
+levels = []
+for fn in ast.walk(ast.parse(open(os.path.join(root, "src", "multimm", "run.py")).read())):
+    if isinstance(fn, ast.FunctionDef) and fn.name == "convenient_argument_changer":
+        def names_of(test):
+            if isinstance(test.comparators[0], ast.Constant):
+                return [test.comparators[0].value]
+            return [e.value for e in test.comparators[0].elts]
+        def sets_of(body):
+            out_ = {}
+            for st in body:
+                call = getattr(st, "value", None)
+                if isinstance(call, ast.Call) and getattr(call.func, "attr", "") == "set_arg":
+                    key = call.args[0].value
+                    try:
+                        out_[key] = ast.literal_eval(call.args[1])
+                    except ValueError:
+                        src = ast.unparse(call.args[1])
+                        out_[key] = "has_compartments" if src == "bool(self.args.COMPARTMENT_PATH)" else {"expr": src}
+            return out_
+        always = sets_of(fn.body)
+        node = next(st for st in fn.body if isinstance(st, ast.If))
+        while node is not None:
+            levels.append({"names": names_of(node.test), "sets": sets_of(node.body), "line": node.lineno})
+            nxt = node.orelse
+            node = nxt[0] if len(nxt) == 1 and isinstance(nxt[0], ast.If) else None
 out = {"source": "src/multimm/config.py (SimulationConfig), read as text with ast; line = line of the field", "fields": fields,
-       "initial_structure_types": kinds, "force_types": forms}
+       "initial_structure_types": kinds, "force_types": forms, "modelling_levels": levels, "modelling_levels_always": always}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_config_defaults.json")
 json.dump(out, open(dst, "w"), indent=1)
 print(len(fields), "fields ->", dst)

@@ -102,7 +102,9 @@ def test_md_config_keys_and_presets():
                      "SIM_N_STEPS": "500", "SIM_FRICTION_COEFF": "0.1", "TRJ_FRAMES": "50",
                      "SIM_INTEGRATOR_TYPE": "brownian"})
     assert c.SIM_RUN_MD and abs(c.SIM_INTEGRATOR_STEP - 0.002) < 1e-15 and c.SIM_TEMPERATURE == 300.0
-    assert (c.SIM_N_STEPS, c.TRJ_FRAMES, c.SIM_FRICTION_COEFF, c.SIM_INTEGRATOR_TYPE) == (500, 50, 0.1, "brownian")
+    # (the preset overwrites the step count, whatever the ini says: run.py:172 -- pinned by tests/test_reference_fixtures.py)
+    assert (c.SIM_N_STEPS, c.TRJ_FRAMES, c.SIM_FRICTION_COEFF, c.SIM_INTEGRATOR_TYPE) == (10000, 50, 0.1, "brownian")
+    assert load_config({"SIM_N_STEPS": "500"}).SIM_N_STEPS == 500
     g = load_config({"GENERATE_ENSEMBLE": "True", "N_ENSEMBLE": "4"})
     assert g.GENERATE_ENSEMBLE is True and g.N_ENSEMBLE == 4 and not load_config({}).GENERATE_ENSEMBLE
     e = load_config({"SIM_INTEGRATOR_TYPE": "amd", "SIM_AMD_ALPHA": "250", "SIM_AMD_E": "5e3"})

@@ -169,3 +169,29 @@ def test_functional_form_names_are_the_reference_branches():
     for key, entry in ref.items():
         assert FORM_NAMES[key][0] == entry["default"], key
         assert sorted(FORM_NAMES[key]) == sorted(entry["names"]), key
+
+
+@pytest.mark.parametrize("has_comp", [False, True])
+def test_modelling_level_presets_equal_the_reference(has_comp):
+    """MODELLING_LEVEL (run.py:128-213, `ArgumentChanger.convenient_argument_changer`, read as text): every name of every branch
+    sets the same keys to the same values here -- literals, or `bool(COMPARTMENT_PATH)` where the reference says so -- starting
+    from a configuration in which each of those keys holds the OPPOSITE value.  (LOC_START / LOC_END of the chromosome level are
+    expressions on the chromosome-size table there; this engine leaves them unset and the ingest takes the whole chromosome.)"""
+    import dataclasses
+    from multimm_amd.config import load_config
+    ref = json.load(open(os.path.join(GOLD, "ref_config_defaults.json")))["modelling_levels"]
+    assert sorted(n for lv in ref for n in lv["names"]) == sorted(["gene", "region", "loc", "chromosome", "chrom", "gw", "genome"])
+    for lv in ref:
+        for name in lv["names"]:
+            start = {"MODELLING_LEVEL": name, "COMPARTMENT_PATH": "comps.bed" if has_comp else None, "PLATFORM": "MI355X"}
+            want = {}
+            for key, val in lv["sets"].items():
+                if isinstance(val, dict) or key.startswith("LOC_"):
+                    continue
+                want[key] = has_comp if val == "has_compartments" else val
+                start[key] = (not want[key]) if isinstance(want[key], bool) else (want[key] + 7)
+            cfg = load_config(start)
+            got = {**{f.name: getattr(cfg, f.name) for f in dataclasses.fields(cfg) if f.name != "ff"},
+                   **{f.name: getattr(cfg.ff, f.name) for f in dataclasses.fields(cfg.ff)}}
+            for key, val in want.items():
+                assert got[key] == val, (name, key, got[key], val)
