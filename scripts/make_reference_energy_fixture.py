@@ -77,9 +77,22 @@ for fn in ast.walk(tree):
         for st in fn.body:
             if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name) and isinstance(st.value, (ast.BinOp, ast.Constant)):
                 radii.append({"name": st.targets[0].id, "value": ast.unparse(st.value), "line": st.lineno})
+# call sites that fix the semantics of the path: minimizeEnergy() is called without arguments (OpenMM's defaults: tolerance
+# 10 kJ/mol/nm, maxIterations 0 = until converged), and no force is ever given a nonbonded method or a cutoff (OpenMM's default
+# for a CustomNonbondedForce: NoCutoff -- every pair)
+calls = {"minimizeEnergy": [], "setNonbondedMethod": 0, "setCutoffDistance": 0, "setUseSwitchingFunction": 0, "addExclusion": 0,
+         "createExclusionsFromBonds": 0}
+for n in ast.walk(tree):
+    if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute):
+        if n.func.attr == "minimizeEnergy":
+            calls["minimizeEnergy"].append({"line": n.lineno, "args": [ast.unparse(a) for a in n.args],
+                                            "keywords": {k.arg: ast.unparse(k.value) for k in n.keywords}})
+        elif n.func.attr in calls:
+            calls[n.func.attr] += 1
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_energy_expressions.json")
 json.dump({"source": "src/multimm/model.py, add_* methods and set_radiuses, read as text with ast", "functions": result,
-           "set_radiuses": radii}, open(dst, "w"), indent=1)
+           "set_radiuses": radii, "calls": calls}, open(dst, "w"), indent=1)
+print("calls:", calls)
 print("set_radiuses:", radii)
 for k, v in result.items():
     for m, b in list(v["branches"].items()) + [("(no branch)", v["common"])]:

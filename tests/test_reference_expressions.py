@@ -187,3 +187,16 @@ def test_loop_expressions(mode):
         extra = {k: float(eval(src, {"__builtins__": {}}, ns)) for k, src in loc.items()}
         want += lepton(text, {"r": np.linalg.norm(s.positions[a] - s.positions[b]), "r0": r0, "k": s.ff.LE_HARMONIC_BOND_K, **extra})
     assert abs(want) > 1.0 and oracle_terms(s)[T_LOOP] == pytest.approx(want, rel=1e-12)
+
+
+def test_call_sites_that_fix_the_semantics():
+    """`simulation.minimizeEnergy()` is called bare (model.py:886): OpenMM's defaults, tolerance 10 kJ/mol/nm and no iteration
+    limit -- this engine's MIN_TOLERANCE / MIN_MAX_ITERATIONS defaults; no force of the reference is ever given a nonbonded
+    method, a cutoff, a switching function or an exclusion: every pair interacts (OpenMM's NoCutoff default), bonded neighbours
+    included -- what `NB_CUTOFF <= 0` reproduces and what the pair sums above assume."""
+    from multimm_amd.config import SimulationConfig
+    calls = REF["calls"]
+    assert len(calls["minimizeEnergy"]) == 1 and calls["minimizeEnergy"][0]["args"] == [] and calls["minimizeEnergy"][0]["keywords"] == {}
+    assert (SimulationConfig().MIN_TOLERANCE, SimulationConfig().MIN_MAX_ITERATIONS) == (10.0, 0)
+    for k in ("setNonbondedMethod", "setCutoffDistance", "setUseSwitchingFunction", "addExclusion", "createExclusionsFromBonds"):
+        assert calls[k] == 0, k
