@@ -41,7 +41,7 @@ def collect(nodes, strings):
                         out[PARAM_CALLS[name]].append(n.args[0].value)
             # plain arithmetic on the radii etc. (sigma = 0.1 * (self.radius2 - self.radius1)): kept as source text
             if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) \
-                    and isinstance(n.value, (ast.BinOp, ast.Constant)) and resolve(n.value) is None:
+                    and isinstance(n.value, (ast.BinOp, ast.Constant, ast.IfExp, ast.Attribute, ast.Subscript)) and resolve(n.value) is None:
                 out["locals"][n.targets[0].id] = ast.unparse(n.value)
     return out
 
@@ -89,10 +89,21 @@ for n in ast.walk(tree):
                                             "keywords": {k.arg: ast.unparse(k.value) for k in n.keywords}})
         elif n.func.attr in calls:
             calls[n.func.attr] += 1
+# the backbone: which bonds and angles the built-in harmonic forces receive (model.py:625-636, 708-720): the range of the loop, the
+# condition under which bead i gets a term, and the arguments of addBond / addAngle, all as source text
+backbone = {}
+for fn in ast.walk(tree):
+    if isinstance(fn, ast.FunctionDef) and fn.name in ("add_harmonic_bonds", "add_stiffness"):
+        loop = next(n for n in ast.walk(fn) if isinstance(n, ast.For))
+        cond = next(n for n in ast.walk(loop) if isinstance(n, ast.If))
+        call = next(n for n in ast.walk(cond) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") in ("addBond", "addAngle"))
+        backbone[fn.name] = {"line": fn.lineno, "range": ast.unparse(loop.iter.args[0]), "index": loop.target.id,
+                             "condition": ast.unparse(cond.test), "call": call.func.attr, "args": [ast.unparse(a) for a in call.args]}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_energy_expressions.json")
 json.dump({"source": "src/multimm/model.py, add_* methods and set_radiuses, read as text with ast", "functions": result,
-           "set_radiuses": radii, "calls": calls}, open(dst, "w"), indent=1)
+           "set_radiuses": radii, "calls": calls, "backbone": backbone}, open(dst, "w"), indent=1)
 print("calls:", calls)
+print("backbone:", backbone)
 print("set_radiuses:", radii)
 for k, v in result.items():
     for m, b in list(v["branches"].items()) + [("(no branch)", v["common"])]:

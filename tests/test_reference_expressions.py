@@ -184,7 +184,7 @@ def test_loop_expressions(mode):
     want = 0.0
     for a, b, r0 in zip(s.loop_m, s.loop_n, s.loop_r0):
         ns = {"r0": float(r0)}
-        extra = {k: float(eval(src, {"__builtins__": {}}, ns)) for k, src in loc.items()}
+        extra = {k: float(eval(src, {"__builtins__": {}}, ns)) for k, src in loc.items() if k not in ("r0", "k")}
         want += lepton(text, {"r": np.linalg.norm(s.positions[a] - s.positions[b]), "r0": r0, "k": s.ff.LE_HARMONIC_BOND_K, **extra})
     assert abs(want) > 1.0 and oracle_terms(s)[T_LOOP] == pytest.approx(want, rel=1e-12)
 
@@ -200,3 +200,28 @@ def test_call_sites_that_fix_the_semantics():
     assert (SimulationConfig().MIN_TOLERANCE, SimulationConfig().MIN_MAX_ITERATIONS) == (10.0, 0)
     for k in ("setNonbondedMethod", "setCutoffDistance", "setUseSwitchingFunction", "addExclusion", "createExclusionsFromBonds"):
         assert calls[k] == 0, k
+
+
+@pytest.mark.parametrize("ends", [[0, 40], [0, 7, 19, 40], [0, 1, 2, 40], [0, 38, 39, 40]])
+def test_backbone_topology_follows_the_reference_conditions(ends):
+    """Which beads get a bond / an angle: the reference's loop range and `if` condition (model.py:625-636, 708-720, read as text:
+    `i not in self.chr_ends` -- chr_ends holds the FIRST bead of every chromosome and N, hence the off-by-one quirks of SURVEY.md
+    appendix A.2) evaluated for every i, against `system.backbone_flags`; the arguments of addBond / addAngle name beads
+    i, i + 1 (, i + 2) and the POL_* keys this engine reads."""
+    from multimm_amd.system import backbone_flags
+    n = ends[-1]
+    flags = backbone_flags(n, np.array(ends))
+    me = SimpleNamespace(chr_ends=np.array(ends), system=SimpleNamespace(getNumParticles=lambda: n))
+    for fn, bit in (("add_harmonic_bonds", 1), ("add_stiffness", 2)):
+        b = REF["backbone"][fn]
+        upper = eval(b["range"], {"__builtins__": {}}, {"self": me})
+        want = np.zeros(n, bool)
+        for i in range(upper):
+            want[i] = bool(eval(b["condition"], {"__builtins__": {}}, {"self": me, b["index"]: i}))
+        assert np.array_equal((flags & bit) != 0, want), (fn, ends)
+    assert REF["backbone"]["add_harmonic_bonds"]["args"] == ["i", "i + 1", "self.args.POL_HARMONIC_BOND_R0", "self.args.POL_HARMONIC_BOND_K"]
+    assert REF["backbone"]["add_stiffness"]["args"] == ["i", "i + 1", "i + 2", "self.args.POL_HARMONIC_ANGLE_R0",
+                                                       "self.args.POL_HARMONIC_ANGLE_CONSTANT_K"]
+    loops = REF["functions"]["add_loops"]["branches"]["harmonic"]["locals"]
+    assert loops == {"r0": "self.args.LE_HARMONIC_BOND_R0 if self.args.LE_FIXED_DISTANCES else self.ds[i]",
+                     "k": "self.args.LE_HARMONIC_BOND_K"}       # what ChromatinSystem.loop_rest_lengths() / the loop kernel use
