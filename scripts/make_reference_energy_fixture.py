@@ -99,9 +99,21 @@ for fn in ast.walk(tree):
         call = next(n for n in ast.walk(cond) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") in ("addBond", "addAngle"))
         backbone[fn.name] = {"line": fn.lineno, "range": ast.unparse(loop.iter.args[0]), "index": loop.target.id,
                              "condition": ast.unparse(cond.test), "call": call.func.attr, "args": [ast.unparse(a) for a in call.args]}
+# MD: which OpenMM integrator every SIM_INTEGRATOR_TYPE constructs and from which keys, in argument order (model.py:768-808),
+# and how velocities are drawn (model.py:878)
+integrators = {}
+for n in ast.walk(tree):
+    if isinstance(n, ast.Match) and ast.unparse(n.subject) == "self.args.SIM_INTEGRATOR_TYPE":
+        for case in n.cases:
+            call = next(c for c in ast.walk(case) if isinstance(c, ast.Call) and ast.unparse(c.func).startswith("mm."))
+            integrators[case.pattern.value.value] = {"class": ast.unparse(call.func), "args": [ast.unparse(a) for a in call.args],
+                                                     "line": call.lineno}
+velocities = [{"args": [ast.unparse(a) for a in n.args], "line": n.lineno} for n in ast.walk(tree)
+              if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "setVelocitiesToTemperature"]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_energy_expressions.json")
 json.dump({"source": "src/multimm/model.py, add_* methods and set_radiuses, read as text with ast", "functions": result,
-           "set_radiuses": radii, "calls": calls, "backbone": backbone}, open(dst, "w"), indent=1)
+           "set_radiuses": radii, "calls": calls, "backbone": backbone, "integrators": integrators,
+           "set_velocities": velocities}, open(dst, "w"), indent=1)
 print("calls:", calls)
 print("backbone:", backbone)
 print("set_radiuses:", radii)

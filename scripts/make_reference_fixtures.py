@@ -19,6 +19,7 @@ of whose bodies reaches a placeholder:
     initial_structure_tools.write_mmcif_chrom (:417-458)
     initial_structure_tools.compute_init_struct for those four curves (the raw float64 arrays)
     utils.get_coordinates_cif on the init files its own writer produced (the reader of model.py:1001,1083)
+    utils.chrom_lengths_array / utils.chrom_strength (module-level tables, utils.py:67-137)
 
 NOT pinned here (needs the absent packages): the Hilbert start (hilbertcurve 2.0.5) and every energy / force / minimizer
 number (OpenMM 8.5.1).  Those rows stay "parity unpinned" ("Oracle").
@@ -189,6 +190,9 @@ def main():
         manifest["cif"].append({"curve": curve, "n": n, "chrom_ends": ends, "init": os.path.basename(dst),
                                 "chrom": os.path.basename(dstc), "chrom_slice": [ends[0], ends[1]]})
         print(f"cif {tag}: {os.path.getsize(dst)} + {os.path.getsize(dstc)} bytes")
+    # module-level tables of utils.py (67-137): the hg38 chromosome lengths and the central-force weights derived from them
+    curves["chrom_lengths_array"] = np.asarray(utils.chrom_lengths_array)
+    curves["chrom_strength"] = np.asarray(utils.chrom_strength, dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "ref_curves.npz"), **curves)
     with open(os.path.join(OUT, "ref_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

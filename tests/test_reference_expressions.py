@@ -225,3 +225,27 @@ def test_backbone_topology_follows_the_reference_conditions(ends):
     loops = REF["functions"]["add_loops"]["branches"]["harmonic"]["locals"]
     assert loops == {"r0": "self.args.LE_HARMONIC_BOND_R0 if self.args.LE_FIXED_DISTANCES else self.ds[i]",
                      "k": "self.args.LE_HARMONIC_BOND_K"}       # what ChromatinSystem.loop_rest_lengths() / the loop kernel use
+
+
+def test_integrator_wiring_follows_the_reference():
+    """SIM_INTEGRATOR_TYPE -> OpenMM integrator and the keys it is built from, in argument order (model.py:768-808, read as
+    text): the four fixed-step ones are what this engine provides, fed from the same keys (`MultiMM.run_md`); the two
+    variable-step ones read `self.SIM_ERROR_TOLERANCE` -- an attribute the class never sets (the key lives in `self.args`) --
+    so the reference itself cannot construct them.  Velocities: setVelocitiesToTemperature(SIM_TEMPERATURE,
+    SHUFFLING_SEED) (model.py:878).  Bead mass: the one atom type of forcefields/ff.xml."""
+    import inspect
+    from multimm_amd import engine, model
+    ints = REF["integrators"]
+    fixed = {k for k, v in ints.items() if not any("SIM_ERROR_TOLERANCE" in a for a in v["args"])}
+    assert fixed == set(engine.INTEGRATORS) == {"langevin", "verlet", "brownian", "amd"}
+    assert ints["langevin"]["args"] == ints["brownian"]["args"] == [
+        "self.args.SIM_TEMPERATURE", "self.args.SIM_FRICTION_COEFF", "self.args.SIM_INTEGRATOR_STEP"]
+    assert ints["verlet"]["args"] == ["self.args.SIM_INTEGRATOR_STEP"]
+    assert ints["amd"]["args"] == ["self.args.SIM_INTEGRATOR_STEP", "self.args.SIM_AMD_ALPHA", "self.args.SIM_AMD_E"]
+    for k in ("variable_verlet", "variable_langevin"):
+        assert "self.SIM_ERROR_TOLERANCE" in ints[k]["args"] and not any("self.args.SIM_ERROR_TOLERANCE" in a for a in ints[k]["args"])
+    assert REF["set_velocities"] == [{"args": ["self.args.SIM_TEMPERATURE", "self.args.SHUFFLING_SEED"], "line": REF["set_velocities"][0]["line"]}]
+    src = inspect.getsource(model.MultiMM.run_md)
+    for key in ("SIM_INTEGRATOR_STEP", "SIM_TEMPERATURE", "SIM_FRICTION_COEFF", "SIM_AMD_ALPHA", "SIM_AMD_E", "SHUFFLING_SEED"):
+        assert key in src, key
+    assert engine.BEAD_MASS_AMU == 16427.889

@@ -195,3 +195,15 @@ def test_modelling_level_presets_equal_the_reference(has_comp):
                    **{f.name: getattr(cfg.ff, f.name) for f in dataclasses.fields(cfg.ff)}}
             for key, val in want.items():
                 assert got[key] == val, (name, key, got[key], val)
+
+
+def test_chromosome_tables_equal_the_reference():
+    """`utils.chrom_lengths_array[1:]` (hg38 lengths, utils.py:67-95) and `utils.chrom_strength` (utils.py:137: the weights the
+    central force multiplies by, model.py:158-162, 621) as the reference's module holds them: the table and the per-bead weights
+    here are bit-equal."""
+    from multimm_amd.system import CHROM_LENGTHS, chrom_strength_per_bead, gw_chr_ends
+    assert np.array_equal(CHROM_LENGTHS, CURVES["chrom_lengths_array"][1:])
+    ends = gw_chr_ends(20000, 22)
+    w = chrom_strength_per_bead(ends, 20000)
+    for i in range(22):
+        assert np.all(w[ends[i]:ends[i + 1]] == CURVES["chrom_strength"][i]), i
