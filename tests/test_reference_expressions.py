@@ -89,6 +89,62 @@ def oracle_terms(s):
     return Oracle(s, as_float32_inputs=False).eval()[0]
 
 
+# ---- the same cases as (system, reference sum, term index): tests/test_gpu_reference_expressions.py runs them on the device ----
+def _pairs(s, text, p, per_pair, x=None):
+    x = s.positions if x is None else x
+    return sum(lepton(text, {**p, "r": np.linalg.norm(x[i] - x[j]), **per_pair(i, j)}) for j in range(s.n_beads) for i in range(j))
+
+
+def expression_cases():
+    out = []
+    for mode in ("powerlaw", "gaussian_core"):
+        s = small_system(EV_USE_EXCLUDED_VOLUME=True, EV_FORCE_TYPE=mode)
+        text, g, loc = branch("add_evforce", mode)
+        p = values(g, loc, s)
+        out.append((f"ev-{mode}", s, _pairs(s, text, p, lambda i, j: {}), T_EV,
+                    lambda x, s=s, text=text, p=p: _pairs(s, text, p, lambda i, j: {}, x)))
+    for fn, key, switch, tag in (("add_compartment_blocks", "COB_FORCE_TYPE", "COB_USE_COMPARTMENT_BLOCKS", "cob"),
+                                 ("add_subcompartment_blocks", "SCB_FORCE_TYPE", "SCB_USE_SUBCOMPARTMENT_BLOCKS", "scb")):
+        for mode in ("gaussian", "yukawa", "theta"):
+            s = small_system(seed=3, spread=0.12, **{switch: True, key: mode})
+            text, g, loc = branch(fn, mode)
+            lab = s.labels.astype(float)
+            p = values(g, loc, s)
+            pp = lambda i, j, lab=lab: {"s1": lab[i], "s2": lab[j]}
+            out.append((f"{tag}-{mode}", s, _pairs(s, text, p, pp), T_GAUSS, lambda x, s=s, text=text, p=p, pp=pp: _pairs(s, text, p, pp, x)))
+    for mode in ("polynomial", "gaussian", "saturating"):
+        s = small_system(seed=5, CHB_USE_CHROMOSOMAL_BLOCKS=True, CHB_FORCE_TYPE=mode)
+        text, g, loc = branch("add_chromosomal_blocks", mode)
+        chrom = np.searchsorted(s.chr_ends, np.arange(s.n_beads), side="right") - 1
+        p = values(g, loc, s)
+        pp = lambda i, j, chrom=chrom: {"chrom1": chrom[i], "chrom2": chrom[j]}
+        out.append((f"chb-{mode}", s, _pairs(s, text, p, pp), T_CHB, lambda x, s=s, text=text, p=p, pp=pp: _pairs(s, text, p, pp, x)))
+    s = small_system(n=40, seed=7, SC_USE_SPHERICAL_CONTAINER=True)
+    s.positions *= 0.5 * s.radii[1] / 0.35
+    text, g, loc = branch("add_spherical_container", None)
+    p = values(g, loc, s)
+    out.append(("container", s, _external(s, text, p), T_CONT, lambda x, s=s, text=text, p=p: _external(s, text, p, None, x)))
+    for mode in ("sin", "gaussian_shell", "harmonic_shell", "logistic_shell"):
+        s = small_system(n=40, seed=9, IBL_USE_B_LAMINA_INTERACTION=True, BLAMINA_FORCE_TYPE=mode)
+        s.positions *= 0.5 * s.radii[1] / 0.35
+        text, g, loc = branch("add_Blamina_interaction", mode)
+        p, per = values(g, loc, s), {"s": s.labels.astype(float)}
+        out.append((f"lamina-{mode}", s, _external(s, text, p, per), T_LAM, lambda x, s=s, text=text, p=p, per=per: _external(s, text, p, per, x)))
+    for mode in ("harmonic", "gaussian", "logistic"):
+        s = small_system(n=40, seed=11, CF_USE_CENTRAL_FORCE=True, CENTRAL_FORCE_TYPE=mode)
+        s.positions *= 0.5 * s.radii[1] / 0.35
+        text, g, loc = branch("add_central_force", mode)
+        p, per = values(g, loc, s), {"chrom_s": s.chrom_strength}
+        out.append((f"central-{mode}", s, _external(s, text, p, per), T_CENT, lambda x, s=s, text=text, p=p, per=per: _external(s, text, p, per, x)))
+    return out
+
+
+def test_case_table_agrees_with_the_oracle():
+    for name, s, want, term, energy_of in expression_cases():
+        assert oracle_terms(s)[term] == pytest.approx(want, rel=1e-12), name
+        assert energy_of(s.positions) == want
+
+
 def test_radii_follow_the_reference_text():
     for n in (1000, 50000, 200000, 1000000):
         ns = {"b0": 0.1, "N": float(n)}
@@ -134,11 +190,12 @@ def test_chromosomal_block_expressions(mode):
     assert abs(want) > 1e-5 and oracle_terms(s)[T_CHB] == pytest.approx(want, rel=1e-12)
 
 
-def _external(s, text, p, per_particle=None):
-    c = s.centre
+def _external(s, text, p, per_particle=None, x=None):
+    c = s.centre            # (a global parameter of the force: set once, from the structure the system was built with)
+    pos = s.positions if x is None else x
     tot = 0.0
     for i in range(s.n_beads):
-        env = {**p, "x": s.positions[i, 0], "y": s.positions[i, 1], "z": s.positions[i, 2], "x0": c[0], "y0": c[1], "z0": c[2]}
+        env = {**p, "x": pos[i, 0], "y": pos[i, 1], "z": pos[i, 2], "x0": c[0], "y0": c[1], "z0": c[2]}
         if per_particle:
             env.update({k: v[i] for k, v in per_particle.items()})
         tot += lepton(text, env)
