@@ -110,13 +110,21 @@ for n in ast.walk(tree):
                                                      "line": call.lineno}
 velocities = [{"args": [ast.unparse(a) for a in n.args], "line": n.lineno} for n in ast.walk(tree)
               if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "setVelocitiesToTemperature"]
+# add_forcefield (model.py:812-857): which switch gates which force builder, in source order
+switches = []
+for fn in ast.walk(tree):
+    if isinstance(fn, ast.FunctionDef) and fn.name == "add_forcefield":
+        for st in fn.body:
+            if isinstance(st, ast.If):
+                call = next(c for c in ast.walk(st) if isinstance(c, ast.Call) and ast.unparse(c.func).startswith("self.add_"))
+                switches.append({"switch": ast.unparse(st.test), "builder": call.func.attr, "line": st.lineno})
 # the one atom type of forcefields/ff.xml: the bead mass the integrators see
 import re
 masses = [float(m) for m in re.findall(r'<Type[^>]*mass="([^"]+)"', open(os.path.join(root, "src", "multimm", "forcefields", "ff.xml")).read())]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_energy_expressions.json")
 json.dump({"source": "src/multimm/model.py, add_* methods and set_radiuses, read as text with ast", "functions": result,
            "set_radiuses": radii, "calls": calls, "backbone": backbone, "integrators": integrators,
-           "set_velocities": velocities, "atom_type_masses": masses}, open(dst, "w"), indent=1)
+           "set_velocities": velocities, "atom_type_masses": masses, "add_forcefield": switches}, open(dst, "w"), indent=1)
 print("calls:", calls)
 print("backbone:", backbone)
 print("set_radiuses:", radii)

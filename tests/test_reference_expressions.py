@@ -306,3 +306,25 @@ def test_integrator_wiring_follows_the_reference():
     for key in ("SIM_INTEGRATOR_STEP", "SIM_TEMPERATURE", "SIM_FRICTION_COEFF", "SIM_AMD_ALPHA", "SIM_AMD_E", "SHUFFLING_SEED"):
         assert key in src, key
     assert REF["atom_type_masses"] == [engine.BEAD_MASS_AMU]
+
+
+def test_every_switch_gates_the_term_the_reference_builds_with_it():
+    """`add_forcefield` (model.py:812-857, read as text): ten `*_USE_*` switches, each guarding one force builder.  With exactly one
+    switch on, exactly the energy term of that builder is non-zero here (oracle), all nine others vanish."""
+    builder_term = {"add_evforce": T_EV, "add_compartment_blocks": T_GAUSS, "add_subcompartment_blocks": T_GAUSS,
+                    "add_chromosomal_blocks": T_CHB, "add_spherical_container": T_CONT, "add_Blamina_interaction": T_LAM,
+                    "add_central_force": T_CENT, "add_harmonic_bonds": T_BOND, "add_loops": T_LOOP, "add_stiffness": T_ANGLE}
+    table = REF["add_forcefield"]
+    assert [t["builder"] for t in table] == list(builder_term)          # source order: the reference's (and this table's)
+    rng = np.random.default_rng(21)
+    for t in table:
+        key = t["switch"].removeprefix("self.args.")
+        assert key in vars(ForceFieldParams()), key
+        s = small_system(n=40, seed=23, spread=0.12, **{key: True})
+        s.positions *= 3.0 if key in ("SC_USE_SPHERICAL_CONTAINER", "IBL_USE_B_LAMINA_INTERACTION", "CF_USE_CENTRAL_FORCE") else 1.0
+        s.loop_m, s.loop_n = np.array([1, 5], np.int32), np.array([9, 30], np.int32)
+        s.loop_r0 = np.array([0.1, 0.15])
+        et = oracle_terms(s)
+        term = builder_term[t["builder"]]
+        assert abs(et[term]) > 1e-9, (key, et)
+        assert np.abs(np.delete(et, term)).max() == 0.0, (key, et)
