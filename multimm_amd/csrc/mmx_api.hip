@@ -113,6 +113,8 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             h->fstride = (h->n_all + 1) * 8;
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
             HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
+            HIPCHK(h, dalloc(&h->slot_of, (size_t)std::max(world > 1 ? h->slice : h->n_own, 1)));
+            HIPCHK(h, dalloc(&h->sync, (size_t)1));
             h->n3_cap = n3_configure(kN3MaxCap);
             // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16 (<= n_all /
             // 128 + cells / 16) runs; a run is one record per window pass over its candidates: the rest of n_all / 16 is theirs
@@ -248,7 +250,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead,
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync,
                     (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
                     (void *)h->md_snap, (void *)h->cell_xref, (void *)h->slotkeys})
         if (p) (void)hipFree(p);
@@ -574,6 +576,12 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "nb_variant") h->nb_variant = (int)value;
     else if (k == "fused_bonded") h->fused_bonded = value != 0.0;
     else if (k == "overlap_bonded") h->overlap_bonded = value != 0.0;
+    else if (k == "fused_tail") {
+        h->fused_tail = value != 0.0;
+        // (k_tail's partials are tagged words, k_history's plain doubles, in the same buffer: neither may take the other's for its own)
+        HIPCHK(h, hipMemsetAsync(h->rows, 0, sizeof(double) * (size_t)MMX_NROWSUM * kPartStride, h->stream));
+    }
+    else if (k == "fused_build") h->fused_build = value != 0.0;
     else if (k == "use_graph") h->use_graph = value != 0.0;
     else if (k == "dd_halo") h->dd_halo = value != 0.0;
     else if (k == "dd_skin") {
@@ -615,6 +623,8 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "nb_variant") *value = h->nb_variant;
     else if (k == "fused_bonded") *value = h->fused_bonded;
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
+    else if (k == "fused_tail") *value = h->fused_tail;
+    else if (k == "fused_build") *value = h->fused_build;
     else if (k == "use_graph") *value = h->use_graph;
     else if (k == "inject_fault") *value = h->inject_fault;
     else if (k == "n3_launches") *value = (double)h->n3_launches;   // read-only: how often the half-shell kernel ran
@@ -705,6 +715,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     h->dd_slack_div = 4;
     int rc = prepare(h);
     if (rc) return rc;
+    h->fsort_dirty = true; // until this call has ended in order
     const auto t0 = std::chrono::steady_clock::now();
     mmx_stats local;
     std::memset(&local, 0, sizeof(local));
@@ -824,6 +835,9 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
             h->st_host->halt_reason = 0;
             if ((rc = push_state(h))) return leave(rc);
             h->prof_eval = 0;
+            // (a void evaluation may have skipped cells -- a slot table too small --, whose cluster slots k_tail then never
+            //  visited: whatever the pair kernel left there must not leak into the repeat)
+            if (h->fsort && h->fused_tail) HIPCHK(h, hipMemsetAsync(h->fsort, 0, sizeof(float) * 3 * (size_t)h->fstride, h->stream));
             enqueue_eval(h, PACK_MOVE, FOLD_MIN, 1);
             if (h->dd_rc != MMX_OK) return leave(h->dd_rc);
             if ((rc = pull_state(h))) return leave(rc);
@@ -873,6 +887,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (out) *out = local;
     if (s.status == MMX_MIN_KERNEL || s.kernel_error) return kernel_error_rc(h);
+    h->fsort_dirty = false;
     if (s.status == MMX_MIN_NAN) return fail(h, MMX_ERR_NAN, "non-finite energy during minimization");
     return MMX_OK;
 } MMX_CATCH(h)
@@ -1355,6 +1370,11 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
 
 } // extern "C"
 
+#ifdef MMX_STAGE_TIMING
+extern "C" int mmx_debug_stage_times(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_stage_t), sizeof(unsigned long long) * 8192);
+}
+#endif
 #ifdef MMX_N3_TIMING
 extern "C" int mmx_debug_n3_times(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_n3_t), sizeof(unsigned long long) * 512 * 20);

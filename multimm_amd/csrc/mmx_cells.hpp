@@ -517,7 +517,8 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
                                               const float4 *__restrict__ pos4, float4 *__restrict__ spos4,
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, const Own &own,
-                                              const unsigned long long *keys = nullptr, int *__restrict__ sbead = nullptr) {
+                                              const unsigned long long *keys = nullptr, int *__restrict__ sbead = nullptr,
+                                              int *__restrict__ slot_of = nullptr) {
     const int o8 = ((no + 7) >> 3) << 3; // slots of the owned clusters
     const int ncl = cell_clusters(cnt, no);
     for (int e = tid; e < ncl * 8; e += nthr) {
@@ -529,13 +530,15 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
             const int b = keys ? (int)(unsigned)(keys[src] & 0xffffffffull) : perm[s + src];
             p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
-            nown = own.owns(b) ? 1 : 0;
             bead = b;
         }
+        const int lb = real ? own.local(bead) : -1;
+        nown = lb >= 0 ? 1 : 0;
         // slot of entry e: the owned clusters at cb, the ghosts' either right behind them or in their own region
         const size_t sl = (cbg < 0 || e < o8) ? (size_t)cb * 8 + e : (size_t)cbg * 8 + (e - o8);
         spos4[sl] = p;
         if (sbead) sbead[sl] = bead; // slot -> bead (k_nb_n3_unsort reads 4 bytes per slot, not a float4)
+        if (slot_of && lb >= 0) slot_of[lb] = (int)sl; // owned bead (local order) -> slot: what k_tail gathers the pair forces by
         const float big = 3.0e38f;
         float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
         float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
@@ -684,7 +687,8 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
                                                  const int *__restrict__ biglist,
                                                  MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
                                                  int *__restrict__ sbead = nullptr, const int slot_cap = 0,
-                                                 const int slot_cells = 0, const int split = 0) {
+                                                 const int slot_cells = 0, const int split = 0,
+                                                 int *__restrict__ slot_of = nullptr) {
     // split: the ghosts' clusters of cell c start at n_clusters_own + istart[c] (ScanArgs::split)
     const int gbase = split ? st->n_clusters_own : 0;
     // slot_cap > 0: `okeys` is the slot table the pack wrote (keys of cell c at c * slot_cap), not the counting sort's slices
@@ -730,7 +734,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             if (lane < cnt) perm[s + lane] = (int)(unsigned)(v & 0xffffffffull);
             __threadfence_block(); // the sorted perm[] is re-read below by other lanes
         }
-        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, lane, 64, own, nullptr, sbead, slot_of);
     }
 
     // ---- pass B: the whole block per large cell, taken from the list the scan compacted (one cell per block in
@@ -757,7 +761,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             else if (n2 == 512) block_sort_regs<2>(s_buf, okeys + kb, cnt, n2);
             else block_sort_regs<4>(s_buf, okeys + kb, cnt, n2);
             for (int q = threadIdx.x; q < cnt; q += 256) perm[s + q] = (int)(unsigned)(s_buf[q] & 0xffffffffull);
-            emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead);
+            emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, s_buf, sbead, slot_of);
             continue;
         }
         if (cnt <= CAP) { // 1025..4096 beads (CAP = 4096 instances only): the all-LDS network
@@ -819,7 +823,7 @@ __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, 
             // the evaluation is void (decomposed handles always run the CAP = 4096 instance: > 4096 beads in one cell)
             if (count_own) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
         }
-        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead);
+        emit_clusters(c, s, cnt, no, cstart[c], split ? gbase + istart[c] : -1, perm, pos4, spos4, cl_lo, cl_hi, threadIdx.x, 256, own, nullptr, sbead, slot_of);
     }
 }
 
@@ -835,10 +839,10 @@ __global__ __launch_bounds__(256) void k_cell_order(const GridParams *__restrict
                                                     const int *__restrict__ biglist,
                                                     MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
                                                     int *__restrict__ sbead = nullptr, const int slot_cap = 0,
-                                                    const int slot_cells = 0) {
+                                                    const int slot_cells = 0, int *__restrict__ slot_of = nullptr) {
     if (st->phase >= PH_DONE) return;
     cell_order_block<CHUNK, CAP>((int)blockIdx.x, (int)gridDim.x, grid, start, istart, count, perm, items, cstart, pos4, spos4,
-                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, 0);
+                                 cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, 0, slot_of);
 }
 
 } // namespace mmx

@@ -115,7 +115,10 @@ struct FormParams {
 // MinState::kernel_error bits
 enum KernelError { KERR_N3_SPIN = 1,   // k_nb_n3: a wave waited for a unit / flush that never came (protocol bug)
                    KERR_N3_ITEMS = 2,  // k_nb_n3's item list is too short for this cell build
-                   KERR_ORDER_DD = 4 }; // decomposed rank: a cell too large for the in-cell sort would mix owned beads and ghosts
+                   KERR_ORDER_DD = 4,  // decomposed rank: a cell too large for the in-cell sort would mix owned beads and ghosts
+                   KERR_BUILD_WAIT = 8, // k_build: a stage waited for an earlier one that never finished (protocol bug)
+                   KERR_BOUNDS = 16,   // a cell-build offset would have left its array (stale counters, corrupt state): nothing was written
+                   KERR_TAIL_WAIT = 32 }; // k_tail: a workgroup's partial sums never arrived at the one that folds them (protocol bug)
 
 // Device-resident minimizer state; mirrored to pinned host memory when polled.
 struct MinState {
@@ -164,15 +167,73 @@ struct MinState {
 };
 static_assert(offsetof(MinState, rowsum) == offsetof(MinState, sums) + 16 * sizeof(double), "sums and rowsum are reduced as one array");
 
+// Counters of the launch whose workgroups depend on each other (device; zero between launches -- the last workgroup of a
+// launch puts them back).  k_build (mmx_build.hpp): the stages of the cell build -- count, scan, fill, order / work items -- are roles of ONE launch; a role takes
+// a ticket, and only ever waits for roles with lower tickets, which are therefore resident or done.
+struct LaunchSync {
+    unsigned build_ticket; // k_build: next logical workgroup id
+    unsigned build_exits;  // ... workgroups that have left
+    int grid_done;         // ... the grid of this build is in place (decomposed ranks: k_grid_init's work)
+    int count_done;        // ... workgroups of the count stage that have finished
+    int scan_done;         // ... offsets, cluster counts, big-cell list, next grid are in place
+    int fill_done;         // ... workgroups of the fill stage that have finished
+    int pad[2];
+};
+
 // ---- wave helpers ---------------------------------------------------------------------------
+// The xor butterfly (offsets 32, 16, 8, 4, 2, 1: every lane ends up with the wave's total, association fixed) WITHOUT the LDS
+// crossbar: __shfl_xor is a ds_bpermute per 32 bits and step -- ~100 cycles each, a dependent chain of six (twelve for a double)
+// per value, and the epilogue of a kernel that folds a dozen accumulators spent 4-8 us in them.  Here: lanes i <-> i ^ 32 and
+// i <-> i ^ 16 by gfx950's v_permlane32_swap / v_permlane16_swap (a copy of the value is swapped half-wise / row-wise with the
+// value itself: one of the two then holds the partner's value in every lane), i ^ 8 and i ^ 4 by DPP row_ror:8 / row_ror:4 (a
+// rotation by 4 pairs lane i with i + 4 mod 16, whose value equals that of i ^ 4 once the i ^ 8 step has made the row 8-periodic),
+// i ^ 2 and i ^ 1 by DPP quad_perm.  Same operand pairs in the same order as the shuffle version (addition, min and max commute):
+// the same bits in every lane (scripts/ubench/wave_sum_check.hip).
+// (after a swap of v with a copy of itself, the two results hold {own value, partner's value} in one order or the other: OP of
+//  the two is OP(own, partner) whichever lane asks)
+#define MMX_SWAP_STEP_I(OP, SWAP, v)                                                                        \
+    do {                                                                                                    \
+        const auto r_ = SWAP((v), (v), false, false);                                                       \
+        (v) = OP((int)r_[0], (int)r_[1]); /* (the builtin returns unsigned) */                              \
+    } while (0)
+#define MMX_SWAP_STEP_F(OP, SWAP, v)                                                                        \
+    do {                                                                                                    \
+        const auto r_ = SWAP(__float_as_int(v), __float_as_int(v), false, false);                           \
+        (v) = OP(__int_as_float(r_[0]), __int_as_float(r_[1]));                                             \
+    } while (0)
+template <int CTRL>
+__device__ __forceinline__ int dpp_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner(float v) { return __int_as_float(dpp_partner<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+    return __hiloint2double(dpp_partner<CTRL>(__double2hiint(v)), dpp_partner<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ float mmx_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    MMX_SWAP_STEP_F(mmx_addf, __builtin_amdgcn_permlane32_swap, v);
+    MMX_SWAP_STEP_F(mmx_addf, __builtin_amdgcn_permlane16_swap, v);
+    v += dpp_partner<0x128>(v); // row_ror:8
+    v += dpp_partner<0x124>(v); // row_ror:4
+    v += dpp_partner<0x4e>(v);  // quad_perm:[2,3,0,1]
+    v += dpp_partner<0xb1>(v);  // quad_perm:[1,0,3,2]
     return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    v += dpp_partner<0x128>(v);
+    v += dpp_partner<0x124>(v);
+    v += dpp_partner<0x4e>(v);
+    v += dpp_partner<0xb1>(v);
     return v;
 }
 // Wave total by DPP (no LDS crossbar): butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, 8),
@@ -193,18 +254,30 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    MMX_SWAP_STEP_F(fminf, __builtin_amdgcn_permlane32_swap, v);
+    MMX_SWAP_STEP_F(fminf, __builtin_amdgcn_permlane16_swap, v);
+    v = fminf(v, dpp_partner<0x128>(v));
+    v = fminf(v, dpp_partner<0x124>(v));
+    v = fminf(v, dpp_partner<0x4e>(v));
+    v = fminf(v, dpp_partner<0xb1>(v));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    MMX_SWAP_STEP_F(fmaxf, __builtin_amdgcn_permlane32_swap, v);
+    MMX_SWAP_STEP_F(fmaxf, __builtin_amdgcn_permlane16_swap, v);
+    v = fmaxf(v, dpp_partner<0x128>(v));
+    v = fmaxf(v, dpp_partner<0x124>(v));
+    v = fmaxf(v, dpp_partner<0x4e>(v));
+    v = fmaxf(v, dpp_partner<0xb1>(v));
     return v;
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    MMX_SWAP_STEP_I(max, __builtin_amdgcn_permlane32_swap, v);
+    MMX_SWAP_STEP_I(max, __builtin_amdgcn_permlane16_swap, v);
+    v = max(v, dpp_partner<0x128>(v));
+    v = max(v, dpp_partner<0x124>(v));
+    v = max(v, dpp_partner<0x4e>(v));
+    v = max(v, dpp_partner<0xb1>(v));
     return v;
 }
 

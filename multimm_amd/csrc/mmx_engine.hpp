@@ -863,21 +863,21 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split);
+                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split, h->slot_of);
             else
                 hipLaunchKernelGGL((k_order_items<kChunk, 4096>), dim3(go + kN3ItemBlocks), dim3(256), 0, h->stream, go, cur,
                                    h->start, h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo,
                                    h->cl_hi, own_of(h), keys, h->biglist, h->n3_items,
                                    (h->inject_fault & 2) ? 1 : h->n3_max_items, h->st, h->count_own, h->sbead,
-                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split);
+                                   (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) | (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8), scap, scells, split, h->slot_of);
         } else if (small_cells)
             hipLaunchKernelGGL((k_cell_order<kChunk, 1024>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells);
+                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells, h->slot_of);
         else
             hipLaunchKernelGGL((k_cell_order<kChunk, 4096>), dim3(go), dim3(256), 0, h->stream, cur, h->start,
                                h->istart, h->count, h->perm, h->items, h->cstart, h->pos4, h->spos4, h->cl_lo, h->cl_hi,
-                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells);
+                               own_of(h), keys, h->biglist, h->st, h->count_own, h->sbead, scap, scells, h->slot_of);
         h->gcur = cur;
         h->build_idx++;
         h->grid_ready = true;
@@ -983,10 +983,43 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
         A.nblk[P_EV] = A.nblk[P_GAUSS] = gn;
     }
     prof_end(h, on, ep);
+    const bool solo = !has_comm(h) || h->dd_frozen; // no all-reduce: this handle's sums are all there is
+    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
+    if (fold == FOLD_MIN && h->fused_tail) {
+        // the minimizer's tail in ONE launch (k_tail): the half-shell kernel's forces out of their cluster slots, the history
+        // pass, and -- by the workgroup that finishes last -- the fold + decision
+        const bool unsort = has_nb(h) && !all_pairs(h) && h->n3_build;
+        if (++h->tail_epoch == 0u) h->tail_epoch = 1u;
+        const TailArgs T{h->slot_of, h->fsort, h->fstride, h->n_own, unsort ? &h->st->n3_queue : nullptr, h->tail_epoch,
+                         (h->inject_fault & 32) ? -1 : kTailSpinLimit}; // option inject_fault bit 5: the fold gives up before its first poll
+        on = prof_begin(h, MMX_K_LBFGS, ep);
+#define TAIL(UNS, SOL)                                                                                        \
+    hipLaunchKernelGGL((k_tail<UNS, SOL>), dim3(gh), dim3(1024), 0, h->stream, h->n4, (const float4 *)h->x,     \
+                       (const float4 *)h->xp, (float4 *)h->g, (const float4 *)h->gp, (const float4 *)h->d,  \
+                       (float4 *)h->S, (float4 *)h->Y, h->rows, h->st, T, A, h->part)
+        if (unsort) {
+            if (solo) TAIL(true, true);
+            else TAIL(true, false);
+        } else {
+            if (solo) TAIL(false, true);
+            else TAIL(false, false);
+        }
+#undef TAIL
+        prof_end(h, on, ep);
+        if (!solo) { // energies, Gram rows, g.d, x.x of all ranks: ONE fp64 all-reduce per evaluation
+            on = prof_begin(h, MMX_K_REDUCE, ep);
+            EventPair cep{};
+            const bool con = coll_prof_begin(h, kCollAllreduce, cep);
+            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            prof_end(h, con, cep);
+            hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
+            prof_end(h, on, ep);
+        }
+        return;
+    }
     if (has_nb(h) && !all_pairs(h)) launch_nb_finish(h);
     if (fold == FOLD_NONE) return;
 
-    const int gh = std::min((h->n4 + 255) / 256, 256); // x kHistGroups column groups
     if (fold == FOLD_MIN) {
         // (s, y) of the step this evaluation would accept, its Gram rows, g.d and x.x: before the decision, so that
         // decision and direction coefficients are ONE launch (and, multi-GPU, one all-reduce)
@@ -997,7 +1030,6 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
         prof_end(h, on, ep);
     }
     on = prof_begin(h, MMX_K_REDUCE, ep);
-    const bool solo = !has_comm(h) || h->dd_frozen; // no all-reduce: this handle's sums are all there is
     if (fold == FOLD_MIN) {
         if (solo) {
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
@@ -1166,6 +1198,9 @@ int kernel_error_rc(mmx_handle_s *h) {
     if (ke & KERR_N3_SPIN) what += " k_nb_n3: a wave waited for a work unit or a window flush that never came;";
     if (ke & KERR_N3_ITEMS) what += " k_nb_n3: the work-item list is too short for this cell build;";
     if (ke & KERR_ORDER_DD) what += " cell build of a decomposed rank: a cell holds more than 4096 beads, owned beads and ghosts cannot be kept in separate clusters;";
+    if (ke & KERR_BUILD_WAIT) what += " cell build: a stage of the launch waited for an earlier one that never finished;";
+    if (ke & KERR_BOUNDS) what += " cell build: an offset derived from the cell counters would have left its array, nothing was written there;";
+    if (ke & KERR_TAIL_WAIT) what += " k_tail: the partial sums of a workgroup never arrived at the one that folds them;";
     if ((ke & 0xff) == 0) what += " reported by another rank;";
     return fail(h, MMX_ERR_STATE, "a force kernel could not do its work, the evaluation is void:" + what +
                                   " forces and energies of this call must not be used");
@@ -1534,6 +1569,10 @@ int prepare(mmx_handle_s *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream)); // h->Q is pageable host memory that may change afterwards
     }
     h->dd_rc = MMX_OK;
+    if (h->fsort_dirty && h->fsort) { // see mmx_handle_s::fsort_dirty
+        HIPCHK(h, hipMemsetAsync(h->fsort, 0, sizeof(float) * 3 * (size_t)h->fstride, h->stream));
+        h->fsort_dirty = false;
+    }
     if (use_halo(h)) {
         if (h->world > kDDMaxWorld) return fail(h, MMX_ERR_BAD_ARG, "the ghost-bead halo supports up to 64 ranks");
         if ((rc = dd_alloc(h))) return rc;

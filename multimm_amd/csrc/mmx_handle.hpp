@@ -220,6 +220,13 @@ struct mmx_handle_s {
     int *sbead = nullptr;                        // half-shell kernel: bead id per cluster slot (-1: padding), written with spos4
     float *fsort = nullptr;                      // half-shell kernel: force per cluster slot, SoA [3][fstride], zero between evaluations
     int fstride = 0;
+    bool fsort_dirty = false;                    // a minimization ended abnormally: k_tail only clears the slots of beads the build
+                                                 // binned, so fsort is cleared wholesale before the next call (prepare)
+    int *slot_of = nullptr;                      // [owned beads, local order] cluster slot of the bead (emit_clusters): what k_tail gathers by
+    LaunchSync *sync = nullptr;                  // tickets / stage flags of the launches whose workgroups depend on each other
+    unsigned tail_epoch = 0u;                    // tag of the last k_tail launch's partials (TailArgs::epoch)
+    int fused_tail = 1;                          // option: unsort + history + decision in one launch (k_tail); 0: the separate kernels (A/B)
+    int fused_build = 1;                         // option: scan + bonded pass + fill + order + work items in one launch (k_build); 0: separate (A/B)
     bool nb_lean = false;                        // the lean pair loop applies (default forms, one cutoff): refresh_params
     int n3_long_items = -1;                      // work items of k_nb_n3: -1 by size (kN3LongItemsFrom), 0 short (16 clusters), 1 long (24)
     int n3_cap = 0;                              // LDS force window of k_nb_n3 in clusters (0: not usable on this device)

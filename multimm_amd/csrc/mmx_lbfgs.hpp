@@ -45,12 +45,14 @@ __device__ __forceinline__ void multi_slot_sum(const double *__restrict__ part, 
         const int n = nblk[s];
         const double *p = part + (size_t)s * stride + (size_t)seg * 1024;
         const int m = min(1024, n - seg * 1024);
+        // (all 16 loads issued back to back, whatever m: the slot's row of kPartStride entries is allocated in full, what lies
+        //  beyond its partials is discarded by value -- a load behind `i < m` is a branch and a wait of its own)
+        double pv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[k] = p[lane + 64 * k];
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = lane + 64 * k;
-            v += i < m ? p[i] : 0.0;
-        }
+        for (int k = 0; k < 16; ++k) v += lane + 64 * k < m ? pv[k] : 0.0;
         v = wave_sum(v);
         if (lane == 0) s_task[task] = v;
     }
@@ -71,16 +73,21 @@ template <int NQ>
 __device__ __forceinline__ void rows_load(const double *__restrict__ rows, int nblk, double (&acc)[3]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     acc[0] = acc[1] = acc[2] = 0.0;
+    // (12 loads per lane issued back to back: rows beyond NQ and partials beyond nblk are read -- the buffer is allocated in
+    //  full -- and discarded by value)
+    double pv[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double *p = rows + (size_t)min(wave + 16 * j, NQ - 1) * kPartStride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[j][k] = p[lane + 64 * k];
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = wave + 16 * j;
         if (r < NQ) {
-            const double *p = rows + (size_t)r * kPartStride;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k;
-                acc[j] += i < nblk ? p[i] : 0.0;
-            }
+            for (int k = 0; k < 4; ++k) acc[j] += lane + 64 * k < nblk ? pv[j][k] : 0.0;
         }
     }
 }
@@ -94,6 +101,74 @@ __device__ __forceinline__ void rows_finish(const double (&acc)[3], double *s_ou
         if (r < NQ && lane == 0) s_out[r] = v;
     }
     __syncthreads();
+}
+
+#ifdef MMX_STAGE_TIMING
+// timing build: [workgroup * 4 + {0 start, 1 merge done, 2 loop done, 3 ticket}] of k_tail, [4096 + {0 fence, 1 decided}] of its
+// last workgroup; k_build: see mmx_build.hpp (10 ns ticks)
+__device__ unsigned long long g_stage_t[8192];
+#define STAGE_STAMP(idx)                                                                              \
+    do {                                                                                               \
+        if (threadIdx.x == 0) g_stage_t[(idx)] = wall_clock64();                                       \
+    } while (0)
+#else
+#define STAGE_STAMP(idx) do {} while (0)
+#endif
+// k_tail's partials are TAGGED: a partial travels as two 64-bit words {low half | tag << 32, high half | tag << 32}, tag = the
+// launch's epoch, stored with agent-scope atomic stores; the workgroup that folds them polls the words themselves until every
+// tag is this launch's -- no ticket, no fence, no wait for store acknowledgements on the writers' side, and the fold's loads
+// ARE the poll.  Layout: row r at rows + r * kPartStride (doubles), 16 bytes per workgroup.
+__device__ __forceinline__ void rows_publish(double *__restrict__ rows, int r, int blk, double v, unsigned epoch) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)epoch << 32;
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(rows + (size_t)r * kPartStride) + 2 * blk;
+    __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Same assignment of rows to waves and of partials to lanes, same order of additions as rows_load: the same bits.
+// false: a partial never arrived (bounded spin).
+template <int NQ>
+__device__ __forceinline__ bool rows_poll(const double *__restrict__ rows, int nblk, unsigned epoch, double (&acc)[3],
+                                          const int spin_limit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long w0[3][4], w1[3][4];
+    bool arrived = false;
+    for (int spins = 0; spins <= spin_limit; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned long long *p =
+                reinterpret_cast<const unsigned long long *>(rows + (size_t)min(wave + 16 * j, NQ - 1) * kPartStride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = min(lane + 64 * k, nblk - 1);
+                w0[j][k] = __hip_atomic_load(p + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1[j][k] = __hip_atomic_load(p + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                ok = ok && (unsigned)(w0[j][k] >> 32) == epoch && (unsigned)(w1[j][k] >> 32) == epoch;
+        if (__all(ok)) {
+            arrived = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    acc[0] = acc[1] = acc[2] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = wave + 16 * j;
+        if (r < NQ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = __longlong_as_double((long long)((w0[j][k] & 0xffffffffull) | (w1[j][k] << 32)));
+                acc[j] += lane + 64 * k < nblk ? v : 0.0;
+            }
+        }
+    }
+    return arrived;
 }
 
 // Line-search controller, run by ONE thread after every evaluation on the folded (and, in a multi-GPU
@@ -414,10 +489,13 @@ __global__ __launch_bounds__(1024) void k_controller(const CtlArgs A, const doub
 }
 
 // Minimizer, single GPU: energies + k_history rows folded together, line-search decision, and on acceptance the
-// direction coefficients -- one launch per evaluation.
-__global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
-                                                 const double *__restrict__ rows, MinState *__restrict__ st) {
-    if (st->phase >= PH_DONE) return;
+// direction coefficients.  The work of ONE 1024-thread workgroup: k_decide (a launch of its own), or the workgroup of k_tail
+// that finishes last.
+constexpr int kTailSpinLimit = 1 << 20; // polls of k_tail's folding workgroup before it gives up (a bug, not a state of the data)
+template <bool POLL = false>
+__device__ __forceinline__ void decide_block(const CtlArgs &A, const double *__restrict__ part, int nblk_rows,
+                                             const double *__restrict__ rows, MinState *__restrict__ st,
+                                             const unsigned epoch = 0u, const int spin_limit = kTailSpinLimit) {
     static_assert(MMX_NROWSUM <= 48, "rows_load covers 3 rows per wave");
     __shared__ double s_task[kMaxTasks];
     __shared__ double s_out[P_NSLOTS];
@@ -427,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
     __shared__ int s_accepted;
     __shared__ double s_ys[MMX_M];
     double acc[3];
-    rows_load<MMX_NROWSUM>(rows, nblk_rows, acc); // nblk_rows <= 256 (enqueue_history)
+    if (!POLL) rows_load<MMX_NROWSUM>(rows, nblk_rows, acc); // nblk_rows <= 256 (enqueue_history)
     // the Gram matrix rides in the same latency round as the partials
     const double gval = threadIdx.x < MMX_NBASIS * MMX_NBASIS ? st->gram[threadIdx.x] : 0.0;
     const double yval = threadIdx.x < MMX_M ? st->ys[threadIdx.x] : 0.0;
@@ -435,7 +513,12 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
     multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
     if (threadIdx.x < MMX_NBASIS * MMX_NBASIS) s_G[threadIdx.x] = gval;
     if (threadIdx.x < MMX_M) s_ys[threadIdx.x] = yval;
+    // (k_tail: what the other workgroups of this very launch publish is waited for last -- everything above came from earlier launches)
+    if (POLL && !rows_poll<MMX_NROWSUM>(rows, nblk_rows, epoch, acc, spin_limit) && (threadIdx.x & 63) == 0)
+        atomicOr(&st->kernel_error, (int)KERR_TAIL_WAIT);
+    STAGE_STAMP(4098);
     rows_finish<MMX_NROWSUM>(acc, s_rows); // ends with a barrier: s_G is complete too
+    STAGE_STAMP(4099);
     if (threadIdx.x == 0) {
         if (st->cell_stale && !st->kernel_error) {
             // the kept cell structure was out of date for this evaluation (k_pack): it never happened.  Nothing is decided;
@@ -451,12 +534,19 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
             for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
             dots_from_rows(sums, s_rows);
             controller_decide(st, sums, st->kernel_error != 0);
+            STAGE_STAMP(4100);
             s_accepted = st->accepted;
             if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
+            STAGE_STAMP(4101);
         }
     }
     __syncthreads();
     if (s_accepted && threadIdx.x < MMX_NBASIS * MMX_NBASIS) st->gram[threadIdx.x] = s_G[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
+                                                 const double *__restrict__ rows, MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    decide_block<false>(A, part, nblk_rows, rows, st);
 }
 
 // Entries 0..15 of the all-reduced array of a decomposed run: the P_NSLOTS slot sums, then the flags every rank must see
@@ -492,6 +582,27 @@ __global__ void k_controller_decide(MinState *__restrict__ st) {
     for (int s = 0; s < P_NSLOTS; ++s) sums[s] = st->sums[s];
     controller_decide(st, sums, st->sums[kSumKernelError] > 0.5);
 }
+// (the work of one 1024-thread workgroup: k_reduce_all, or the workgroup of k_tail that finishes last)
+template <bool POLL = false>
+__device__ __forceinline__ void reduce_all_block(const CtlArgs &A, const double *__restrict__ part, int nblk_rows,
+                                                 const double *__restrict__ rows, MinState *__restrict__ st,
+                                                 const unsigned epoch = 0u, const int spin_limit = kTailSpinLimit) {
+    __shared__ double s_task[kMaxTasks];
+    __shared__ double s_out[P_NSLOTS];
+    __shared__ double s_rows[MMX_NROWSUM];
+    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
+    double acc[3];
+    if (!POLL) rows_load<MMX_NROWSUM>(rows, nblk_rows, acc);
+    slot_counts(A, s_n);
+    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
+    if (POLL && !rows_poll<MMX_NROWSUM>(rows, nblk_rows, epoch, acc, spin_limit) && (threadIdx.x & 63) == 0)
+        atomicOr(&st->kernel_error, (int)KERR_TAIL_WAIT);
+    __syncthreads(); // (a time-out just raised is in the flags that go out below)
+    rows_finish<MMX_NROWSUM>(acc, s_rows);
+    // slot 12 of the all-reduced array: "some rank's ghost lists are out of date" (see k_dd_displacement)
+    if (threadIdx.x < 16) st->sums[threadIdx.x] = flag_or_sum(st, s_out, threadIdx.x);
+    if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+}
 __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
                                                      const double *__restrict__ rows, MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) {
@@ -499,18 +610,7 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
         if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
         return;
     }
-    __shared__ double s_task[kMaxTasks];
-    __shared__ double s_out[P_NSLOTS];
-    __shared__ double s_rows[MMX_NROWSUM];
-    __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
-    double acc[3];
-    rows_load<MMX_NROWSUM>(rows, nblk_rows, acc);
-    slot_counts(A, s_n);
-    multi_slot_sum<P_NSLOTS>(part, kPartStride, s_n, s_task, s_first, s_out);
-    rows_finish<MMX_NROWSUM>(acc, s_rows);
-    // slot 12 of the all-reduced array: "some rank's ghost lists are out of date" (see k_dd_displacement)
-    if (threadIdx.x < 16) st->sums[threadIdx.x] = flag_or_sum(st, s_out, threadIdx.x);
-    if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+    reduce_all_block<false>(A, part, nblk_rows, rows, st);
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
@@ -528,6 +628,202 @@ __global__ void k_decide_reduced(MinState *__restrict__ st) {
     dots_from_rows(sums, st->rowsum);
     controller_decide(st, sums, st->sums[kSumKernelError] > 0.5);
     if (st->accepted) coef_decide(st, st->rowsum, st->gram, ysl);
+}
+
+// ---- k_tail: what follows the pair kernel of a minimizer's evaluation, in ONE launch --------------------------------------
+// (1) the half-shell kernel's forces leave their cluster slots: g[li] -= fsort[slot_of[li]] (k_nb_n3_unsort's job -- here only
+//     the slots of real owned beads are visited, through the bead -> slot table the cell build wrote; the padded sweep, its
+//     launch and its pass over g are gone);
+// (2) k_history's pass, with the same summation order (bitwise the same partials): a workgroup of 1024 threads is the four
+//     column groups of k_history on the same 256 float4 -- x, xp, gp and the (merged) gradient are fetched ONCE per workgroup,
+//     one by each group, and handed over in LDS instead of being read by four workgroups each;
+// (3) the workgroup with the highest index folds the partials of all of them -- tagged, so that it can poll the values themselves
+//     (rows_publish / rows_poll) -- and decides: k_decide's work (decomposed ranks: k_reduce_all's, the all-reduce and
+//     k_decide_reduced follow), instead of a launch of one workgroup behind a grid drain.
+struct TailArgs {
+    const int *slot_of; // [n_own] cluster slot of every owned bead, local order (written by emit_clusters)
+    float *fsort;       // [3][fstride] force per cluster slot; zero again afterwards
+    int fstride, n_own;
+    int *n3_queue;      // head of the half-shell kernel's work queue: rewound for the next launch on this cell build
+    unsigned epoch;     // tag of this launch's partials (rows_publish): never 0, different from the previous launch's
+    int spin_limit;     // polls before the folding workgroup gives up (tests inject 0)
+};
+constexpr int kTailKeep = 4; // tiles of a workgroup whose merged gradient stays in LDS between the merge and the history pass
+template <bool UNSORT, bool SOLO>
+__global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict__ x, const float4 *__restrict__ xp,
+                                               float4 *g, const float4 *__restrict__ gp,
+                                               const float4 *__restrict__ d, float4 *__restrict__ S, float4 *__restrict__ Y,
+                                               double *__restrict__ rows, MinState *__restrict__ st, const TailArgs T,
+                                               const CtlArgs A, const double *__restrict__ part) {
+    const int phase = st->phase;
+    if (phase != PH_INIT && phase != PH_LINESEARCH) {
+        if (!SOLO && blockIdx.x == 0) { // keep the collective's input finite (k_reduce_all)
+            if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0;
+            if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
+        }
+        return;
+    }
+    STAGE_STAMP(blockIdx.x * 4);
+    __shared__ float4 s_v[4][256];
+    __shared__ float4 s_g[UNSORT ? kTailKeep : 1][256];
+    __shared__ double s_w[4][MMX_NROWS * 4 * 4];
+    const int slot = st->end;
+    const bool store = phase == PH_LINESEARCH;
+    const int cg = threadIdx.x >> 8, tv = threadIdx.x & 255; // column group (k_history's blockIdx.y), thread of the group
+    const bool last = cg == kHistGroups - 1;
+    double e_gd = 0.0, e_xx = 0.0;
+    const int col0 = cg * 4, ncol = min(4, MMX_NBASIS - col0);
+    // columns of this group; a column that is not a stored vector (s_new, y_new, g, or none) points at x: its load is issued
+    // like the others -- every thread has the same loads in flight, no branch around any of them -- and ignored
+    const float4 *colp[4];
+    int colkind[4]; // 0: stored vector, 1: s_new, 2: y_new, 3: g
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = col0 + k;
+        colp[k] = x;
+        colkind[k] = 3;
+        if (b < MMX_M) {
+            colkind[k] = (store && b == slot) ? 1 : 0;
+            if (colkind[k] == 0) colp[k] = S + (size_t)b * n4;
+        } else if (b < 2 * MMX_M) {
+            colkind[k] = (store && b - MMX_M == slot) ? 2 : 0;
+            if (colkind[k] == 0) colp[k] = Y + (size_t)(b - MMX_M) * n4;
+        }
+    }
+    // the vector this group fetches for all four: x, xp, gp, and the gradient
+    const float4 *const shared_src = cg == 0 ? x : cg == 1 ? xp : cg == 2 ? gp : (const float4 *)g;
+    double acc[MMX_NROWS][4];
+#pragma unroll
+    for (int r = 0; r < MMX_NROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[r][k] = 0.0;
+
+    const int stride = gridDim.x * 256, base0 = blockIdx.x * 256;
+    const int ntile = base0 < n4 ? (n4 - base0 + stride - 1) / stride : 0;
+    // loads of tile t: issued one tile ahead of their use
+    float4 ncv[4], nmine, nD;
+    auto prefetch = [&](int t) {
+        const int ic = min(base0 + t * stride + tv, n4 - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ncv[k] = colp[k][ic];
+        nmine = shared_src[ic]; // (group 3 with UNSORT: taken again below, after the merge)
+        nD = d[ic];
+    };
+    if (ntile > 0) prefetch(0);
+    if (UNSORT) {
+        // ---- the pair forces leave their cluster slots.  All the tiles of the workgroup at once: group q merges tiles q, q + 4, ...
+        for (int t = cg; t < ntile; t += 4) {
+            const int i = base0 + t * stride + tv;
+            if (i < n4) {
+                float4 G = g[i];
+                // flat elements 4i .. 4i+3 = components of beads li0 and li0 + 1
+                const int e0 = 4 * i, li0 = e0 / 3, r = e0 - 3 * li0;
+                const int s0 = li0 < T.n_own ? T.slot_of[li0] : -1;
+                const int s1 = li0 + 1 < T.n_own ? T.slot_of[li0 + 1] : -1;
+                float f[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int q = r + c, nb = q >= 3 ? 1 : 0, comp = q - 3 * nb, sl = nb ? s1 : s0;
+                    f[c] = 0.f;
+                    if (sl >= 0) {
+                        float *p = T.fsort + (size_t)comp * T.fstride + sl;
+                        f[c] = *p;
+                        *p = 0.f;
+                    }
+                }
+                G.x -= f[0];
+                G.y -= f[1];
+                G.z -= f[2];
+                G.w -= f[3];
+                g[i] = G; // the gradient of this evaluation, complete (what the next trial move reads)
+                if (t < kTailKeep) s_g[t][tv] = G;
+            }
+        }
+        if (ntile > kTailKeep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tiles beyond kTailKeep are read back from g by another wave
+        __syncthreads();
+    }
+    STAGE_STAMP(blockIdx.x * 4 + 1);
+    for (int t = 0; t < ntile; ++t) { // (block-uniform trip count: barriers inside)
+        const int i = base0 + t * stride + tv;
+        const bool in = i < n4;
+        float4 cv[4], mine = nmine;
+        const float4 D = nD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = ncv[k];
+        if (UNSORT && last) mine = t < kTailKeep ? s_g[t][tv] : g[min(i, n4 - 1)];
+        if (t + 1 < ntile) prefetch(t + 1);
+        __syncthreads(); // the previous tile has been read
+        s_v[cg][tv] = mine;
+        __syncthreads();
+        const float4 X = s_v[0][tv], XP = s_v[1][tv], GP = s_v[2][tv], G = s_v[3][tv];
+        if (!in) continue; // (after the barriers)
+        float4 sn = make_float4(X.x - XP.x, X.y - XP.y, X.z - XP.z, X.w - XP.w);
+        float4 yn = make_float4(G.x - GP.x, G.y - GP.y, G.z - GP.z, G.w - GP.w);
+        if (!store) {
+            sn = make_float4(0.f, 0.f, 0.f, 0.f);
+            yn = sn;
+        }
+        if (last) {
+            e_gd += ((double)G.x * D.x + (double)G.y * D.y) + ((double)G.z * D.z + (double)G.w * D.w);
+            e_xx += ((double)X.x * X.x + (double)X.y * X.y) + ((double)X.z * X.z + (double)X.w * X.w);
+            if (store) {
+                S[(size_t)slot * n4 + i] = sn;
+                Y[(size_t)slot * n4 + i] = yn;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < ncol) {
+                float4 v;
+                if (colkind[k] == 0) v = cv[k];
+                else if (colkind[k] == 1) v = sn;
+                else if (colkind[k] == 2) v = yn;
+                else v = G;
+                acc[0][k] += (double)(sn.x * v.x + sn.y * v.y) + (double)(sn.z * v.z + sn.w * v.w);
+                acc[1][k] += (double)(yn.x * v.x + yn.y * v.y) + (double)(yn.z * v.z + yn.w * v.w);
+                acc[2][k] += (double)(G.x * v.x + G.y * v.y) + (double)(G.z * v.z + G.w * v.w);
+            }
+        }
+    }
+    STAGE_STAMP(blockIdx.x * 4 + 2);
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3; // wave of the group
+#pragma unroll
+    for (int r = 0; r < MMX_NROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sm = wave_sum(acc[r][k]);
+            if (lane == 0) s_w[cg][(r * 4 + k) * 4 + wave] = sm;
+        }
+    __syncthreads();
+    if (tv < MMX_NROWS * 4) {
+        const int r = tv >> 2, k = tv & 3;
+        if (k < ncol) {
+            const double *q = s_w[cg] + tv * 4;
+            rows_publish(rows, r * MMX_NBASIS + col0 + k, blockIdx.x, (q[0] + q[1]) + (q[2] + q[3]), T.epoch);
+        }
+    }
+    __syncthreads();
+    {
+        const double s1 = wave_sum(e_gd), s2 = wave_sum(e_xx);
+        if (last && lane == 0) {
+            s_w[cg][wave] = s1;
+            s_w[cg][4 + wave] = s2;
+        }
+        __syncthreads();
+        if (last && tv < 2) {
+            const double *q = s_w[cg] + 4 * tv;
+            rows_publish(rows, MMX_ROW_GD + tv, blockIdx.x, (q[0] + q[1]) + (q[2] + q[3]), T.epoch);
+        }
+    }
+    STAGE_STAMP(blockIdx.x * 4 + 3);
+    // ---- the workgroup with the highest index (dispatched last) folds and decides: it polls the tagged partials of the others
+    // (rows_poll); they are independent of it, so it cannot keep any of them from running
+    if (blockIdx.x != gridDim.x - 1) return;
+    STAGE_STAMP(4096);
+    if (threadIdx.x == 0 && T.n3_queue) *T.n3_queue = 0;
+    if (SOLO) decide_block<true>(A, part, (int)gridDim.x, rows, st, T.epoch, T.spin_limit);
+    else reduce_all_block<true>(A, part, (int)gridDim.x, rows, st, T.epoch, T.spin_limit);
+    STAGE_STAMP(4097);
 }
 
 // d = sum_a coef[a] * B_a (with xp <- x, gp <- g) is formed per bead by the next trial move: k_pack<.., DIR> in

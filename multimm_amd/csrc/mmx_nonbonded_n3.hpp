@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
                                                      N3Item *__restrict__ n3_items, int n3_max_items,
                                                      MinState *__restrict__ st, int *__restrict__ count_own = nullptr,
                                                      int *__restrict__ sbead = nullptr, const int n3_long_items = 0,
-                                                     const int slot_cap = 0, const int slot_cells = 0, const int split = 0) {
+                                                     const int slot_cap = 0, const int slot_cells = 0, const int split = 0,
+                                                     int *__restrict__ slot_of = nullptr) {
     if (st->phase >= PH_DONE) return;
     const int n_items_blocks = (int)gridDim.x - n_order; // they come FIRST: dispatched at once, their latency chains
     if ((int)blockIdx.x < n_items_blocks) {              // run beside the cell order instead of behind it
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void k_order_items(const int n_order, const Gr
         return;
     }
     cell_order_block<CHUNK, CAP>((int)blockIdx.x - n_items_blocks, n_order, grid, start, istart, count, perm, items, cstart, pos4,
-                                 spos4, cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, split);
+                                 spos4, cl_lo, cl_hi, own, okeys, biglist, st, count_own, sbead, slot_cap, slot_cells, split, slot_of);
 }
 
 #ifdef MMX_N3_TIMING
