@@ -209,6 +209,44 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_partner(double v) {
     return __hiloint2double(dpp_partner<CTRL>(__double2hiint(v)), dpp_partner<CTRL>(__double2loint(v)));
 }
+// Value of lane i ^ J (J a power of two) without the LDS crossbar.  32 / 16: permlane swaps (see above; the lane's half / row
+// decides which of the two results holds the partner), 8: DPP row_ror:8, 4: row_half_mirror (i -> i ^ 7 within 8 lanes) followed by
+// quad_perm:[3,2,1,0] (i -> i ^ 3), 2 / 1: quad_perm.  Whole waves must call.
+template <int J>
+__device__ __forceinline__ int lane_xor(int v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "power of two below 64");
+    if (J == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+    }
+    if (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+    }
+    if (J == 8) return dpp_partner<0x128>(v);
+    if (J == 4) return dpp_partner<0x1b>(dpp_partner<0x141>(v)); // row_half_mirror, then quad_perm:[3,2,1,0]
+    if (J == 2) return dpp_partner<0x4e>(v);
+    return dpp_partner<0xb1>(v);
+}
+template <int J>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor<J>(__float_as_int(v))); }
+template <int J>
+__device__ __forceinline__ unsigned long long lane_xor(unsigned long long v) {
+    const unsigned lo = (unsigned)lane_xor<J>((int)(unsigned)(v & 0xffffffffull)), hi = (unsigned)lane_xor<J>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// ... with the distance as a run-time value (wave-uniform): the switch folds away where the caller's loop is unrolled
+template <class T>
+__device__ __forceinline__ T lane_xor_rt(T v, int j) {
+    switch (j) {
+    case 32: return lane_xor<32>(v);
+    case 16: return lane_xor<16>(v);
+    case 8: return lane_xor<8>(v);
+    case 4: return lane_xor<4>(v);
+    case 2: return lane_xor<2>(v);
+    default: return lane_xor<1>(v);
+    }
+}
 __device__ __forceinline__ float mmx_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
     MMX_SWAP_STEP_F(mmx_addf, __builtin_amdgcn_permlane32_swap, v);

@@ -38,6 +38,14 @@ __global__ void k(const double *d, const float *f, const int *ii, unsigned long 
     if (__float_as_int(mn) != __float_as_int(mn2)) atomicAdd(bad + 2, 1ull);
     if (__float_as_int(mx) != __float_as_int(mx2)) atomicAdd(bad + 3, 1ull);
     if (im != im2) atomicAdd(bad + 4, 1ull);
+    // lane_xor against __shfl_xor, every distance, 32- and 64-bit
+    const unsigned long long key = ((unsigned long long)(unsigned)ii[i] << 32) | (unsigned)__float_as_int(f[i]);
+    bool okx = true;
+    okx = okx && lane_xor<1>(ii[i]) == __shfl_xor(ii[i], 1, 64) && lane_xor<2>(ii[i]) == __shfl_xor(ii[i], 2, 64);
+    okx = okx && lane_xor<4>(ii[i]) == __shfl_xor(ii[i], 4, 64) && lane_xor<8>(ii[i]) == __shfl_xor(ii[i], 8, 64);
+    okx = okx && lane_xor<16>(ii[i]) == __shfl_xor(ii[i], 16, 64) && lane_xor<32>(ii[i]) == __shfl_xor(ii[i], 32, 64);
+    for (int j = 1; j < 64; j <<= 1) okx = okx && lane_xor_rt(key, j) == __shfl_xor(key, j, 64);
+    if (!okx) atomicAdd(bad + 5, 1ull);
 }
 int main() {
     const int n = 1 << 20;
@@ -52,14 +60,14 @@ int main() {
         ii[i] = rand() - RAND_MAX / 2;
     }
     double *dd; float *df; int *di; unsigned long long *bad;
-    hipMalloc(&dd, n * 8); hipMalloc(&df, n * 4); hipMalloc(&di, n * 4); hipMalloc(&bad, 5 * 8);
+    hipMalloc(&dd, n * 8); hipMalloc(&df, n * 4); hipMalloc(&di, n * 4); hipMalloc(&bad, 6 * 8);
     hipMemcpy(dd, d.data(), n * 8, hipMemcpyHostToDevice);
     hipMemcpy(df, f.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(di, ii.data(), n * 4, hipMemcpyHostToDevice);
-    hipMemset(bad, 0, 5 * 8);
+    hipMemset(bad, 0, 6 * 8);
     hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dd, df, di, bad);
-    unsigned long long h[5];
-    hipMemcpy(h, bad, 5 * 8, hipMemcpyDeviceToHost);
-    printf("lanes that differ: sum f64 %llu, sum f32 %llu, min %llu, max %llu, max int %llu (of %d)\n", h[0], h[1], h[2], h[3], h[4], n);
-    return (h[0] | h[1] | h[2] | h[3] | h[4]) ? 1 : 0;
+    unsigned long long h[6];
+    hipMemcpy(h, bad, 6 * 8, hipMemcpyDeviceToHost);
+    printf("lanes that differ: sum f64 %llu, sum f32 %llu, min %llu, max %llu, max int %llu, lane_xor %llu (of %d)\n", h[0], h[1], h[2], h[3], h[4], h[5], n);
+    return (h[0] | h[1] | h[2] | h[3] | h[4] | h[5]) ? 1 : 0;
 }
