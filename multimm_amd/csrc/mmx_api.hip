@@ -115,6 +115,10 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
             HIPCHK(h, dalloc(&h->slot_of, (size_t)std::max(world > 1 ? h->slice : h->n_own, 1)));
             HIPCHK(h, dalloc(&h->sync, (size_t)1));
+            if (world == 1) {
+                HIPCHK(h, dalloc(&h->dcount, (size_t)2 * ((size_t)h->maxcells + 1)));
+                HIPCHK(h, dalloc(&h->drows, (size_t)4 * kDirectMaxRows));
+            }
             h->n3_cap = n3_configure(kN3MaxCap);
             // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16 (<= n_all /
             // 128 + cells / 16) runs; a run is one record per window pass over its candidates: the rest of n_all / 16 is theirs
@@ -250,7 +254,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync,
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync, (void *)h->dcount, (void *)h->drows,
                     (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
                     (void *)h->md_snap, (void *)h->cell_xref, (void *)h->slotkeys})
         if (p) (void)hipFree(p);
@@ -659,6 +663,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "n3_slice_cap") *value = h->n3_slice_cap;
     else if (k == "cell_slot_halts") *value = (double)h->slot_halts;
     else if (k == "cell_reuse") *value = h->cell_reuse;
+    else if (k == "direct_builds") *value = (double)h->direct_builds; // read-only: full builds that went through k_build_direct
     else if (k == "cell_builds") *value = (double)h->cell_builds;     // read-only: tracked full builds / evaluations on a kept
     else if (k == "cell_reuses") *value = (double)h->cell_reuses;     // structure / evaluations voided because it had gone stale
     else if (k == "cell_stale_halts") *value = (double)h->cell_stale_halts;
@@ -716,6 +721,8 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     int rc = prepare(h);
     if (rc) return rc;
     h->fsort_dirty = true; // until this call has ended in order
+    h->direct_ok = true;
+    if ((rc = direct_reset(h))) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     mmx_stats local;
     std::memset(&local, 0, sizeof(local));
@@ -820,6 +827,12 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
                 h->st_host->cell_stale = 0;
                 if ((rc = ensure_slots(h, true))) return leave(rc);
             }
+            if (h->st_host->halt_reason & 16) { // the grid has outgrown the direct build: the scan-based one for the rest of the call
+                h->direct_ok = false;
+                h->struct_valid = false;
+                h->st_host->cell_stale = 0;
+            }
+            if ((rc = direct_reset(h))) return leave(rc);
             if (h->st_host->halt_reason & 4) { // the kept cell structure went stale: build anew for the repeat, keep structures for half as long
                 h->cell_stale_halts++;
                 h->struct_valid = false;

@@ -5,13 +5,21 @@
 
 namespace mmx {
 
+constexpr int kWaveCellMax = 256; // direct build: cells up to this many beads are sorted by ONE wave in registers; rowbig counts the larger ones
+constexpr int kRowAgg = 8; // rows a workgroup of the pack sums in LDS before it updates the global row totals (cell_rank)
 // Slot of a bead inside its cell: group the lanes of the wave by cell with ballots only (no memory traffic inside
 // the loop), then let the first lane of every group issue its atomicAdd in ONE instruction -- one round trip per
 // wave instead of one per distinct cell (Hilbert-ordered beads: ~3 distinct cells per wave).  Whole wave must call.
 // count_own (decomposed runs): the cell's OWNED beads are counted separately -- they and the ghosts of a cell form
 // separate clusters (cell_scan_block, emit_clusters).
+// rowcl / rowbig (the direct build, mmx_build.hpp): per ROW of the cell grid (row = c / nx), the clusters of 8 its cells need
+// and its cells of more than kWaveCellMax beads, kept current with every increment -- the population goes from `base` to `base + m`, so
+// the row's totals move by the difference of the derived quantities -- which is what lets every workgroup of the build find a
+// cell's place in the cluster list by itself (a prefix over <= 2048 row totals + one row of populations), without a scan pass.
 __device__ __forceinline__ int cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count,
-                                         int *__restrict__ count_own = nullptr, bool owned = true) {
+                                         int *__restrict__ count_own = nullptr, bool owned = true,
+                                         int *__restrict__ rowcl = nullptr, int *__restrict__ rowbig = nullptr, const int nx = 1,
+                                         int *s_rows = nullptr /* LDS [3][kRowAgg]: row (-1: free), clusters, large cells */) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long own_lanes = count_own ? __ballot(todo && owned) : 0ull;
@@ -26,8 +34,33 @@ __device__ __forceinline__ int cell_rank(bool todo, int c, int i, int *__restric
     const int first = todo ? __ffsll((long long)mine) - 1 : lane;
     int base = 0;
     if (todo && lane == first) {
-        base = atomicAdd(&count[c], __popcll(mine));
+        const int m = __popcll(mine);
+        base = atomicAdd(&count[c], m);
         if (count_own && (mine & own_lanes)) atomicAdd(&count_own[c], __popcll(mine & own_lanes));
+        if (rowcl) {
+            const int nc = base + m, dcl = ((nc + 7) >> 3) - ((base + 7) >> 3), dbig = (nc > kWaveCellMax ? 1 : 0) - (base > kWaveCellMax ? 1 : 0);
+            // The rows are few (121 at the densest): straight global atomics put ~80 updates on every address, one after the
+            // other at the memory side (measured: the pack took 27.5 us instead of 13).  A workgroup's 256 chain-consecutive beads
+            // sit in a handful of rows: they are summed in LDS first, one global update per row and workgroup at the end.
+            if (dcl | dbig) {
+                const int row = c / nx;
+                int slot = -1;
+                if (s_rows) {
+                    for (int q = 0; q < kRowAgg && slot < 0; ++q) {
+                        int k = s_rows[q];
+                        if (k == -1) k = atomicCAS(&s_rows[q], -1, row);
+                        if (k == -1 || k == row) slot = q;
+                    }
+                }
+                if (slot >= 0) {
+                    if (dcl) atomicAdd(&s_rows[kRowAgg + slot], dcl);
+                    if (dbig) atomicAdd(&s_rows[2 * kRowAgg + slot], dbig);
+                } else {
+                    if (dcl) atomicAdd(&rowcl[row], dcl);
+                    if (dbig) atomicAdd(&rowbig[row], dbig);
+                }
+            }
+        }
     }
     base = __shfl(base, first, 64);
     const int r = base + __popcll(mine & lt);
@@ -111,9 +144,11 @@ struct RefArgs {
 // write into the cell's slice of the counting sort after the scan: that launch disappears (5 us + a dispatch gap per
 // evaluation).  A cell beyond the table or fuller than cap voids the evaluation (st->cell_stale bit 1: PH_HALT, the host
 // enlarges the table and the evaluation is repeated).
+constexpr int kDirectMaxRows = 2048; // rows (ny * nz) of a grid the direct build handles
 struct SlotArgs {
     unsigned long long *keys;
     int cap, cells;
+    int *rowcl = nullptr, *rowbig = nullptr; // direct build (mmx_build.hpp): per-row totals kept by the pack (cell_rank)
 };
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
@@ -131,6 +166,8 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
     if (st->phase >= PH_DONE) return;
     __shared__ float s_bb[6][4];
     __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
+    __shared__ int s_rows[3 * kRowAgg];
+    if (MOVE && COUNT && threadIdx.x < 3 * kRowAgg) s_rows[threadIdx.x] = threadIdx.x < kRowAgg ? -1 : 0; // (before the barrier below)
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
     float px = 0.f, py = 0.f, pz = 0.f;
     const bool act = i < n_own;
@@ -230,7 +267,11 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
             c = (cz * G.ny + cy) * G.nx + cx;
             cell_of[i] = c;
         }
-        const int r = cell_rank(act, c, i, rank, count);
+        const int r = cell_rank(act, c, i, rank, count, nullptr, true, T.rowcl, T.rowbig, G.nx, (MOVE && T.rowcl) ? s_rows : nullptr);
+        if (T.rowcl && i == 0) stw->n3_items = 0; // (direct build: no scan resets the work-item count the item builders append to)
+        // the direct build reads a row of populations with one lane per cell and keeps the row prefixes in LDS: a grid beyond
+        // that voids the evaluation (the host falls back to the scan-based build for the rest of the call)
+        if (T.rowcl && i == 0 && (G.nx > 64 || G.ny * G.nz > kDirectMaxRows)) atomicOr(&stw->cell_stale, 4);
         if (T.keys && act) {
             if (c < T.cells && r < T.cap)
                 T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, i, false);
@@ -260,6 +301,13 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         float r = s_bb[k][0];
         for (int w = 1; w < 4; ++w) r = k < 3 ? fminf(r, s_bb[k][w]) : fmaxf(r, s_bb[k][w]);
         bbox_part[k * gridDim.x + blockIdx.x] = r;
+    }
+    if (MOVE && COUNT && T.rowcl && threadIdx.x >= 64 && threadIdx.x < 64 + kRowAgg) { // (the barrier above: every wave's updates are in)
+        const int q = threadIdx.x - 64, row = s_rows[q];
+        if (row >= 0) {
+            if (s_rows[kRowAgg + q]) atomicAdd(&T.rowcl[row], s_rows[kRowAgg + q]);
+            if (s_rows[2 * kRowAgg + q]) atomicAdd(&T.rowbig[row], s_rows[2 * kRowAgg + q]);
+        }
     }
 }
 
@@ -518,7 +566,10 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
                                               float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi, int tid,
                                               int nthr, const Own &own,
                                               const unsigned long long *keys = nullptr, int *__restrict__ sbead = nullptr,
-                                              int *__restrict__ slot_of = nullptr) {
+                                              int *__restrict__ slot_of = nullptr, const int cap_slots = 0x7fffffff,
+                                              MinState *__restrict__ st_err = nullptr, const int n_beads = 0x7fffffff) {
+    // cap_slots (a multiple of 8): slots of the cluster list.  Offsets derive from the cell counters; counters that a void
+    // evaluation left behind, or any corruption of them, must end in an error code, never in a store past the arrays
     const int o8 = ((no + 7) >> 3) << 3; // slots of the owned clusters
     const int ncl = cell_clusters(cnt, no);
     for (int e = tid; e < ncl * 8; e += nthr) {
@@ -529,13 +580,21 @@ __device__ __forceinline__ void emit_clusters(int c, int s, int cnt, int no, int
         if (real) {
             // sorted bead id: from the sorted keys still in LDS when the caller has them (no global round trip)
             const int b = keys ? (int)(unsigned)(keys[src] & 0xffffffffull) : perm[s + src];
-            p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
-            bead = b;
+            if ((unsigned)b < (unsigned)n_beads) {
+                p = pos4[b]; // as it is: the pair kernels see the state bit for bit (k_nb_clusters_j)
+                bead = b;
+            } else if (st_err) { // (a key that is no bead: counters and keys of different builds)
+                atomicOr(&st_err->kernel_error, (int)KERR_BOUNDS);
+            }
         }
-        const int lb = real ? own.local(bead) : -1;
+        const int lb = bead >= 0 ? own.local(bead) : -1;
         nown = lb >= 0 ? 1 : 0;
         // slot of entry e: the owned clusters at cb, the ghosts' either right behind them or in their own region
         const size_t sl = (cbg < 0 || e < o8) ? (size_t)cb * 8 + e : (size_t)cbg * 8 + (e - o8);
+        if (sl >= (size_t)cap_slots) { // (whole clusters: the eight lanes of a cluster agree)
+            if (st_err && (e & 7) == 0) atomicOr(&st_err->kernel_error, (int)KERR_BOUNDS);
+            continue;
+        }
         spos4[sl] = p;
         if (sbead) sbead[sl] = bead; // slot -> bead (k_nb_n3_unsort reads 4 bytes per slot, not a float4)
         if (slot_of && lb >= 0) slot_of[lb] = (int)sl; // owned bead (local order) -> slot: what k_tail gathers the pair forces by

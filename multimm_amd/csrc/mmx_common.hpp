@@ -147,6 +147,8 @@ struct MinState {
     int dd_overflow;     // decomposed runs: a ghost list built on the stream outgrew its message (capacity known to the host)
     int cell_stale;      // kept cell structure (mmx_engine.hpp, "cell_reuse"): a bead has moved more than half the skin since it was
                          // binned -- the evaluation is void (PH_HALT, halt_reason bit 2) and is repeated after a full build
+    int ncells_set[2];   // direct build (mmx_build.hpp): cells of the grid each of the two counter sets was last used with (what the
+                         // build that zeroes the set for the next pack has to cover)
     unsigned disp2_bits; // largest squared displacement of a bead from where it was binned, as float bits (non-negative floats
                          // order like unsigned ints), over the evaluations since the host last cleared it
     double fx;      // energy at the last accepted point
@@ -180,6 +182,19 @@ struct LaunchSync {
     int pad[2];
 };
 
+namespace stage_timing_ {}
+#ifdef MMX_STAGE_TIMING
+// timing build (10 ns ticks): [workgroup * 4 + {0 start, 1 merge done, 2 loop done, 3 published}] of k_tail, [4096 ..] its folding
+// workgroup; [4200 ..] k_build_direct: +0..3 workgroup 0 (start, grid, prefix, done), +4..7 the first order workgroup that takes
+// small cells (start, grid, prefix, done), +8..11 the first one that takes large cells, +12..15 item workgroup 1
+__device__ unsigned long long g_stage_t[8192];
+#define STAGE_STAMP(idx)                                                                              \
+    do {                                                                                               \
+        if (threadIdx.x == 0) g_stage_t[(idx)] = wall_clock64();                                       \
+    } while (0)
+#else
+#define STAGE_STAMP(idx) do {} while (0)
+#endif
 // ---- wave helpers ---------------------------------------------------------------------------
 // The xor butterfly (offsets 32, 16, 8, 4, 2, 1: every lane ends up with the wave's total, association fixed) WITHOUT the LDS
 // crossbar: __shfl_xor is a ds_bpermute per 32 bits and step -- ~100 cycles each, a dependent chain of six (twelve for a double)
@@ -307,6 +322,16 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_partner<0x124>(v));
     v = fmaxf(v, dpp_partner<0x4e>(v));
     v = fmaxf(v, dpp_partner<0xb1>(v));
+    return v;
+}
+__device__ __forceinline__ int mmx_addi(int a, int b) { return a + b; }
+__device__ __forceinline__ int wave_sum_i(int v) {
+    MMX_SWAP_STEP_I(mmx_addi, __builtin_amdgcn_permlane32_swap, v);
+    MMX_SWAP_STEP_I(mmx_addi, __builtin_amdgcn_permlane16_swap, v);
+    v += dpp_partner<0x128>(v);
+    v += dpp_partner<0x124>(v);
+    v += dpp_partner<0x4e>(v);
+    v += dpp_partner<0xb1>(v);
     return v;
 }
 __device__ __forceinline__ int wave_max_i(int v) {

@@ -728,6 +728,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     }
     if (!tracked) h->struct_valid = false; // whatever is built below is not tracked by cell_xref
     h->slots_now = false;
+    bool direct = false;
     if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
         MdParams M = h->md;
         M.step_lo = (uint32_t)h->md_step;
@@ -755,10 +756,16 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             const RefArgs R{h->cell_xref, tracked ? (h->struct_valid ? 2 : 3) : 0, 0.f};
             // sort keys straight into the slot table: no k_cell_fill below
             h->slots_now = h->cell_slots && h->slotkeys && h->slot_cap > 0 && !h->capturing && !h->use_graph;
-            const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells};
+            // the direct build (mmx_build.hpp): the pack also keeps the per-row totals, in the counter set of this build's parity
+            direct = h->slots_now && h->fused_build && h->direct_ok && h->dcount && bonded && h->fused_bonded && h->overlap_bonded;
+            const int par = h->build_idx & 1;
+            int *const dcnt = h->dcount + (size_t)par * ((size_t)h->maxcells + 1);
+            int *const drcl = h->drows + (size_t)par * 2 * kDirectMaxRows, *const drbig = drcl + kDirectMaxRows;
+            const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells, direct ? drcl : nullptr,
+                             direct ? drbig : nullptr};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
-                               h->count, dir_args(h), R, h->st, T);
+                               direct ? dcnt : h->count, dir_args(h), R, h->st, T);
             if (tracked) {
                 h->struct_valid = true;
                 h->struct_evals = 1;
@@ -779,6 +786,93 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
                            h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr, (int *)nullptr,
                            (int *)nullptr, (int *)nullptr, DirArgs{}, RefArgs{nullptr, 0, 0.f}, (MinState *)nullptr,
                            SlotArgs{nullptr, 0, 0}, ddg, ddo);
+    if (direct) { // ONE launch: bonded pass || in-cell order || work items, every workgroup finding its offsets by itself
+        const float hm = hmin_of(h);
+        const int par = h->build_idx & 1;
+        GridParams *cur = h->grid + par, *next = h->grid + (par ^ 1);
+        h->grid_factor[par ^ 1] = edge_factor(h); // the grid this build lays out for the next one
+        h->n3_build = use_n3(h);
+        const bool small_cells = h->last_max_per_cell > 0 && h->last_max_per_cell <= 640;
+        const int nvb = grid_beads(h->n_own);
+        const int nib = h->n3_build ? kN3ItemBlocks : 1; // (workgroup 0 publishes the totals and the next grid either way)
+        // ONE round of workgroups: every workgroup of the launch pays the row-prefix prologue (~2 us), so the launch is sized to what
+        // is resident at once -- the bonded pass in half as many workgroups as it has virtual blocks, the rest of the slots order
+        // cells (a wave per cell: four cells in flight per workgroup)
+        const int vi = (small_cells ? 0 : 2) + (h->n3_build ? 1 : 0);
+        if (h->direct_slots[vi] <= 0) {
+            int per_cu = 0;
+            hipError_t oe = hipErrorUnknown;
+            switch (vi) {
+            case 0: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, false>, 256, 0); break;
+            case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, true>, 256, 0); break;
+            case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, false>, 256, 0); break;
+            default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, true>, 256, 0); break;
+            }
+            if (oe != hipSuccess || per_cu <= 0) {
+                (void)hipGetLastError();
+                per_cu = 3;
+            }
+            h->direct_slots[vi] = per_cu * std::max(h->n_cus, 1);
+        }
+        const int nbr = (nvb + 1) / 2;
+        const int go = std::max(256, std::min(2048, h->direct_slots[vi] - nib - nbr));
+        const size_t cset = (size_t)h->maxcells + 1;
+        const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+        const bool loops_on = h->n_rows > 0 && h->lstart;
+        DirectArgs D{};
+        D.grid = cur;
+        D.grid_next = next;
+        D.parity = par;
+        D.bbox_part = h->bbox_part;
+        D.nblk_bbox = gb;
+        D.hmin = hm;
+        D.maxcells = h->maxcells;
+        D.count = h->dcount + (size_t)par * cset;
+        D.rowcl = h->drows + (size_t)par * 2 * kDirectMaxRows;
+        D.rowbig = D.rowcl + kDirectMaxRows;
+        D.count_zero = h->dcount + (size_t)(par ^ 1) * cset;
+        D.rowcl_zero = h->drows + (size_t)(par ^ 1) * 2 * kDirectMaxRows;
+        D.rowbig_zero = D.rowcl_zero + kDirectMaxRows;
+        D.keys = h->slotkeys;
+        D.slot_cap = h->slot_cap;
+        D.slot_cells = h->slot_cells;
+        D.pos4 = h->pos4;
+        D.spos4 = h->spos4;
+        D.cl_lo = h->cl_lo;
+        D.cstart = h->cstart;
+        D.sbead = h->sbead;
+        D.slot_of = h->slot_of;
+        D.cap_clusters = h->n_all;
+        D.n_beads = h->n;
+        D.n3_items = h->n3_items;
+        D.n3_max_items = (h->inject_fault & 2) ? 1 : h->n3_max_items;
+        D.n3_flags = (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) |
+                     (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8);
+        D.n_items_blocks = nib;
+        D.n_bonded_blocks = nbr;
+        D.n_order = go;
+        const BondedArgs BA{bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part,
+                            h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb};
+        const dim3 gd(nib + nbr + go);
+#define BUILD_DIRECT(CAPV, N3V) hipLaunchKernelGGL((k_build_direct<kChunk, CAPV, N3V>), gd, dim3(256), 0, h->stream, D, h->st, h->P, BA)
+        if (small_cells) {
+            if (h->n3_build) BUILD_DIRECT(1024, true);
+            else BUILD_DIRECT(1024, false);
+        } else {
+            if (h->n3_build) BUILD_DIRECT(4096, true);
+            else BUILD_DIRECT(4096, false);
+        }
+#undef BUILD_DIRECT
+        enqueue_bonded(h, *bonded, true); // (bookkeeping of the pass that rode along + the chromosomal blocks)
+        h->gcur = cur;
+        h->build_idx++;
+        h->grid_ready = true;
+        h->last_build_direct = true;
+        h->last_direct_parity = par;
+        h->direct_builds++;
+        return;
+    }
+    h->last_build_direct = false;
     // dd_frozen (measurement: scripts/dd_projection.py): no collective is issued -- the ghost lists and the ghost positions
     // last received stay, so one rank's kernels can be timed alone on exactly the beads it holds in a real run
     if (redecomp && use_halo(h) && !h->dd_frozen) { // fresh ghost lists from the positions the pack has just written
@@ -1124,7 +1218,20 @@ int push_state(mmx_handle_s *h) {
     HIPCHK(h, hipMemcpyAsync(h->st, h->st_host, sizeof(MinState), hipMemcpyHostToDevice, h->stream));
     return MMX_OK;
 }
+// Both counter sets of the direct build back to zero (start of a call, repeat of a halted evaluation: the evaluations the device
+// skipped have advanced the host's build parity, so which set the next pack counts into is not the one the last build zeroed)
+int direct_reset(mmx_handle_s *h) {
+    if (!h->dcount) return MMX_OK;
+    HIPCHK(h, hipMemsetAsync(h->dcount, 0, sizeof(int) * 2 * ((size_t)h->maxcells + 1), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->drows, 0, sizeof(int) * 4 * kDirectMaxRows, h->stream));
+    h->last_build_direct = false;
+    return MMX_OK;
+}
+
 int pull_state(mmx_handle_s *h) {
+    if (h->last_build_direct) // the fullest cell of the last build (the scan-based build publishes it itself)
+        hipLaunchKernelGGL(k_poll_stats, dim3(1), dim3(256), 0, h->stream,
+                           h->dcount + (size_t)h->last_direct_parity * ((size_t)h->maxcells + 1), h->gcur, h->st);
     HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
     const bool halo = use_halo(h) && h->dd_lists_valid && h->dd_cnt_host;
     if (halo)

@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/mmx.h"
 #include "mmx_bonded.hpp"
+#include "mmx_build.hpp"
 #include "mmx_cells.hpp"
 #include "mmx_common.hpp"
 #include "mmx_dd.hpp"
@@ -226,6 +227,13 @@ struct mmx_handle_s {
     LaunchSync *sync = nullptr;                  // tickets / stage flags of the launches whose workgroups depend on each other
     unsigned tail_epoch = 0u;                    // tag of the last k_tail launch's partials (TailArgs::epoch)
     int fused_tail = 1;                          // option: unsort + history + decision in one launch (k_tail); 0: the separate kernels (A/B)
+    int *dcount = nullptr;                       // direct build: two sets of cell populations [2][maxcells + 1] ...
+    int *drows = nullptr;                        // ... and of row totals [2][2][kDirectMaxRows] (clusters, large cells), alternating with the build's parity
+    int direct_slots[4] = {0, 0, 0, 0};          // workgroups of k_build_direct<CAP, N3> resident at once (occupancy x CUs), per instance
+    bool direct_ok = true;                       // this call's grids have fitted the direct build so far (nx <= 64, rows <= kDirectMaxRows)
+    bool last_build_direct = false;              // the last enqueued full build was a direct one (the polls fetch its fullest cell: k_poll_stats)
+    int last_direct_parity = 0;
+    long long direct_builds = 0;                 // statistics
     int fused_build = 1;                         // option: scan + bonded pass + fill + order + work items in one launch (k_build); 0: separate (A/B)
     bool nb_lean = false;                        // the lean pair loop applies (default forms, one cutoff): refresh_params
     int n3_long_items = -1;                      // work items of k_nb_n3: -1 by size (kN3LongItemsFrom), 0 short (16 clusters), 1 long (24)

@@ -103,17 +103,6 @@ __device__ __forceinline__ void rows_finish(const double (&acc)[3], double *s_ou
     __syncthreads();
 }
 
-#ifdef MMX_STAGE_TIMING
-// timing build: [workgroup * 4 + {0 start, 1 merge done, 2 loop done, 3 ticket}] of k_tail, [4096 + {0 fence, 1 decided}] of its
-// last workgroup; k_build: see mmx_build.hpp (10 ns ticks)
-__device__ unsigned long long g_stage_t[8192];
-#define STAGE_STAMP(idx)                                                                              \
-    do {                                                                                               \
-        if (threadIdx.x == 0) g_stage_t[(idx)] = wall_clock64();                                       \
-    } while (0)
-#else
-#define STAGE_STAMP(idx) do {} while (0)
-#endif
 // k_tail's partials are TAGGED: a partial travels as two 64-bit words {low half | tag << 32, high half | tag << 32}, tag = the
 // launch's epoch, stored with agent-scope atomic stores; the workgroup that folds them polls the words themselves until every
 // tag is this launch's -- no ticket, no fence, no wait for store acknowledgements on the writers' side, and the fold's loads
@@ -524,7 +513,7 @@ __device__ __forceinline__ void decide_block(const CtlArgs &A, const double *__r
             // the kept cell structure was out of date for this evaluation (k_pack): it never happened.  Nothing is decided;
             // every kernel of the evaluations already in the stream returns at once, the host builds anew and repeats it.
             st->halt_phase = st->phase;
-            st->halt_reason = ((st->cell_stale & 1) ? 4 : 0) | ((st->cell_stale & 2) ? 8 : 0); // stale structure / slot table too small
+            st->halt_reason = ((st->cell_stale & 1) ? 4 : 0) | ((st->cell_stale & 2) ? 8 : 0) | ((st->cell_stale & 4) ? 16 : 0); // stale structure / slot table too small / grid beyond the direct build
             st->phase = PH_HALT;
             st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
             s_accepted = 0;

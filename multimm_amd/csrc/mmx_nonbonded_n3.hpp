@@ -207,13 +207,13 @@ __device__ __forceinline__ N3Cell n3_cell(const N3ItemShape S, const int *__rest
     return C;
 }
 
-// `bid` of `nblk` workgroups of 256 threads
-__device__ __forceinline__ void n3_items_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
-                                               const int *__restrict__ cstart, N3Item *__restrict__ items, int max_items,
-                                               MinState *__restrict__ st, const int long_items,
-                                               const int *__restrict__ gstart = nullptr, const bool pass_records = true,
-                                               const int slice_cap = kN3MaxCap) {
-    const GridParams G = *grid;
+// `bid` of `nblk` workgroups of 256 threads.  row_setup(row, y, z, R): fills the N3Row of grid row `row` -- where the cluster
+// offsets of its five (+ nine) candidate rows are found: the scan's cstart array (n3_items_block), or offsets the wave itself
+// derives from the populations (the direct build, mmx_build.hpp).
+template <class RowSetup>
+__device__ __forceinline__ void n3_items_rows(const int bid, const int nblk, const GridParams &G, N3Item *__restrict__ items,
+                                              int max_items, MinState *__restrict__ st, const int long_items,
+                                              const bool pass_records, const int slice_cap, RowSetup row_setup) {
     const N3ItemShape S = n3_item_shape(long_items);
     const int nrows = G.ny * G.nz, nx = G.nx;
     // (the wave index in a scalar register: everything that depends on the row only -- N3Row -- then lives in SGPRs; this
@@ -221,21 +221,9 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int row = bid * 4 + wave; row < nrows; row += nblk * 4) {
         N3Row R;
-        R.cstart = cstart;
-        R.nx = nx;
         const int y = row % G.ny, z = row / G.ny;
-        R.gstart = gstart;
-        R.gbase = gstart ? st->n_clusters_own : 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
-            R.gb[r] = (gstart && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) ? (zz * G.ny + yy) * nx : -1;
-        }
-        R.base[0] = row * nx;
-        R.base[1] = y + 1 < G.ny ? (row + 1) * nx : -1;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-            R.base[3 + dy] = (z + 1 < G.nz && y + dy >= 0 && y + dy < G.ny) ? (row + G.ny + dy) * nx : -1;
+        row_setup(row, y, z, R);
+        const int *const cstart = R.cstart;
         const int *cs = cstart + R.base[0];
         const int c_hi = cs[nx];
         if (c_hi == cs[0]) continue; // empty row
@@ -313,6 +301,33 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
             }
         }
     }
+}
+
+__device__ __forceinline__ void n3_items_block(const int bid, const int nblk, const GridParams *__restrict__ grid,
+                                               const int *__restrict__ cstart, N3Item *__restrict__ items, int max_items,
+                                               MinState *__restrict__ st, const int long_items,
+                                               const int *__restrict__ gstart = nullptr, const bool pass_records = true,
+                                               const int slice_cap = kN3MaxCap) {
+    const GridParams G = *grid;
+    const int gbase = gstart ? st->n_clusters_own : 0;
+    n3_items_rows(bid, nblk, G, items, max_items, st, long_items, pass_records, slice_cap,
+                  [&](int row, int y, int z, N3Row &R) {
+                      const int nx = G.nx;
+                      R.cstart = cstart;
+                      R.nx = nx;
+                      R.gstart = gstart;
+                      R.gbase = gbase;
+#pragma unroll
+                      for (int r = 0; r < 9; ++r) {
+                          const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
+                          R.gb[r] = (gstart && yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) ? (zz * G.ny + yy) * nx : -1;
+                      }
+                      R.base[0] = row * nx;
+                      R.base[1] = y + 1 < G.ny ? (row + 1) * nx : -1;
+#pragma unroll
+                      for (int dy = -1; dy <= 1; ++dy)
+                          R.base[3 + dy] = (z + 1 < G.nz && y + dy >= 0 && y + dy < G.ny) ? (row + G.ny + dy) * nx : -1;
+                  });
 }
 
 // The item builder needs the scan's cluster offsets only, the in-cell ordering needs nothing of the items: both run in

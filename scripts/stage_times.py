@@ -26,4 +26,9 @@ print(f"  folding workgroup: own partials out {us(t[4096]):6.2f}  all partials i
       f"line search decided {us(t[4100]):6.2f}  coefficients {us(t[4101]):6.2f}  done {us(t[4097]):6.2f}")
 if t[4200] > 0:
     b = t[4200:4200 + 16]
-    print("  k_build stamps (us from ticket 0's start):", [round((int(v) - int(b[0])) / 100.0, 2) if v else None for v in b])
+    f = lambda q: [round((int(v) - int(b[0])) / 100.0, 2) if v else None for v in b[q:q + 4]]
+    print("  k_build_direct (us from workgroup 0's start; start / grid read / row prefix / done):")
+    print("    workgroup 0 (totals, next grid, items)", f(0))
+    print("    first order workgroup, small cells    ", f(4))
+    print("    first order workgroup, large cells    ", f(8))
+    print("    item workgroup 1                      ", f(12))
