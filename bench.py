@@ -13,7 +13,10 @@ over a synthetic Hilbert-curve-initialised bead system.  N = 1: BASELINE config 
 beads, GW preset = EV + compartment blocks + container + lamina + bonds + angles + loops).  N > 1:
 BASELINE config 4, one independent genome-wide replica per GPU with seeds 0..N-1 (the reference's
 ensemble loop, run.py:471-485, is embarrassingly parallel): no data-path collective, "weak" scaling.
-`value` is the whole-job rate: total iterations of all ranks / max-over-ranks wall time.  At N > 1 the same JSON line
+`value` is the whole-job rate: total iterations of all ranks / max-over-ranks wall time.  Every line also carries north_star's
+STRONG-scaling curve as top-level keys `strong_1m_*` (gw_1m, ONE system on the N GPUs of the run: iterations/s, speed-up and
+parallel efficiency against one GPU, ranks RCCL saw; at N = 1 one GPU minimizing gw_1m alone): the N = 1, 2, 4, 8 lines of a
+scaling run form the curve by themselves.  At N > 1 the same JSON line
 also carries a `dd` object: BASELINE config 5, ONE gw_1m system decomposed over the N GPUs (ghost-bead halo exchange +
 one all-reduce per evaluation on RCCL), with its iterations/s, bytes exchanged per evaluation and parallel efficiency
 against one GPU minimizing the same system (never part of `value`).
@@ -70,7 +73,7 @@ def parse_args():
                     help="what `value` is at N > 1: 'ensemble' = one gw_200k replica per GPU (config 4, weak scaling, no "
                          "collective; the default, with the gw_1m decomposed run reported beside it as the `dd` object); "
                          "'dd' = the timed headline itself is ONE system decomposed over the GPUs (config 5, RCCL)")
-    ap.add_argument("--no-dd-leg", action="store_true", help="N > 1, ensemble mode: skip the gw_1m decomposed leg")
+    ap.add_argument("--no-dd-leg", action="store_true", help="skip the gw_1m strong-scaling leg (N > 1: the decomposed run beside the ensemble; N = 1: one GPU minimizing gw_1m)")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="extra leg at N=1 (never part of `value`, off by default so that a profile of the default "
                          "command contains the timed minimization only): aggregate rate of this many replicas sharing "
@@ -214,6 +217,10 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
         progress["stage"] = name
         return name
     try:
+        if os.environ.get("MMX_BENCH_INJECT_DD_STALL"):  # tests / rehearsals of the watchdog: a leg that never comes back
+            stage = at("injected stall")
+            while True:
+                time.sleep(1.0)
         system = synthetic_system("gw_1m", seed=0, NB_CUTOFF=args.cutoff)
         out["n_beads"] = system.n_beads
         eng = engine_for(system, device=local_rank, rank=rank, world=world)
@@ -279,6 +286,78 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
     except Exception as exc:  # noqa: BLE001 -- the headline line must survive a failing extra leg
         out["error"] = f"{stage}: {exc!r}"
     return out
+
+
+STRONG_KEYS = ("strong_1m_iters_per_s", "strong_1m_single_gpu_iters_per_s", "strong_1m_speedup", "strong_1m_parallel_efficiency",
+               "strong_1m_ranks_rccl_saw", "strong_1m_critical_path_us")
+
+
+def hoist_strong(out: dict, leg: dict | None, world: int) -> None:
+    """north_star's strong-scaling curve as TOP-LEVEL keys of the line: gw_1m iterations/s of ONE system on the N GPUs of
+    this run (N = 1: one GPU minimizing it alone), speed-up and parallel efficiency against one GPU, the ranks RCCL saw.
+    The N = 1, 2, 4, 8 lines of a scaling run then form the curve by themselves.  None: not measured (the reason is in
+    `dd` / `strong_1m_note`)."""
+    leg = leg or {}
+    out["strong_1m_iters_per_s"] = leg.get("value")
+    out["strong_1m_single_gpu_iters_per_s"] = leg.get("single_gpu_iters_per_s")
+    out["strong_1m_speedup"] = leg.get("speedup")
+    out["strong_1m_parallel_efficiency"] = leg.get("parallel_efficiency")
+    out["strong_1m_ranks_rccl_saw"] = leg.get("ranks_rccl_saw", world if leg.get("value") else None)
+    out["strong_1m_critical_path_us"] = leg.get("critical_path_us")
+    if leg.get("error"):
+        out["strong_1m_note"] = leg["error"]
+
+
+def guarded_leg(leg_fn, timeout_s: float, rank: int, world: int, out: dict, exit_fn=os._exit, emit_fn=None):
+    """Runs the decomposed leg under a watchdog.  A leg that does not come back within `timeout_s` costs the `dd` object, not
+    the line: rank 0 prints the line -- headline complete, the stage the leg was stuck in spelled out, the strong_1m_* keys
+    None -- and then EVERY rank leaves with exit status 3: a rank hung in a collective holds its GPU, the launcher and the
+    driver must see the job as failed (os._exit: a process stuck inside RCCL does not return)."""
+    import threading
+    progress = {"stage": "setup"}
+    finished = threading.Event()
+    emit_fn = emit_fn or emit
+
+    def watchdog():
+        if finished.wait(timeout_s):
+            return
+        if rank == 0:
+            leg = {"workload": "gw_1m", "mode": "dd", "ranks": world,
+                   "error": f"no result after {timeout_s:.0f} s (stage: {progress['stage']}); leg abandoned, exit status 3"}
+            out["dd"] = leg
+            hoist_strong(out, leg, world)
+            emit_fn(out)
+        else:
+            time.sleep(3.0)
+        exit_fn(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    leg = leg_fn(progress)
+    finished.set()
+    return leg
+
+
+def strong_single_gpu(args, device: int) -> dict:
+    """N = 1 point of the strong-scaling curve: gw_1m on this one GPU, same warm-up / steps as the headline, outside the timed
+    region.  Skipped under rocprofv3 (its kernels carry the same names as the timed workload's and would mix into the kernel
+    statistics of the profile)."""
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    if "rocprof" in preload.lower():
+        return {"error": "skipped under rocprofv3: the gw_1m kernels would mix into the kernel statistics of the timed workload"}
+    try:
+        from multimm_amd import synthetic_system
+        from multimm_amd.engine import engine_for
+        system = synthetic_system("gw_1m", seed=0, NB_CUTOFF=args.cutoff)
+        with engine_for(system, device=device) as e1:
+            if args.warmup > 0:
+                e1.minimize(tolerance=0.0, max_iters=args.warmup)
+            t0 = time.perf_counter()
+            s1 = e1.minimize(tolerance=0.0, max_iters=args.steps)
+            d1 = time.perf_counter() - t0
+        v = s1.iterations / d1
+        return {"value": v, "single_gpu_iters_per_s": v, "speedup": 1.0, "parallel_efficiency": 1.0, "ranks_rccl_saw": 1,
+                "iterations": s1.iterations, "n_beads": system.n_beads}
+    except Exception as exc:  # noqa: BLE001 -- never let the extra leg break the bench line
+        return {"error": repr(exc)}
 
 
 _JSON_FD = None
@@ -555,30 +634,19 @@ def main():
         except Exception as exc:  # noqa: BLE001
             out["truncation"] = {"error": repr(exc)}
     if world > 1 and not dd and not args.no_dd_leg:  # every rank takes part; rank 0 carries the result
-        # The RCCL path of the decomposed run has never met more than one rank on hardware: a watchdog
-        # makes sure that a leg which does not come back costs the `dd` object, not the line.
-        import threading
-        progress = {"stage": "setup"}
-        finished = threading.Event()
-
-        def watchdog():
-            if finished.wait(args.dd_timeout):
-                return
-            if rank == 0:
-                out["dd"] = {"workload": "gw_1m", "mode": "dd", "ranks": world,
-                             "error": f"no result after {args.dd_timeout:.0f} s (stage: {progress['stage']}); leg abandoned"}
-                emit(out)
-            else:
-                time.sleep(3.0)
-            # The headline of this run is complete and on stdout; the hung leg is an auxiliary measurement whose failure is
-            # spelled out in the line itself.  Exit status 0 on every rank, so that the launcher does not report the whole
-            # job -- and with it the headline -- as failed; os._exit because a process stuck in a collective does not return.
-            os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        leg = dd_leg(args, rank, world, local_rank, tdev, barrier, progress)
-        finished.set()
+        # The RCCL path of the decomposed run has never met more than one rank on hardware: a watchdog makes sure
+        # that a leg which does not come back costs the `dd` object, not the line -- and ends the job with exit status 3.
+        leg = guarded_leg(lambda progress: dd_leg(args, rank, world, local_rank, tdev, barrier, progress), args.dd_timeout,
+                          rank, world, out if rank == 0 else {})
         if rank == 0:
             out["dd"] = leg
+            hoist_strong(out, leg, world)
+    elif rank == 0 and dd:  # --mode dd: the headline itself is the decomposed run of whatever workload was asked for
+        hoist_strong(out, {"value": out["value"], "ranks_rccl_saw": world} if args.workload == "gw_1m" else None, world)
+    elif rank == 0 and n_gpus == 1 and not args.no_dd_leg:
+        hoist_strong(out, strong_single_gpu(args, local_rank), 1)
+    elif rank == 0:
+        hoist_strong(out, None, world)
     if rank == 0:
         if n_gpus == 1 and args.replicas_per_gpu > 1:
             out["replicas_per_gpu"] = replicas_per_gpu_leg(args.workload, args.n_beads, args.cutoff, local_rank,

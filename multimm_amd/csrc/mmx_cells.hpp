@@ -149,6 +149,7 @@ struct SlotArgs {
     unsigned long long *keys;
     int cap, cells;
     int *rowcl = nullptr, *rowbig = nullptr; // direct build (mmx_build.hpp): per-row totals kept by the pack (cell_rank)
+    int force_void = 0;                      // tests (inject_fault bit 6): behave as if the grid were beyond the direct build
 };
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         if (T.rowcl && i == 0) stw->n3_items = 0; // (direct build: no scan resets the work-item count the item builders append to)
         // the direct build reads a row of populations with one lane per cell and keeps the row prefixes in LDS: a grid beyond
         // that voids the evaluation (the host falls back to the scan-based build for the rest of the call)
-        if (T.rowcl && i == 0 && (G.nx > 64 || G.ny * G.nz > kDirectMaxRows)) atomicOr(&stw->cell_stale, 4);
+        if (T.rowcl && i == 0 && (G.nx > 64 || G.ny * G.nz > kDirectMaxRows || T.force_void)) atomicOr(&stw->cell_stale, 4);
         if (T.keys && act) {
             if (c < T.cells && r < T.cap)
                 T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, i, false);

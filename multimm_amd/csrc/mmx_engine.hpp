@@ -69,8 +69,8 @@ void refresh_params(mmx_handle_s *h) {
     P.own_lo = h->own_lo;
     P.n_own = h->n_own;
     P.nseg = h->nseg;
-    P.seg_own = h->d_seg_own;     // nullptr while the ownership is the initial contiguous one
-    P.seg_local = h->d_seg_local;
+    P.seg_own = h->seg_owner.empty() ? nullptr : h->d_seg_own;     // nullptr while the ownership is the initial contiguous one
+    P.seg_local = h->seg_owner.empty() ? nullptr : h->d_seg_local;
     const float inf = std::numeric_limits<float>::infinity();
     P.ev_rc2 = (P.use_ev && h->ev_cut > 0.f) ? h->ev_cut * h->ev_cut : inf;
     P.g_rc2 = (P.use_gauss && h->g_cut > 0.f) ? h->g_cut * h->g_cut : inf;
@@ -164,7 +164,10 @@ bool use_n3(const mmx_handle_s *h) {
 int grid_beads(int n) { return std::min((n + 255) / 256, 1024); }
 
 // ---- ownership (decomposed runs: segments of kSeg beads, see Own in mmx_common.hpp) ----------------------------
-Own own_of(const mmx_handle_s *h) { return Own{h->own_lo, h->n_own, h->nseg, h->d_seg_own, h->d_seg_local}; }
+Own own_of(const mmx_handle_s *h) {
+    const bool tables = !h->seg_owner.empty(); // (the device tables may be allocated ahead of their first use: dd_reassign)
+    return Own{h->own_lo, h->n_own, h->nseg, tables ? h->d_seg_own : nullptr, tables ? h->d_seg_local : nullptr};
+}
 // rank that owns global bead b
 int owner_of(const mmx_handle_s *h, int b) {
     if (h->world == 1) return 0;
@@ -762,7 +765,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             int *const dcnt = h->dcount + (size_t)par * ((size_t)h->maxcells + 1);
             int *const drcl = h->drows + (size_t)par * 2 * kDirectMaxRows, *const drbig = drcl + kDirectMaxRows;
             const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells, direct ? drcl : nullptr,
-                             direct ? drbig : nullptr};
+                             direct ? drbig : nullptr, (h->inject_fault & 64) ? 1 : 0};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
                                direct ? dcnt : h->count, dir_args(h), R, h->st, T);
@@ -1524,10 +1527,17 @@ int dd_reassign(mmx_handle_s *h, bool &changed, double min_moved_fraction = 0.02
     if (!use_halo(h) || h->seg_per <= 0) return MMX_OK;
     h->dd_reassign_attempts++;
     const int W = h->world, SP = h->seg_per, NS = h->nseg;
+    // (every allocation of the call before its first collective: a rank that cannot allocate fails here, where its peers are not
+    //  yet waiting for it inside one)
     if (!h->seg_cent) {
         HIPCHK(h, dalloc(&h->seg_cent, (size_t)W * SP));
         HIPCHK(h, hipHostMalloc((void **)&h->seg_cent_host, sizeof(float4) * (size_t)W * SP, hipHostMallocDefault));
         HIPCHK(h, dalloc(&h->d_mig_src, (size_t)SP));
+    }
+    if (!h->mig) HIPCHK(h, dalloc(&h->mig, (size_t)3 * h->slice * h->world));
+    if (!h->d_seg_own) {
+        HIPCHK(h, dalloc(&h->d_seg_own, (size_t)SP));
+        HIPCHK(h, dalloc(&h->d_seg_local, (size_t)NS));
     }
     // 1. centroids of the owned segments -> everybody
     HIPCHK(h, hipMemsetAsync(h->seg_cent + (size_t)h->rank * SP, 0, sizeof(float4) * SP, h->stream));
@@ -1614,9 +1624,17 @@ int dd_reassign(mmx_handle_s *h, bool &changed, double min_moved_fraction = 0.02
     if (h->v) vecs.push_back(h->v);
     if (h->xlo) vecs.push_back(h->xlo);
     const int gm = std::min((cap_floats + 255) / 256, 1024);
+    // From the first migrated vector on, an error leaves some vectors in the new order under the old tables: the handle is
+    // poisoned (positions must be set again, the lists rebuilt) instead of carrying on to a wrong result.
+    auto poison = [&](int code) {
+        h->have_pos = false;
+        h->dd_lists_valid = false;
+        h->grid_ready = false;
+        return code;
+    };
     for (float *vec : vecs) {
         int rc = coll_allgather_vec(h, vec); // (blocks in the OLD local order: n_own is still the old count)
-        if (rc) return rc;
+        if (rc) return poison(rc);
         hipLaunchKernelGGL(k_migrate_vec, dim3(gm), dim3(256), 0, h->stream, n_own_new, cap_floats, h->d_mig_src, h->mig, vec);
     }
     // 5. the new tables
@@ -1627,17 +1645,19 @@ int dd_reassign(mmx_handle_s *h, bool &changed, double min_moved_fraction = 0.02
     h->own_lo = mine.front() * kSeg;
     std::vector<int> seg_local((size_t)NS, -1);
     for (size_t t = 0; t < mine.size(); ++t) seg_local[mine[t]] = (int)t;
-    if (!h->d_seg_own) {
-        HIPCHK(h, dalloc(&h->d_seg_own, (size_t)SP));
-        HIPCHK(h, dalloc(&h->d_seg_local, (size_t)NS));
+    {
+        hipError_t e1 = hipMemcpyAsync(h->d_seg_own, mine.data(), sizeof(int) * mine.size(), hipMemcpyHostToDevice, h->stream);
+        if (e1 == hipSuccess) e1 = hipMemcpyAsync(h->d_seg_local, seg_local.data(), sizeof(int) * (size_t)NS, hipMemcpyHostToDevice, h->stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
+        if (e1 != hipSuccess) {
+            h->err = std::string("dd_reassign: ") + hipGetErrorString(e1);
+            return poison(MMX_ERR_HIP);
+        }
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_seg_own, mine.data(), sizeof(int) * mine.size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_seg_local, seg_local.data(), sizeof(int) * (size_t)NS, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->coll_failed) return fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out");
+    if (h->coll_failed) return poison(fail(h, MMX_ERR_RCCL, !h->coll_error.empty() ? h->coll_error : "loopback collective timed out"));
     int rc = rebuild_loops(h);
-    if (rc) return rc;
-    if ((rc = dd_upload_static(h))) return rc;
+    if (rc) return poison(rc);
+    if ((rc = dd_upload_static(h))) return poison(rc);
     h->dd_static_dirty = false;
     refresh_params(h);
     h->dd_lists_valid = false;
@@ -1663,6 +1683,14 @@ int prepare(mmx_handle_s *h) {
     h->struct_valid = false; // a kept cell structure does not outlive the call that built it
     if (h->world > 1 && has_nb(h) && (all_pairs(h) || h->nb_variant == 1))
         return fail(h, MMX_ERR_STATE, "multi-GPU runs need a pair cutoff and the cluster kernel (nb_variant 0)");
+    // A minimization with the halo may have re-assigned the 62-bead segments to the ranks (dd_reassign): the vectors then hold
+    // scattered segments.  The paths without a halo (option dd_halo = 0; chromosomal blocks, which switch it off) all-gather
+    // contiguous slices of pos4 and walk contiguous bead ranges (k_chb): on a re-assigned ownership they would compute wrong
+    // forces without any sign of it.
+    if (h->world > 1 && !h->seg_owner.empty() && !use_halo(h))
+        return fail(h, MMX_ERR_STATE, "the ownership of this decomposed system was re-assigned by an earlier minimization (scattered "
+                                      "62-bead segments); evaluations without the ghost-bead halo (dd_halo = 0, chromosomal blocks) "
+                                      "need the initial contiguous slices: create the handles anew");
     if (has_nb(h) && !all_pairs(h) && h->n_all > (1 << 24)) // the cluster kernel addresses spos4 with 32-bit offsets
         return fail(h, MMX_ERR_BAD_ARG, "the cell-list pair kernel supports up to 2^24 beads (the largest Hilbert start the "
                                         "reference can build)");

@@ -146,7 +146,7 @@ struct mmx_handle_s {
     std::vector<int> seg_owner;   // [nseg] owner of every segment (identical on all ranks; empty: identity); segments past the last bead: -1
     std::vector<int> seg_lidx;    // [nseg] local segment index at its owner
     std::vector<int> my_segs;     // owned segments, ascending
-    int *d_seg_own = nullptr, *d_seg_local = nullptr; // device tables of this rank (nullptr: identity)
+    int *d_seg_own = nullptr, *d_seg_local = nullptr; // device tables of this rank (in use once seg_owner is set: own_of)
     int dd_spatial = 1;           // option: re-assign segments while minimizing (0: ownership stays the initial slices)
     int dd_reassign_first = 48;   // evaluations of a minimization before the first attempt; the interval doubles up to ...
     int dd_reassign_max = 768;
@@ -320,7 +320,9 @@ struct mmx_handle_s {
     int cell_edge_auto = 1;      // option: 0 = cells of edge cutoff throughout (A/B)
     float edge_auto = 1.f;       // the factor in force
     float cell_edge_scale = 1.f; // measurement only (option cell_edge_scale): grid cells of edge scale * cutoff -- what a Verlet skin would cost the pair kernels
-    int inject_fault = 0; // tests only: bit 0 = every wait of k_nb_n3 times out at once, bit 1 = its item list holds one item
+    int inject_fault = 0; // tests only: bit 0 = every wait of k_nb_n3 times out at once, bit 1 = its item list holds one item,
+                          // bit 2 = halo messages without slack, bit 3 = a kept cell structure is always stale, bit 4 = slot rows of 64,
+                          // bit 5 = k_tail's fold gives up before its first poll, bit 6 = the direct build finds its grid too large
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool capturing = false;

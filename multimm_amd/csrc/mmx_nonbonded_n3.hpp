@@ -131,6 +131,7 @@ struct N3Row {
     int nx, base[5]; // cell index of x = 0 in the five candidate rows (-1: the row does not exist)
     const int *gstart; // split layout: ghost-cluster offsets per cell (nullptr: no ghost runs), gbase: id of the first ghost cluster
     int gbase, gb[9];  // cell index of x = 0 in the nine rows around the item (-1: outside the grid)
+    int *err = nullptr; // MinState::kernel_error: a ghost run longer than its 16-bit length field voids the evaluation
     __device__ __forceinline__ int TG(int xa, int xb, int *grlo, unsigned short *grn) const {
         const int x0 = max(xa - 1, 0), x1 = min(xb + 1, nx - 1);
         int t = 0;
@@ -141,6 +142,9 @@ struct N3Row {
             if (gstart && gb[r] >= 0) {
                 const int lo = gstart[gb[r] + x0], len = gstart[gb[r] + x1 + 1] - lo;
                 grlo[r] = gbase + lo;
+                // (cannot be reached today -- a cell of more than 4096 beads already raises KERR_ORDER_DD --; if that bound is ever
+                //  relaxed, owned-ghost pairs must not be dropped in silence)
+                if (len > 65535 && err) atomicOr(err, (int)KERR_N3_ITEMS);
                 grn[r] = (unsigned short)min(len, 65535);
                 t += (int)grn[r];
             }
@@ -317,6 +321,7 @@ __device__ __forceinline__ void n3_items_block(const int bid, const int nblk, co
                       R.nx = nx;
                       R.gstart = gstart;
                       R.gbase = gbase;
+                      R.err = &st->kernel_error;
 #pragma unroll
                       for (int r = 0; r < 9; ++r) {
                           const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;

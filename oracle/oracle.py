@@ -67,9 +67,25 @@ FORM_NAMES = {
 
 
 def build(force: bool = False) -> str:
+    """(Re)builds the library when a source is newer.  MMX_ORACLE_LIB names another build of it to load instead (the
+    sanitizer build: `make -C oracle asan`, see the Makefile) -- never a different implementation."""
+    if os.environ.get("MMX_ORACLE_LIB"):
+        return os.path.abspath(os.environ["MMX_ORACLE_LIB"])
     srcs = [os.path.join(HERE, f) for f in ("mmx_oracle.c", "mmx_cpu_fast.c", "mmx_cpu_fast_sweep.c", "mmx_oracle.h", "Makefile")]
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.run(["make", "-C", HERE, "-s", "-B" if force else "-s"], check=True)
+
+    def stale():
+        return force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs)
+    if stale():
+        import fcntl
+        # several processes may arrive here together (rank processes, pytest workers): one builds, the others wait and find
+        # the library current (the Makefile itself builds in a private directory and renames the result into place)
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.run(["make", "-C", HERE, "-s", "-B" if force else "-s"], check=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
@@ -79,8 +95,7 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(LIB)
+        _lib = C.CDLL(build())
         _lib.orc_eval.restype = C.c_int
         _lib.orc_eval.argtypes = [C.POINTER(OrcSystem), C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_minimize.restype = C.c_int

@@ -60,3 +60,46 @@ def test_a_failed_child_stays_a_failure(monkeypatch, capsys):
     assert capsys.readouterr().out.startswith('{"metric"')
     monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, stdout=None: types.SimpleNamespace(returncode=0, stdout=b"nothing\n"))
     assert bench.spawn_ranks(bench.parse_args()) == 5   # a child that printed no line is not a success either
+
+
+def test_strong_scaling_keys_are_top_level_and_a_hung_leg_exits_3():
+    """north_star's 1 -> 8 GPU curve must be readable from the lines' top-level keys, and a decomposed leg that never comes
+    back must cost the `dd` object only -- the line is printed -- while the job ends with exit status 3 (a rank hung in a
+    collective holds its GPU: the launcher and the driver have to see a failure).  The stall is injected; no GPU involved."""
+    import threading
+    import time
+    bench = _load_bench()
+    out = {"metric": "m", "value": 1.0}
+    bench.hoist_strong(out, {"value": 2400.0, "single_gpu_iters_per_s": 780.0, "speedup": 3.08, "parallel_efficiency": 0.385,
+                             "ranks_rccl_saw": 8, "critical_path_us": 250.0}, 8)
+    for k in bench.STRONG_KEYS:
+        assert k in out
+    assert out["strong_1m_iters_per_s"] == 2400.0 and out["strong_1m_ranks_rccl_saw"] == 8 and out["strong_1m_speedup"] == 3.08
+    # a leg that hangs: the watchdog prints the line (rank 0) and leaves with status 3
+    emitted, exits, release = [], [], threading.Event()
+
+    def hung(progress):
+        progress["stage"] = "injected stall"
+        release.wait(10.0)
+        return {"value": None}
+
+    line = {"metric": "m", "value": 3300.0}
+    t = threading.Thread(target=lambda: bench.guarded_leg(hung, 0.2, 0, 2, line, exit_fn=lambda c: (exits.append(c), release.set()),
+                                                          emit_fn=emitted.append), daemon=True)
+    t.start()
+    t.join(10.0)
+    assert exits == [3]
+    assert len(emitted) == 1 and "injected stall" in emitted[0]["dd"]["error"] and emitted[0]["value"] == 3300.0
+    assert emitted[0]["strong_1m_iters_per_s"] is None and "exit status 3" in emitted[0]["strong_1m_note"]
+    # a rank that is not rank 0 prints nothing and leaves with the same status (after giving rank 0 time to print)
+    exits2, rel2 = [], threading.Event()
+    t0 = time.perf_counter()
+    t = threading.Thread(target=lambda: bench.guarded_leg(lambda p: rel2.wait(10.0), 0.1, 1, 2, {}, exit_fn=lambda c: (exits2.append(c), rel2.set()),
+                                                          emit_fn=emitted.append), daemon=True)
+    t.start()
+    t.join(10.0)
+    assert exits2 == [3] and len(emitted) == 1 and time.perf_counter() - t0 >= 3.0
+    # a leg that comes back in time: nothing fires
+    exits3 = []
+    leg = bench.guarded_leg(lambda p: {"value": 5.0}, 5.0, 0, 2, {}, exit_fn=exits3.append, emit_fn=emitted.append)
+    assert leg == {"value": 5.0} and exits3 == [] and len(emitted) == 1
