@@ -115,10 +115,11 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
             HIPCHK(h, dalloc(&h->slot_of, (size_t)std::max(world > 1 ? h->slice : h->n_own, 1)));
             HIPCHK(h, dalloc(&h->sync, (size_t)1));
-            if (world == 1) {
-                HIPCHK(h, dalloc(&h->dcount, (size_t)2 * ((size_t)h->maxcells + 1)));
-                HIPCHK(h, dalloc(&h->drows, (size_t)4 * kDirectMaxRows));
-            }
+            // direct build: two sets (build parity) of cell populations and row totals; decomposed ranks: + the ghosts' populations and
+            // the rows' ghost-cluster totals
+            HIPCHK(h, dalloc(&h->dcount, (size_t)2 * ((size_t)h->maxcells + 1)));
+            HIPCHK(h, dalloc(&h->drows, (size_t)2 * kDirectRowSet));
+            if (world > 1) HIPCHK(h, dalloc(&h->dcount_g, (size_t)2 * ((size_t)h->maxcells + 1)));
             h->n3_cap = n3_configure(kN3MaxCap);
             // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16 (<= n_all /
             // 128 + cells / 16) runs; a run is one record per window pass over its candidates: the rest of n_all / 16 is theirs
@@ -254,7 +255,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync, (void *)h->dcount, (void *)h->drows,
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync, (void *)h->dcount, (void *)h->drows, (void *)h->dcount_g,
                     (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
                     (void *)h->md_snap, (void *)h->cell_xref, (void *)h->slotkeys})
         if (p) (void)hipFree(p);
@@ -678,6 +679,9 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "n_clusters") *value = h->st_host ? h->st_host->n_clusters : 0;   // read-only: the last cell build
     else if (k == "n_cells") *value = h->st_host ? h->st_host->ncells : 0;
     else if (k == "max_per_cell") *value = h->st_host ? h->st_host->max_per_cell : 0;
+    else if (k == "cell_edge") *value = h->st_host ? h->st_host->cell_edge : 0.0;
+    else if (k == "slot_cap") *value = h->slot_cap;       // read-only: rows of the slot table as cut at the last poll
+    else if (k == "slot_cells") *value = h->slot_cells;
     else if (k == "kernel_error") *value = h->st_host ? h->st_host->kernel_error : 0;
     else if (k == "n3_items") *value = h->st_host ? h->st_host->n3_items : 0;
     else if (k == "order_fallbacks") *value = h->st_host ? h->st_host->order_fallbacks : 0; // read-only diagnostic
@@ -1221,8 +1225,10 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             const dim3 gq(std::min((mx + 255) / 256, 256), h->world);
             hipLaunchKernelGGL(k_dd_pack, gq, dim3(256), 0, h->stream, h->dd_send_ids, h->dd_send_cnt, h->slice, h->pos4,
                                h->dd_sendbuf, h->dd_scap, h->st);
-            hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
-                               h->dd_ghost_ids, h->n_all, h->st);
+            // (direct build: the unpack is k_dd_unpack_count, part of the force evaluation's launch sequence -- MMX_K_FORCES times it)
+            if (!(h->fused_build && h->direct_ok && h->dcount_g && h->cell_slots && h->slotkeys && h->slot_cap > 0))
+                hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
+                                   h->dd_ghost_ids, h->n_all, h->st);
             bytes = 16.0 * (double)h->dd_nghost;
             break;
         }

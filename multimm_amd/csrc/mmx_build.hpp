@@ -456,14 +456,356 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
     BUILD_DONE_STAMP();
 }
 
+// ---- decomposed ranks: the same build over owned beads AND ghosts -------------------------------------------------------
+// The pack counts the owned beads (counter set `count`), k_dd_unpack_count the ghosts as they arrive (set `count_g`, keys
+// behind the owned ones in the cell's row of the slot table); both keep per-row totals of the clusters they need -- owned beads
+// and ghosts never share a cluster, and the ghosts' clusters lie in a region of their own behind all the owned ones (the split
+// layout of the half-shell kernel's DD instance) -- and of the cells that hold more than kWaveCellMax beads ALTOGETHER.  The grid
+// is the one the previous build laid out from its owned box grown by the cutoff; beads and ghosts beyond it are clamped into
+// its boundary cells, which keeps every pair within the cutoff inside the 27-cell stencil (k_dd_unpack_count).
+constexpr int kDirectRowSet = 3 * kDirectMaxRows; // ints of one set of row totals: clusters, large cells, ghost clusters
+constexpr int kDirectDDCap = 2048;  // beads of the largest cell its block sort takes (LDS); beyond: KERR_ORDER_DD
+constexpr int kDirectDDRows = 1024; // rows of a rank's grid the build handles (LDS: three prefix arrays)
+struct DirectDD {
+    const int *count_g, *rowclg; // ghosts per cell, ghost clusters per row (this build's set)
+    int *count_g_zero, *rowclg_zero;
+    int *istart;                 // [cells + 1] out: ghost-cluster offsets per cell (counted from the first ghost cluster)
+    float expand;                // the next grid: owned box grown by this much (the cutoff)
+    Own own;
+};
+
+// Exclusive prefixes of one array of row totals (<= kDirectDDRows) in LDS, total at [nrows].  Whole workgroup (256).
+__device__ __forceinline__ void direct_row_prefix1(const int *__restrict__ rows, const int nrows, int *s_out) {
+    constexpr int PER = kDirectDDRows / 256;
+    __shared__ int s_wt[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int v[PER], sa = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int r = t * PER + j;
+        v[j] = r < nrows ? rows[r] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sa += v[j];
+    int ia = sa;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ua = __shfl_up(ia, o, 64);
+        if (lane >= o) ia += ua;
+    }
+    __syncthreads(); // (s_wt of the previous call has been read)
+    if (lane == 63) s_wt[wave] = ia;
+    __syncthreads();
+    int oa = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) oa += w < wave ? s_wt[w] : 0;
+    int ra = oa + ia - sa;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int r = t * PER + j;
+        if (r < nrows) s_out[r] = ra;
+        ra += v[j];
+    }
+    if (t == 255) s_out[nrows] = ra;
+    __syncthreads();
+}
+
+// Cluster slots of one sorted cell of a decomposed rank from the keys in registers (sorted: the ko owned beads first, then the
+// kg ghosts): the owned clusters at cb, the ghosts' at cbg.
+template <int H, int HMAX>
+__device__ __forceinline__ void direct_emit_wave_dd(const DirectArgs &D, const DirectDD &X, MinState *__restrict__ st,
+                                                    const unsigned long long (&v)[HMAX], const int c, const int ko, const int kg,
+                                                    const int cb, const int cbg, const int cap_slots, const int lane) {
+    const int o8 = ((ko + 7) >> 3) << 3, g8 = ((kg + 7) >> 3) << 3;
+    for (int e0 = 0; e0 < o8 + g8; e0 += 64) { // (wave-uniform trip count)
+        const int e = e0 + lane;
+        const bool in = e < o8 + g8;
+        const int src = !in ? -1 : e < o8 ? (e < ko ? e : -1) : (e - o8 < kg ? ko + (e - o8) : -1); // place in the sorted cell
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const unsigned long long t = __shfl(v[h], max(src, 0) & 63, 64);
+            if ((max(src, 0) >> 6) == h) key = t;
+        }
+        if (in) {
+            bool real = src >= 0;
+            int bead = real ? (int)(unsigned)(key & 0xffffffffull) : -1;
+            if (real && (unsigned)bead >= (unsigned)D.n_beads) {
+                atomicOr(&st->kernel_error, (int)KERR_BOUNDS);
+                real = false;
+                bead = -1;
+            }
+            float4 p = make_float4(1e18f, 1e18f, 1e18f, __int_as_float(-8));
+            if (real) p = D.pos4[bead];
+            const int lb = real ? X.own.local(bead) : -1;
+            const int sl = e < o8 ? cb * 8 + e : cbg * 8 + (e - o8);
+            const bool fits = sl < cap_slots;
+            if (fits) {
+                D.spos4[sl] = p;
+                D.sbead[sl] = bead;
+                if (lb >= 0) D.slot_of[lb] = sl;
+            }
+            const float big = 3.0e38f;
+            float lx = real ? p.x : big, ly = real ? p.y : big, lz = real ? p.z : big;
+            float hx = real ? p.x : -big, hy = real ? p.y : -big, hz = real ? p.z : -big;
+            int nreal = real ? 1 : 0, nown = lb >= 0 ? 1 : 0;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                lx = fminf(lx, __shfl_xor(lx, o, 64));
+                ly = fminf(ly, __shfl_xor(ly, o, 64));
+                lz = fminf(lz, __shfl_xor(lz, o, 64));
+                hx = fmaxf(hx, __shfl_xor(hx, o, 64));
+                hy = fmaxf(hy, __shfl_xor(hy, o, 64));
+                hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+                nreal += __shfl_xor(nreal, o, 64);
+                nown += __shfl_xor(nown, o, 64);
+            }
+            if ((lane & 7) == 0) {
+                if (fits) {
+                    const int cl = sl >> 3;
+                    D.cl_lo[2 * cl] = make_float4(lx, ly, lz, __int_as_float(c));
+                    D.cl_lo[2 * cl + 1] = make_float4(hx, hy, hz, __int_as_float((nown << 8) | nreal));
+                } else {
+                    atomicOr(&st->kernel_error, (int)KERR_BOUNDS);
+                }
+            }
+        }
+    }
+}
+
+template <int CAP, bool N3>
+__global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, const DirectDD X, MinState *__restrict__ st,
+                                                          const FFParams P, const BondedArgs B) {
+    if (st->phase >= PH_DONE) return;
+    __shared__ unsigned long long s_buf[CAP];
+    __shared__ int s_cl[kDirectDDRows + 1], s_clg[kDirectDDRows + 1], s_big[kDirectDDRows + 1];
+    __shared__ double s_w[4];
+    static_assert(sizeof(unsigned long long) * CAP >= sizeof(int) * 4 * (kN3Runs + kN3GhostRuns) * 66, "item builders' scratch");
+    const int nbb = D.n_bonded_blocks;
+    if ((int)blockIdx.x >= D.n_items_blocks && (int)blockIdx.x < D.n_items_blocks + nbb) {
+        for (int vb = (int)blockIdx.x - D.n_items_blocks; vb < B.nvb; vb += nbb)
+            bonded_fused_block<256>(P, D.pos4, B.flags, B.lstart, B.partner, B.r0, B.cf_w, B.g, B.part, B.loop_form, B.lam_form,
+                                    B.cf_form, vb, B.nvb, s_w);
+        return;
+    }
+    const GridParams G = *D.grid;
+    const int nx = G.nx, nrows = G.ny * G.nz, ncells = G.ncells;
+    if (nx > 64 || nrows > kDirectDDRows) return; // (k_pack has voided the evaluation)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cap_slots = D.cap_clusters * 8;
+    // Layout of the cluster list.  Half-shell kernel (N3): SPLIT -- all owned clusters first (offsets from s_cl), the ghosts' in a
+    // region of their own behind them (offsets from s_clg, counted from the first ghost cluster).  Full-shell kernel: a cell's
+    // ghost clusters right behind its owned ones (k_nb_clusters_j walks cstart[c] .. cstart[c + 1]): ONE offset space, s_cl holds
+    // the prefix of both kinds together and s_clg stays zero.
+    constexpr bool SPLIT = N3;
+    direct_row_prefix1(D.rowcl, nrows, s_cl);
+    direct_row_prefix1(X.rowclg, nrows, s_clg);
+    direct_row_prefix1(D.rowbig, nrows, s_big);
+    if (!SPLIT) {
+        for (int r = threadIdx.x; r <= nrows; r += 256) {
+            s_cl[r] += s_clg[r];
+            s_clg[r] = 0;
+        }
+        __syncthreads();
+    }
+    const int tot_cl = s_cl[nrows], tot_clg = s_clg[nrows], nbig = s_big[nrows];
+
+    if ((int)blockIdx.x < D.n_items_blocks) {
+        if (blockIdx.x == 0) {
+            __shared__ float s_red[6 * 4];
+            const GridParams GN = grid_from_parts<256>(D.bbox_part, D.nblk_bbox, D.hmin, D.maxcells, s_red, X.expand);
+            if (threadIdx.x == 0) {
+                *D.grid_next = GN;
+                st->n_clusters = tot_cl + tot_clg;
+                st->n_clusters_own = tot_cl; // (interleaved layout: all of them, as the scan-based build reports it)
+                st->n_big = nbig;
+                st->ncells = ncells;
+                st->ncells_set[D.parity] = ncells;
+                st->cell_edge = (double)G.h;
+                D.cstart[ncells] = min(tot_cl, D.cap_clusters);
+                X.istart[ncells] = min(tot_clg, D.cap_clusters);
+                st->dd_excess_bits = 0u; // (read by this build's ghost count, which ran before; the next pack starts from zero)
+                if (tot_cl + tot_clg > D.cap_clusters) atomicOr(&st->kernel_error, (int)KERR_BOUNDS);
+            }
+        }
+        if (!N3) return;
+        // work items: offsets of the five owned rows and the nine ghost rows around the wave's row, from the populations
+        int *const cs_w = reinterpret_cast<int *>(s_buf) + wave * ((kN3Runs + kN3GhostRuns) * 66);
+        n3_items_rows((int)blockIdx.x, D.n_items_blocks, G, D.n3_items, D.n3_max_items, st, (D.n3_flags & 4) ? 2 : (D.n3_flags & 1),
+                      !(D.n3_flags & 2), (D.n3_flags >> 8) > 0 ? min(D.n3_flags >> 8, kN3MaxCap) : kN3MaxCap,
+                      [&](int row, int y, int z, N3Row &R) {
+                          int rb[kN3Runs], rg[kN3GhostRuns];
+                          rb[0] = row;
+                          rb[1] = y + 1 < G.ny ? row + 1 : -1;
+#pragma unroll
+                          for (int dy = -1; dy <= 1; ++dy)
+                              rb[3 + dy] = (z + 1 < G.nz && y + dy >= 0 && y + dy < G.ny) ? row + G.ny + dy : -1;
+#pragma unroll
+                          for (int r = 0; r < kN3GhostRuns; ++r) {
+                              const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
+                              rg[r] = (yy >= 0 && yy < G.ny && zz >= 0 && zz < G.nz) ? zz * G.ny + yy : -1;
+                          }
+                          int cnt[kN3Runs], cng[kN3GhostRuns];
+#pragma unroll
+                          for (int r = 0; r < kN3Runs; ++r) cnt[r] = (rb[r] >= 0 && lane < nx) ? D.count[rb[r] * nx + lane] : 0;
+#pragma unroll
+                          for (int r = 0; r < kN3GhostRuns; ++r) cng[r] = (rg[r] >= 0 && lane < nx) ? X.count_g[rg[r] * nx + lane] : 0;
+                          wave_lds_sync(); // the previous row's offsets have been read
+                          auto put = [&](int slot, int rowid, int cnt_l, const int *s_pref) {
+                              const int cl = (cnt_l + 7) >> 3;
+                              int inc = cl;
+#pragma unroll
+                              for (int o = 1; o < 64; o <<= 1) {
+                                  const int u = __shfl_up(inc, o, 64);
+                                  if (lane >= o) inc += u;
+                              }
+                              if (rowid >= 0) {
+                                  const int base = s_pref[rowid];
+                                  if (lane < nx) cs_w[slot * 66 + lane] = base + inc - cl;
+                                  if (lane == 63) cs_w[slot * 66 + nx] = base + inc;
+                              }
+                          };
+#pragma unroll
+                          for (int r = 0; r < kN3Runs; ++r) {
+                              put(r, rb[r], cnt[r], s_cl);
+                              R.base[r] = rb[r] >= 0 ? r * 66 : -1;
+                          }
+#pragma unroll
+                          for (int r = 0; r < kN3GhostRuns; ++r) {
+                              put(kN3Runs + r, rg[r], cng[r], s_clg);
+                              R.gb[r] = rg[r] >= 0 ? (kN3Runs + r) * 66 : -1;
+                          }
+                          wave_lds_sync();
+                          R.cstart = cs_w;
+                          R.nx = nx;
+                          R.gstart = cs_w;
+                          R.gbase = tot_cl;
+                          R.err = &st->kernel_error;
+                      });
+        return;
+    }
+
+    const int bid = (int)blockIdx.x - D.n_items_blocks - nbb, nblk = D.n_order;
+    {
+        const int nz_cells = min(st->ncells_set[D.parity ^ 1], D.maxcells);
+        for (int q = bid * 256 + (int)threadIdx.x; q < nz_cells; q += nblk * 256) {
+            D.count_zero[q] = 0;
+            X.count_g_zero[q] = 0;
+        }
+        for (int q = bid * 256 + (int)threadIdx.x; q < kDirectDDRows; q += nblk * 256) {
+            D.rowcl_zero[q] = 0;
+            D.rowbig_zero[q] = 0;
+            X.rowclg_zero[q] = 0;
+        }
+    }
+    const int nB = min(nbig, nblk - (nblk >> 2));
+    const int kvec = min(D.slot_cap >> 6, kWaveCellMax / 64);
+    for (int c = (bid - nB) * 4 + wave; bid >= nB && c < ncells; c += (nblk - nB) * 4) {
+        const int row = c / nx, x = c - row * nx;
+        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = lane < nx ? X.count_g[row * nx + lane] : 0;
+        const bool in_table = c < D.slot_cells;
+        unsigned long long v[kWaveCellMax / 64];
+#pragma unroll
+        for (int h = 0; h < kWaveCellMax / 64; ++h) {
+            v[h] = ~0ull;
+            if (in_table && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
+        }
+        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64), k = ko + kg;
+        const int cb = s_cl[row] + direct_row_before(SPLIT ? (ko_l + 7) >> 3 : ((ko_l + 7) >> 3) + ((kg_l + 7) >> 3), lane, x);
+        const int cg = SPLIT ? tot_cl + s_clg[row] + direct_row_before((kg_l + 7) >> 3, lane, x) : cb + ((ko + 7) >> 3);
+        if (lane == 0) {
+            D.cstart[c] = min(cb, D.cap_clusters);
+            X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
+        }
+        if (k > kWaveCellMax || k == 0) continue;
+        if (!in_table || k > D.slot_cap) continue; // (a void evaluation: the counting kernels flagged it)
+#pragma unroll
+        for (int h = 0; h < kWaveCellMax / 64; ++h)
+            if (h * 64 + lane >= k) v[h] = ~0ull;
+        if (k <= 64) {
+            if (k > 1) wave_sort_keys<1>(v, lane);
+            direct_emit_wave_dd<1>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+        } else if (k <= 128) {
+            wave_sort_keys<2>(v, lane);
+            direct_emit_wave_dd<2>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+        } else {
+            wave_sort_keys<4>(v, lane);
+            direct_emit_wave_dd<4>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+        }
+    }
+    for (int bi = bid; bid < nB && bi < nbig; bi += nB) {
+        int lo = 0, hi = nrows;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_big[mid] <= bi) lo = mid;
+            else hi = mid;
+        }
+        const int row = lo;
+        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = lane < nx ? X.count_g[row * nx + lane] : 0;
+        unsigned long long m = __ballot(ko_l + kg_l > kWaveCellMax);
+        for (int k = bi - s_big[row]; k > 0 && m; --k) m &= m - 1;
+        if (!m) continue;
+        const int x = __ffsll((long long)m) - 1;
+        const int c = row * nx + x;
+        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64), cnt = ko + kg;
+        const int cb = s_cl[row] + direct_row_before(SPLIT ? (ko_l + 7) >> 3 : ((ko_l + 7) >> 3) + ((kg_l + 7) >> 3), lane, x);
+        const int cg = SPLIT ? tot_cl + s_clg[row] + direct_row_before((kg_l + 7) >> 3, lane, x) : cb + ((ko + 7) >> 3);
+        if (threadIdx.x == 0) {
+            D.cstart[c] = min(cb, D.cap_clusters);
+            X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
+        }
+        if (c >= D.slot_cells || cnt > D.slot_cap) continue;
+        const unsigned long long *kp = D.keys + (size_t)c * D.slot_cap;
+        __syncthreads();
+        if (cnt > CAP) { // owned beads and ghosts cannot be kept in separate clusters without the sort: the evaluation is void
+            if (threadIdx.x == 0) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
+            continue;
+        }
+        if (cnt <= 1024) {
+            int n2 = 128;
+            while (n2 < cnt) n2 <<= 1;
+            if (n2 <= 256) block_sort_regs<1>(s_buf, kp, cnt, n2);
+            else if (n2 == 512) block_sort_regs<2>(s_buf, kp, cnt, n2);
+            else block_sort_regs<4>(s_buf, kp, cnt, n2);
+        } else {
+            int n2 = 128;
+            while (n2 < cnt) n2 <<= 1;
+            for (int q = threadIdx.x; q < n2; q += 256) {
+                unsigned long long kq = ~0ull;
+                if (q < cnt) kq = kp[q];
+                s_buf[q] = kq;
+            }
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    __syncthreads();
+                    for (int q = threadIdx.x; q < (n2 >> 1); q += 256) {
+                        const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                        const int i1 = i0 | j;
+                        const unsigned long long a = s_buf[i0], b = s_buf[i1];
+                        const bool up = (i0 & k) == 0;
+                        if ((a > b) == up) {
+                            s_buf[i0] = b;
+                            s_buf[i1] = a;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        emit_clusters(c, 0, cnt, ko, cb, cg, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, X.own, s_buf, D.sbead,
+                      D.slot_of, cap_slots, st, D.n_beads);
+    }
+}
+
 // The fullest cell of the last direct build, for the host's polls (the scan used to publish it per build): the counter set is
 // intact until the next build zeroes it.
 __global__ __launch_bounds__(256) void k_poll_stats(const int *__restrict__ count, const GridParams *__restrict__ grid,
-                                                    MinState *__restrict__ st) {
+                                                    MinState *__restrict__ st, const int *__restrict__ count_g = nullptr) {
     __shared__ int s_m[4];
     const int n = grid->ncells;
     int m = 0;
-    for (int q = threadIdx.x; q < n; q += 256) m = max(m, count[q]);
+    for (int q = threadIdx.x; q < n; q += 256) m = max(m, count[q] + (count_g ? count_g[q] : 0));
     m = wave_max_i(m);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();

@@ -19,7 +19,9 @@ constexpr int kRowAgg = 8; // rows a workgroup of the pack sums in LDS before it
 __device__ __forceinline__ int cell_rank(bool todo, int c, int i, int *__restrict__ rank, int *__restrict__ count,
                                          int *__restrict__ count_own = nullptr, bool owned = true,
                                          int *__restrict__ rowcl = nullptr, int *__restrict__ rowbig = nullptr, const int nx = 1,
-                                         int *s_rows = nullptr /* LDS [3][kRowAgg]: row (-1: free), clusters, large cells */) {
+                                         int *s_rows = nullptr /* LDS [3][kRowAgg]: row (-1: free), clusters, large cells */,
+                                         const int *__restrict__ count_before = nullptr /* decomposed ranks, ghosts: the cell's owned
+                                         beads, counted by the pack before -- a cell is large by what it holds altogether */) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long own_lanes = count_own ? __ballot(todo && owned) : 0ull;
@@ -38,7 +40,8 @@ __device__ __forceinline__ int cell_rank(bool todo, int c, int i, int *__restric
         base = atomicAdd(&count[c], m);
         if (count_own && (mine & own_lanes)) atomicAdd(&count_own[c], __popcll(mine & own_lanes));
         if (rowcl) {
-            const int nc = base + m, dcl = ((nc + 7) >> 3) - ((base + 7) >> 3), dbig = (nc > kWaveCellMax ? 1 : 0) - (base > kWaveCellMax ? 1 : 0);
+            const int nc = base + m, dcl = ((nc + 7) >> 3) - ((base + 7) >> 3), b0 = count_before ? count_before[c] : 0;
+            const int dbig = (b0 + nc > kWaveCellMax ? 1 : 0) - (b0 + base > kWaveCellMax ? 1 : 0);
             // The rows are few (121 at the densest): straight global atomics put ~80 updates on every address, one after the
             // other at the memory side (measured: the pack took 27.5 us instead of 13).  A workgroup's 256 chain-consecutive beads
             // sit in a handful of rows: they are summed in LDS first, one global update per row and workgroup at the end.
@@ -150,6 +153,8 @@ struct SlotArgs {
     int cap, cells;
     int *rowcl = nullptr, *rowbig = nullptr; // direct build (mmx_build.hpp): per-row totals kept by the pack (cell_rank)
     int force_void = 0;                      // tests (inject_fault bit 6): behave as if the grid were beyond the direct build
+    int max_rows = kDirectMaxRows;           // rows (ny * nz) the build that follows can take
+    float dd_margin = -1.f;                  // decomposed ranks: the cutoff the grid box was grown by (>= 0: record the owned beads' excess)
 };
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
     __shared__ float s_bb[6][4];
     __shared__ float4 s_xp[MOVE ? 192 : 1], s_d[MOVE ? 192 : 1]; // the block's 768 floats of xp and d
     __shared__ int s_rows[3 * kRowAgg];
-    if (MOVE && COUNT && threadIdx.x < 3 * kRowAgg) s_rows[threadIdx.x] = threadIdx.x < kRowAgg ? -1 : 0; // (before the barrier below)
+    if (COUNT && threadIdx.x < 3 * kRowAgg) s_rows[threadIdx.x] = threadIdx.x < kRowAgg ? -1 : 0;
+    if (COUNT && !MOVE) __syncthreads(); // (MOVE: the barrier of the hand-over below)
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // local index of an owned bead
     float px = 0.f, py = 0.f, pz = 0.f;
     const bool act = i < n_own;
@@ -258,24 +264,37 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
             if (R.mode == 1 && m > R.thr2) atomicOr(&stw->cell_stale, 1);
         }
     }
-    if (COUNT) { // single-domain handles only: every bead is owned, bead == i
+    if (COUNT) { // the owned beads (single domain: all of them, bead == i; decomposed ranks with the direct build: the ghosts are
+                 // counted when they arrive, k_dd_unpack_count)
         const GridParams G = *grid;
         int c = 0, cx = 0, cy = 0, cz = 0;
+        const int bead_c = act ? own.bead(i) : 0;
         if (act) {
             cx = cell_coord(px, G.ox, G.inv_h, G.nx);
             cy = cell_coord(py, G.oy, G.inv_h, G.ny);
             cz = cell_coord(pz, G.oz, G.inv_h, G.nz);
             c = (cz * G.ny + cy) * G.nx + cx;
-            cell_of[i] = c;
+            cell_of[bead_c] = c;
         }
-        const int r = cell_rank(act, c, i, rank, count, nullptr, true, T.rowcl, T.rowbig, G.nx, (MOVE && T.rowcl) ? s_rows : nullptr);
+        const int r = cell_rank(act, c, bead_c, rank, count, nullptr, true, T.rowcl, T.rowbig, G.nx, T.rowcl ? s_rows : nullptr);
         if (T.rowcl && i == 0) stw->n3_items = 0; // (direct build: no scan resets the work-item count the item builders append to)
         // the direct build reads a row of populations with one lane per cell and keeps the row prefixes in LDS: a grid beyond
         // that voids the evaluation (the host falls back to the scan-based build for the rest of the call)
-        if (T.rowcl && i == 0 && (G.nx > 64 || G.ny * G.nz > kDirectMaxRows || T.force_void)) atomicOr(&stw->cell_stale, 4);
+        if (T.rowcl && i == 0 && (G.nx > 64 || G.ny * G.nz > T.max_rows || T.force_void)) atomicOr(&stw->cell_stale, 4);
+        if (T.dd_margin >= 0.f) { // how far owned beads reach beyond the grid box shrunk by the cutoff (MinState::dd_excess_bits)
+            float ex = 0.f;
+            if (act) {
+                const float hx = G.ox + (float)G.nx * G.h, hy = G.oy + (float)G.ny * G.h, hz = G.oz + (float)G.nz * G.h, m = T.dd_margin;
+                ex = fmaxf(fmaxf(fmaxf(G.ox + m - px, px - (hx - m)), fmaxf(G.oy + m - py, py - (hy - m))),
+                           fmaxf(fmaxf(G.oz + m - pz, pz - (hz - m)), 0.f));
+                if (!(ex >= 0.f)) ex = 3e38f; // (NaN: keep every ghost)
+            }
+            ex = wave_max(ex);
+            if ((threadIdx.x & 63) == 0 && ex > 0.f && __float_as_uint(ex) > stw->dd_excess_bits) atomicMax(&stw->dd_excess_bits, __float_as_uint(ex));
+        }
         if (T.keys && act) {
             if (c < T.cells && r < T.cap)
-                T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, i, false);
+                T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, bead_c, false);
             else
                 atomicOr(&stw->cell_stale, 2); // the table is too small for this state: the evaluation is void (k_decide halts)
         }
@@ -303,7 +322,7 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         for (int w = 1; w < 4; ++w) r = k < 3 ? fminf(r, s_bb[k][w]) : fmaxf(r, s_bb[k][w]);
         bbox_part[k * gridDim.x + blockIdx.x] = r;
     }
-    if (MOVE && COUNT && T.rowcl && threadIdx.x >= 64 && threadIdx.x < 64 + kRowAgg) { // (the barrier above: every wave's updates are in)
+    if (COUNT && T.rowcl && threadIdx.x >= 64 && threadIdx.x < 64 + kRowAgg) { // (the barrier above: every wave's updates are in)
         const int q = threadIdx.x - 64, row = s_rows[q];
         if (row >= 0) {
             if (s_rows[kRowAgg + q]) atomicAdd(&T.rowcl[row], s_rows[kRowAgg + q]);
@@ -409,6 +428,8 @@ struct ScanArgs {
     const GridParams *grid;
     GridParams *grid_next;
     const int *count_own; // decomposed runs: owned beads per cell (nullptr: every bead is owned)
+    float expand_next = 0.f; // decomposed ranks: the NEXT build's grid is this evaluation's owned box grown by the cutoff (the direct
+                             // build bins on it, ghosts included: mmx_build.hpp)
     int split;            // decomposed ranks running the half-shell kernel: the clusters of owned beads come first in the cluster
                           // list (cstart: their offsets per cell), the ghosts' clusters behind them (istart: THEIR offsets per
                           // cell, counted from the first ghost cluster) -- every owned-ghost pair is then taken from the owned
@@ -428,7 +449,7 @@ __device__ __forceinline__ void cell_scan_block(const ScanArgs &a, MinState *__r
     __shared__ float s_red[6 * 16];
     const GridParams G = *grid;
     // grid of the NEXT build from this evaluation's bounding box (see k_cell_count on staleness)
-    const GridParams GN = grid_from_parts<1024>(bbox_part, nblk, hmin, maxcells, s_red);
+    const GridParams GN = grid_from_parts<1024>(bbox_part, nblk, hmin, maxcells, s_red, a.expand_next);
     const int t = threadIdx.x;
     const int per = (G.ncells + 1023) / 1024;
     const int c0 = t * per, c1 = min(c0 + per, G.ncells);

@@ -149,6 +149,9 @@ struct MinState {
                          // binned -- the evaluation is void (PH_HALT, halt_reason bit 2) and is repeated after a full build
     int ncells_set[2];   // direct build (mmx_build.hpp): cells of the grid each of the two counter sets was last used with (what the
                          // build that zeroes the set for the next pack has to cover)
+    unsigned dd_excess_bits; // decomposed ranks, direct build: how far (nm, float bits) an owned bead lies outside the build's grid box
+                             // shrunk by the cutoff -- ghosts farther than that outside the grid box cannot be within the cutoff of
+                             // any owned bead and are not binned (k_dd_unpack_count); reset by the build
     unsigned disp2_bits; // largest squared displacement of a bead from where it was binned, as float bits (non-negative floats
                          // order like unsigned ints), over the evaluations since the host last cleared it
     double fx;      // energy at the last accepted point

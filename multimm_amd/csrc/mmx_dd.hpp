@@ -213,6 +213,73 @@ __global__ __launch_bounds__(256) void k_dd_unpack(const float4 *__restrict__ re
     }
 }
 
+// k_dd_unpack + the ghosts' share of the direct build's counting (mmx_build.hpp; the pack has counted the owned beads): every
+// arriving ghost is binned on the build's grid -- CLAMPED like an owned bead: two beads within the cutoff of each other are at
+// most one cell apart per axis before the clamp and therefore after it, so a grid laid out from an earlier evaluation's box stays
+// exact; a ghost beyond the box merely lands in a boundary cell --, takes a place behind the cell's owned beads in its row of
+// the slot table, and moves the per-row totals of ghost clusters / large cells.  One workgroup = 256 consecutive entries of one
+// peer's message (whole waves: cell_rank).  grid (blocks, world)
+struct GhostCount {
+    const GridParams *grid;
+    int *cell_of, *rank;
+    int *count_g;            // [cells] ghosts per cell (this build's set)
+    const int *count_o;      // [cells] owned beads per cell: final, the pack ran before
+    int *rowclg, *rowbig;    // [rows]
+    unsigned long long *keys;
+    int cap, cells;
+};
+__global__ __launch_bounds__(256) void k_dd_unpack_count(const float4 *__restrict__ recvbuf, const DDOffsets O, int slice,
+                                                         float4 *__restrict__ pos4, int *__restrict__ ghost_ids, int n_all,
+                                                         const GhostCount C, MinState *__restrict__ st) {
+    if (st->phase >= PH_DONE) return;
+    __shared__ int s_rows[3 * kRowAgg];
+    if (threadIdx.x < 3 * kRowAgg) s_rows[threadIdx.x] = threadIdx.x < kRowAgg ? -1 : 0;
+    __syncthreads();
+    const GridParams G = *C.grid;
+    const float excess = __uint_as_float(st->dd_excess_bits) * 1.0001f + 1e-6f; // (final: the pack ran before)
+    const int q = blockIdx.y, n = O.off[q + 1] - O.off[q];
+    for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) { // (block-uniform trip count: whole waves reach cell_rank)
+        const int k = k0 + (int)threadIdx.x;
+        int id = -1, c = 0, cx = 0, cy = 0, cz = 0;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n) {
+            p = recvbuf[(size_t)q * slice + k];
+            id = __float_as_int(p.w) >> 3;
+            if ((unsigned)id >= (unsigned)n_all) id = -1;
+            if (id >= 0) pos4[id] = p;
+            ghost_ids[O.off[q] + k] = id;
+        }
+        bool todo = id >= 0;
+        if (todo) { // farther outside the grid box than any owned bead reaches beyond the box shrunk by the cutoff: no partner here
+            const float hx = G.ox + (float)G.nx * G.h, hy = G.oy + (float)G.ny * G.h, hz = G.oz + (float)G.nz * G.h;
+            const float out = fmaxf(fmaxf(fmaxf(G.ox - p.x, p.x - hx), fmaxf(G.oy - p.y, p.y - hy)), fmaxf(G.oz - p.z, p.z - hz));
+            todo = !(out > excess);
+            if (!todo) C.cell_of[id] = -1;
+        }
+        if (todo) {
+            cx = cell_coord(p.x, G.ox, G.inv_h, G.nx);
+            cy = cell_coord(p.y, G.oy, G.inv_h, G.ny);
+            cz = cell_coord(p.z, G.oz, G.inv_h, G.nz);
+            c = (cz * G.ny + cy) * G.nx + cx;
+            C.cell_of[id] = c;
+        }
+        const int r = cell_rank(todo, c, todo ? id : 0, C.rank, C.count_g, nullptr, true, C.rowclg, C.rowbig, G.nx, s_rows, C.count_o);
+        if (todo) {
+            const int at = C.count_o[c] + r; // behind the cell's owned beads
+            if (c < C.cells && at < C.cap) C.keys[(size_t)c * C.cap + at] = order_key(p, G, cx, cy, cz, id, true);
+            else atomicOr(&st->cell_stale, 2); // the row is too short for this cell: the evaluation is void, longer rows for the repeat
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kRowAgg) {
+        const int row = s_rows[threadIdx.x];
+        if (row >= 0) {
+            if (s_rows[kRowAgg + threadIdx.x]) atomicAdd(&C.rowclg[row], s_rows[kRowAgg + threadIdx.x]);
+            if (s_rows[2 * kRowAgg + threadIdx.x]) atomicAdd(&C.rowbig[row], s_rows[2 * kRowAgg + threadIdx.x]);
+        }
+    }
+}
+
 // Raises st->dd_stale when an owned bead is farther than sqrt(thr2) from where it was when the lists were built.
 __global__ __launch_bounds__(256) void k_dd_displacement(int n_own, const float *__restrict__ x, const float *__restrict__ xref,
                                                          float thr2, MinState *__restrict__ st) {

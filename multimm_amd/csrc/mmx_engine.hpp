@@ -692,6 +692,111 @@ int dd_schedule(mmx_handle_s *h) {
 
 void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
 
+// The counter set of parity `par` must be zero before a pack counts into it: it is, unless the last direct build used this very
+// parity (scan-based builds in between flip the parity without touching the sets)
+void direct_claim_set(mmx_handle_s *h, const int par) {
+    if (h->dset_dirty[par]) {
+        const size_t cset = (size_t)h->maxcells + 1;
+        (void)hipMemsetAsync(h->dcount + (size_t)par * cset, 0, sizeof(int) * cset, h->stream);
+        (void)hipMemsetAsync(h->drows + (size_t)par * kDirectRowSet, 0, sizeof(int) * kDirectRowSet, h->stream);
+        if (h->dcount_g) (void)hipMemsetAsync(h->dcount_g + (size_t)par * cset, 0, sizeof(int) * cset, h->stream);
+    }
+    h->dset_dirty[par] = true;      // this build's counts stay in it ...
+    h->dset_dirty[par ^ 1] = false; // ... and it zeroes the other one
+}
+
+// Decomposed ranks, direct build: what arrived from the peers goes to pos4 AND is counted into this parity's ghost set
+void dd_ghost_count(mmx_handle_s *h, const dim3 gq) {
+    const int par = h->build_idx & 1;
+    const size_t cset = (size_t)h->maxcells + 1;
+    int *const drcl = h->drows + (size_t)par * kDirectRowSet;
+    const GhostCount C{h->grid + par, h->cell_of, h->rank_in_cell, h->dcount_g + (size_t)par * cset, h->dcount + (size_t)par * cset,
+                       drcl + 2 * kDirectMaxRows, drcl + kDirectMaxRows, h->slotkeys, h->slot_cap, h->slot_cells};
+    hipLaunchKernelGGL(k_dd_unpack_count, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4, h->dd_ghost_ids,
+                       h->n_all, C, h->st);
+}
+
+int local_beads(const mmx_handle_s *h);
+bool use_n3(const mmx_handle_s *h);
+void launch_build_direct_dd(mmx_handle_s *h, CtlArgs &bonded, const int gb) {
+    const float hm = hmin_of(h);
+    const int par = h->build_idx & 1;
+    GridParams *cur = h->grid + par, *next = h->grid + (par ^ 1);
+    h->grid_factor[par ^ 1] = edge_factor(h);
+    h->grid_factor[par] = edge_factor(h);
+    h->n3_build = use_n3(h);
+    const int nvb = grid_beads(h->n_own);
+    const int nib = h->n3_build ? kN3ItemBlocks : 1;
+    const int vi = h->n3_build ? 1 : 0;
+    if (h->direct_dd_slots[vi] <= 0) {
+        int per_cu = 0;
+        const hipError_t oe = vi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, true>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, false>, 256, 0);
+        if (oe != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();
+            per_cu = 3;
+        }
+        h->direct_dd_slots[vi] = per_cu * std::max(h->n_cus, 1);
+    }
+    const int nbr = (nvb + 1) / 2;
+    const int go = std::max(256, std::min(2048, h->direct_dd_slots[vi] - nib - nbr));
+    const size_t cset = (size_t)h->maxcells + 1;
+    const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
+    const bool loops_on = h->n_rows > 0 && h->lstart;
+    DirectArgs D{};
+    D.grid = cur;
+    D.grid_next = next;
+    D.parity = par;
+    D.bbox_part = h->bbox_part;
+    D.nblk_bbox = gb;
+    D.hmin = hm;
+    D.maxcells = h->maxcells;
+    D.count = h->dcount + (size_t)par * cset;
+    D.rowcl = h->drows + (size_t)par * kDirectRowSet;
+    D.rowbig = D.rowcl + kDirectMaxRows;
+    D.count_zero = h->dcount + (size_t)(par ^ 1) * cset;
+    D.rowcl_zero = h->drows + (size_t)(par ^ 1) * kDirectRowSet;
+    D.rowbig_zero = D.rowcl_zero + kDirectMaxRows;
+    D.keys = h->slotkeys;
+    D.slot_cap = h->slot_cap;
+    D.slot_cells = h->slot_cells;
+    D.pos4 = h->pos4;
+    D.spos4 = h->spos4;
+    D.cl_lo = h->cl_lo;
+    D.cstart = h->cstart;
+    D.sbead = h->sbead;
+    D.slot_of = h->slot_of;
+    D.cap_clusters = h->n_all;
+    D.n_beads = h->n_all;
+    D.n3_items = h->n3_items;
+    D.n3_max_items = (h->inject_fault & 2) ? 1 : h->n3_max_items;
+    D.n3_flags = (h->n3_long_items == 2 ? 5 : h->n3_long_items >= 0 ? h->n3_long_items : local_beads(h) >= kN3LongItemsFrom ? 1 : 0) |
+                 (h->n3_pass_records ? 0 : 2) | (h->n3_slice_cap << 8);
+    D.n_items_blocks = nib;
+    D.n_bonded_blocks = nbr;
+    D.n_order = go;
+    DirectDD X{};
+    X.count_g = h->dcount_g + (size_t)par * cset;
+    X.rowclg = D.rowcl + 2 * kDirectMaxRows;
+    X.count_g_zero = h->dcount_g + (size_t)(par ^ 1) * cset;
+    X.rowclg_zero = D.rowcl_zero + 2 * kDirectMaxRows;
+    X.istart = h->istart;
+    X.expand = hm / edge_factor(h); // (grown by the cutoff, whatever the cell edge)
+    X.own = own_of(h);
+    const BondedArgs BA{bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part,
+                        h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb};
+    const dim3 gd(nib + nbr + go);
+    if (h->n3_build) hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, true>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    else hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, false>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    enqueue_bonded(h, bonded, true);
+    h->gcur = cur;
+    h->build_idx++;
+    h->grid_ready = true;
+    h->last_build_direct = true;
+    h->last_direct_parity = par;
+    h->direct_builds++;
+}
+
 // Pack (+ trial move / integrator step), then the cell build.  With `bonded` set, the bonded terms of the evaluation
 // -- which only need pos4 -- are enqueued with it: inside the launch of the cell scan ("overlap_bonded", default), or
 // right behind the pack.
@@ -732,6 +837,12 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     if (!tracked) h->struct_valid = false; // whatever is built below is not tracked by cell_xref
     h->slots_now = false;
     bool direct = false;
+    // decomposed ranks: the direct build over owned beads and ghosts (mmx_build.hpp, k_build_direct_dd) -- on the grid the
+    // previous build laid out, with the ghost lists in place (or about to be rebuilt on the way: redecomp)
+    const bool direct_dd = dd && !init && h->world > 1 && use_halo(h) && (h->dd_lists_valid || redecomp == 1) &&
+                           h->fused_build && h->direct_ok && h->dcount_g && bonded && h->fused_bonded && h->overlap_bonded &&
+                           has_nb(h) && !all_pairs(h) && h->grid_ready && h->cell_slots && h->slotkeys && h->slot_cap > 0 &&
+                           !h->capturing && (mode == PACK_MOVE || mode == PACK_PLAIN);
     if (mode == PACK_MD) { // integrator step fused with the pack (forces of the current positions are in g)
         MdParams M = h->md;
         M.step_lo = (uint32_t)h->md_step;
@@ -762,8 +873,9 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             // the direct build (mmx_build.hpp): the pack also keeps the per-row totals, in the counter set of this build's parity
             direct = h->slots_now && h->fused_build && h->direct_ok && h->dcount && bonded && h->fused_bonded && h->overlap_bonded;
             const int par = h->build_idx & 1;
+            if (direct) direct_claim_set(h, par);
             int *const dcnt = h->dcount + (size_t)par * ((size_t)h->maxcells + 1);
-            int *const drcl = h->drows + (size_t)par * 2 * kDirectMaxRows, *const drbig = drcl + kDirectMaxRows;
+            int *const drcl = h->drows + (size_t)par * kDirectRowSet, *const drbig = drcl + kDirectMaxRows;
             const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells, direct ? drcl : nullptr,
                              direct ? drbig : nullptr, (h->inject_fault & 64) ? 1 : 0};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
@@ -779,6 +891,22 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         else
             hipLaunchKernelGGL((k_pack<false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp,
                                h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, h->count);
+    } else if (direct_dd) { // decomposed rank, direct build: the pack counts the OWNED beads into this parity's set (keys into the slot table)
+        const int par = h->build_idx & 1;
+        direct_claim_set(h, par);
+        int *const dcnt = h->dcount + (size_t)par * ((size_t)h->maxcells + 1);
+        int *const drcl = h->drows + (size_t)par * kDirectRowSet;
+        const SlotArgs T{h->slotkeys, h->slot_cap, h->slot_cells, drcl, drcl + kDirectMaxRows, (h->inject_fault & 64) ? 1 : 0, kDirectDDRows,
+                         hmin_of(h) / edge_factor(h)};
+        GridParams *cur = h->grid + par;
+        if (mode == PACK_MOVE)
+            hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
+                               h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, dcnt,
+                               dir_args(h), RefArgs{nullptr, 0, 0.f}, h->st, T, ddg, ddo);
+        else
+            hipLaunchKernelGGL((k_pack<false, true, false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
+                               h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, dcnt,
+                               DirArgs{}, RefArgs{nullptr, 0, 0.f}, h->st, T, ddg, ddo);
     } else if (mode == PACK_MOVE)
         hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
@@ -831,10 +959,10 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         D.hmin = hm;
         D.maxcells = h->maxcells;
         D.count = h->dcount + (size_t)par * cset;
-        D.rowcl = h->drows + (size_t)par * 2 * kDirectMaxRows;
+        D.rowcl = h->drows + (size_t)par * kDirectRowSet;
         D.rowbig = D.rowcl + kDirectMaxRows;
         D.count_zero = h->dcount + (size_t)(par ^ 1) * cset;
-        D.rowcl_zero = h->drows + (size_t)(par ^ 1) * 2 * kDirectMaxRows;
+        D.rowcl_zero = h->drows + (size_t)(par ^ 1) * kDirectRowSet;
         D.rowbig_zero = D.rowcl_zero + kDirectMaxRows;
         D.keys = h->slotkeys;
         D.slot_cap = h->slot_cap;
@@ -902,10 +1030,22 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             coll_halo_exchange(h);
             prof_end(h, con, cep);
         }
-        hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
-                           h->dd_ghost_ids, h->n_all, h->st);
+        if (direct_dd) {
+            dd_ghost_count(h, gq);
+        } else
+            hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
+                               h->dd_ghost_ids, h->n_all, h->st);
     } else if (has_comm(h) && !h->dd_frozen) // every rank contributes its slice of pos4 (in place): ghosts for pairs, bonds, loops
         coll_allgather_pos4(h);
+    if (direct_dd) {
+        if (halo && h->dd_frozen) { // (measurement: the ghosts of the last exchange are counted again, nothing is exchanged)
+            int mx = 1;
+            for (int q = 0; q < h->world; ++q) mx = std::max(mx, h->dd_rcap.cap[q]);
+            dd_ghost_count(h, dim3(std::min((mx + 255) / 256, 256), h->world));
+        }
+        launch_build_direct_dd(h, *bonded, gb);
+        return;
+    }
     const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);
     if (bonded && !in_scan) enqueue_bonded(h, *bonded, false);
     if (has_nb(h) && !all_pairs(h)) {
@@ -929,7 +1069,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         // decomposed ranks on the half-shell kernel: the ghosts' clusters in a region of their own behind the owned ones
         const int split = (dd && h->n3_build && h->count_own && h->dd_split) ? 1 : 0;
         const ScanArgs sa{h->bbox_part, gb, hm, h->maxcells, h->count, h->start, h->istart, h->cstart, h->biglist, cur, next,
-                          h->count_own, split};
+                          h->count_own, dd ? hm / edge_factor(h) : 0.f, split};
         if (in_scan) { // block 0 scans, the others are the bonded pass (four virtual 256-thread blocks each)
             const int nvb = grid_beads(h->n_own);
             const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
@@ -1226,15 +1366,18 @@ int push_state(mmx_handle_s *h) {
 int direct_reset(mmx_handle_s *h) {
     if (!h->dcount) return MMX_OK;
     HIPCHK(h, hipMemsetAsync(h->dcount, 0, sizeof(int) * 2 * ((size_t)h->maxcells + 1), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->drows, 0, sizeof(int) * 4 * kDirectMaxRows, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->drows, 0, sizeof(int) * 2 * kDirectRowSet, h->stream));
+    if (h->dcount_g) HIPCHK(h, hipMemsetAsync(h->dcount_g, 0, sizeof(int) * 2 * ((size_t)h->maxcells + 1), h->stream));
     h->last_build_direct = false;
+    h->dset_dirty[0] = h->dset_dirty[1] = false;
     return MMX_OK;
 }
 
 int pull_state(mmx_handle_s *h) {
     if (h->last_build_direct) // the fullest cell of the last build (the scan-based build publishes it itself)
         hipLaunchKernelGGL(k_poll_stats, dim3(1), dim3(256), 0, h->stream,
-                           h->dcount + (size_t)h->last_direct_parity * ((size_t)h->maxcells + 1), h->gcur, h->st);
+                           h->dcount + (size_t)h->last_direct_parity * ((size_t)h->maxcells + 1), h->gcur, h->st,
+                           (h->world > 1 && h->dcount_g) ? h->dcount_g + (size_t)h->last_direct_parity * ((size_t)h->maxcells + 1) : nullptr);
     HIPCHK(h, hipMemcpyAsync(h->st_host, h->st, sizeof(MinState), hipMemcpyDeviceToHost, h->stream));
     const bool halo = use_halo(h) && h->dd_lists_valid && h->dd_cnt_host;
     if (halo)
@@ -1324,9 +1467,10 @@ int kernel_error_rc(mmx_handle_s *h) {
 // sort's fill until a later poll.  Called with the stream idle.  grow: after an evaluation that did not fit its cut.
 constexpr int kSlotsPerBead = 32;
 int ensure_slots(mmx_handle_s *h, bool grow) {
-    if (!h->cell_slots || h->world > 1 || h->n_own != h->n || h->last_ncells <= 0 || h->last_max_per_cell <= 0) return MMX_OK;
+    if (!h->cell_slots || h->last_ncells <= 0 || h->last_max_per_cell <= 0) return MMX_OK;
     if (!h->slotkeys) {
-        h->slot_total = (size_t)kSlotsPerBead * (size_t)std::max(h->n_all, 4096);
+        // (decomposed ranks: a slice of owned beads and about as many ghosts at most)
+        h->slot_total = (size_t)kSlotsPerBead * (size_t)std::max(h->world > 1 ? 2 * h->slice : h->n_all, 4096);
         if (h->slot_total * 8 > ((size_t)1 << 33)) { // (16.7 M beads: 4.3 GB -- fine on this part; beyond: the fill stays)
             h->cell_slots = 0;
             return MMX_OK;
@@ -1704,6 +1848,11 @@ int prepare(mmx_handle_s *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream)); // h->Q is pageable host memory that may change afterwards
     }
     h->dd_rc = MMX_OK;
+    {   // (evaluations the device skipped at the end of the last call -- the minimizer was done -- advanced the host's build parity:
+        //  which counter set the next pack finds clean is not known any more)
+        const int rc_d = direct_reset(h);
+        if (rc_d) return rc_d;
+    }
     if (h->fsort_dirty && h->fsort) { // see mmx_handle_s::fsort_dirty
         HIPCHK(h, hipMemsetAsync(h->fsort, 0, sizeof(float) * 3 * (size_t)h->fstride, h->stream));
         h->fsort_dirty = false;

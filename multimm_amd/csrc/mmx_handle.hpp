@@ -228,8 +228,13 @@ struct mmx_handle_s {
     unsigned tail_epoch = 0u;                    // tag of the last k_tail launch's partials (TailArgs::epoch)
     int fused_tail = 1;                          // option: unsort + history + decision in one launch (k_tail); 0: the separate kernels (A/B)
     int *dcount = nullptr;                       // direct build: two sets of cell populations [2][maxcells + 1] ...
-    int *drows = nullptr;                        // ... and of row totals [2][2][kDirectMaxRows] (clusters, large cells), alternating with the build's parity
+    int *drows = nullptr;                        // ... and of row totals [2][3][kDirectMaxRows] (clusters, large cells, ghost clusters), alternating with the build's parity
+    int *dcount_g = nullptr;                     // decomposed ranks: the ghosts' populations [2][maxcells + 1]
     int direct_slots[4] = {0, 0, 0, 0};          // workgroups of k_build_direct<CAP, N3> resident at once (occupancy x CUs), per instance
+    int direct_dd_slots[2] = {0, 0};             // ... of k_build_direct_dd<N3>
+    bool dset_dirty[2] = {false, false};         // the direct build's counter set of that parity holds the counts of an earlier build
+                                                 // (a direct build leaves its own set behind and zeroes the other one; builds through
+                                                 // the scan in between flip the parity without touching either)
     bool direct_ok = true;                       // this call's grids have fitted the direct build so far (nx <= 64, rows <= kDirectMaxRows)
     bool last_build_direct = false;              // the last enqueued full build was a direct one (the polls fetch its fullest cell: k_poll_stats)
     int last_direct_parity = 0;

@@ -543,11 +543,15 @@ __global__ __launch_bounds__(1024) void k_decide(const CtlArgs A, const double *
 // which a bead has moved beyond half the skin since the ghost lists were built (k_dd_displacement), 13: ranks whose force
 // kernel failed (MinState::kernel_error), 14: ranks with a ghost list longer than its message (k_dd_build_lists).
 constexpr int kSumStale = 12, kSumKernelError = 13, kSumOverflow = 14;
+// 15: ranks whose direct cell build was void (MinState::cell_stale): + 1 per rank with a slot row too short, + 1024 per rank with a
+// grid beyond the build (64 ranks at most: the two counts do not mix)
+constexpr int kSumCellVoid = 15;
 __device__ __forceinline__ double flag_or_sum(const MinState *__restrict__ st, const double *s_out, int t) {
     if (t < P_NSLOTS) return s_out[t];
     if (t == kSumStale) return st->dd_stale ? 1.0 : 0.0;
     if (t == kSumKernelError) return st->kernel_error ? 1.0 : 0.0;
     if (t == kSumOverflow) return st->dd_overflow ? 1.0 : 0.0;
+    if (t == kSumCellVoid) return ((st->cell_stale & 2) ? 1.0 : 0.0) + ((st->cell_stale & 4) ? 1024.0 : 0.0);
     return 0.0;
 }
 
@@ -603,9 +607,11 @@ __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const doub
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
-    if (st->sums[kSumKernelError] <= 0.5 && (st->sums[kSumStale] > 0.5 || st->sums[kSumOverflow] > 0.5)) { // a ghost is missing somewhere: this evaluation never happened (every rank sees the same sum)
+    if (st->sums[kSumKernelError] <= 0.5 && (st->sums[kSumStale] > 0.5 || st->sums[kSumOverflow] > 0.5 || st->sums[kSumCellVoid] > 0.5)) { // a ghost is missing somewhere, or a rank's cell build was void: this evaluation never happened (every rank sees the same sums)
+        const double cv = st->sums[kSumCellVoid];
         st->halt_phase = st->phase;
-        st->halt_reason = (st->sums[kSumStale] > 0.5 ? 1 : 0) | (st->sums[kSumOverflow] > 0.5 ? 2 : 0);
+        st->halt_reason = (st->sums[kSumStale] > 0.5 ? 1 : 0) | (st->sums[kSumOverflow] > 0.5 ? 2 : 0) |
+                          (cv - 1024.0 * floor(cv / 1024.0) > 0.5 ? 8 : 0) | (cv >= 1023.5 ? 16 : 0);
         st->phase = PH_HALT;
         st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
         return;
