@@ -347,15 +347,18 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         const bool in_table = c < D.slot_cells;
         unsigned long long v[kWaveCellMax / 64];
 #pragma unroll
-        for (int h = 0; h < kWaveCellMax / 64; ++h) { // (whole vectors of the cell's row of the table: nothing past it is touched)
-            v[h] = ~0ull;
-            if (in_table && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
-        }
+        for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = ~0ull;
+        if (in_table) v[0] = D.keys[(size_t)c * D.slot_cap + lane]; // (slot_cap >= 64: the first 64 keys of the row are there)
         const int cnt = __shfl(cnt_l, x, 64);
         const int cb = s_cl[row] + direct_row_before((cnt_l + 7) >> 3, lane, x);
         if (lane == 0) D.cstart[c] = min(cb, D.cap_clusters);
         if (cnt > kWaveCellMax || cnt == 0) continue; // (larger: pass B)
         if (!in_table || cnt > D.slot_cap) continue; // (a void evaluation: k_pack flagged it)
+        if (cnt > 64) { // the rest of a larger cell's keys: a second load round, for those cells only
+#pragma unroll
+            for (int h = 1; h < kWaveCellMax / 64; ++h)
+                if (h * 64 < cnt && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
+        }
 #pragma unroll
         for (int h = 0; h < kWaveCellMax / 64; ++h)
             if (h * 64 + lane >= cnt) v[h] = ~0ull;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         } else if (cnt <= 128) {
             wave_sort_keys<2>(v, lane);
             direct_emit_wave<2>(D, st, v, c, cnt, cb, cap_slots, lane);
-        } else {
+        } else { // (a wave sorting 512 keys in 8 registers was measured too: the launch got 6 us longer than with those cells in pass B)
             wave_sort_keys<4>(v, lane);
             direct_emit_wave<4>(D, st, v, c, cnt, cb, cap_slots, lane);
         }
@@ -706,10 +709,8 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         const bool in_table = c < D.slot_cells;
         unsigned long long v[kWaveCellMax / 64];
 #pragma unroll
-        for (int h = 0; h < kWaveCellMax / 64; ++h) {
-            v[h] = ~0ull;
-            if (in_table && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
-        }
+        for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = ~0ull;
+        if (in_table) v[0] = D.keys[(size_t)c * D.slot_cap + lane];
         const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64), k = ko + kg;
         const int cb = s_cl[row] + direct_row_before(SPLIT ? (ko_l + 7) >> 3 : ((ko_l + 7) >> 3) + ((kg_l + 7) >> 3), lane, x);
         const int cg = SPLIT ? tot_cl + s_clg[row] + direct_row_before((kg_l + 7) >> 3, lane, x) : cb + ((ko + 7) >> 3);
@@ -719,6 +720,11 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         }
         if (k > kWaveCellMax || k == 0) continue;
         if (!in_table || k > D.slot_cap) continue; // (a void evaluation: the counting kernels flagged it)
+        if (k > 64) {
+#pragma unroll
+            for (int h = 1; h < kWaveCellMax / 64; ++h)
+                if (h * 64 < k && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
+        }
 #pragma unroll
         for (int h = 0; h < kWaveCellMax / 64; ++h)
             if (h * 64 + lane >= k) v[h] = ~0ull;

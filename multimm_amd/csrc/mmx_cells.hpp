@@ -141,6 +141,8 @@ struct RefArgs {
     float *xref;
     int mode;
     float thr2;
+    int dd = 0; // decomposed ranks: xref = where the owned beads were when the ghost lists were built (dd_rebuild_every > 1); a bead
+                // beyond half the skin raises MinState::dd_stale (k_dd_displacement's job, without its launch and its pass over x)
 };
 // Slot table (trial moves of a single-domain minimization): the pack itself writes the bead's 64-bit sort key into its cell's
 // slot -- keys[cell * cap + rank in cell], cap from the largest cell the last poll saw -- which is what k_cell_fill would
@@ -260,8 +262,12 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         }
         const float m = wave_max(d2);
         if ((threadIdx.x & 63) == 0 && m > 0.f) {
-            if (__float_as_uint(m) > stw->disp2_bits) atomicMax(&stw->disp2_bits, __float_as_uint(m));
-            if (R.mode == 1 && m > R.thr2) atomicOr(&stw->cell_stale, 1);
+            if (R.dd) {
+                if (R.mode == 1 && m > R.thr2) stw->dd_stale = 1;
+            } else {
+                if (__float_as_uint(m) > stw->disp2_bits) atomicMax(&stw->disp2_bits, __float_as_uint(m));
+                if (R.mode == 1 && m > R.thr2) atomicOr(&stw->cell_stale, 1);
+            }
         }
     }
     if (COUNT) { // the owned beads (single domain: all of them, bead == i; decomposed ranks with the direct build: the ghosts are

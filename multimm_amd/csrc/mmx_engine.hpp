@@ -663,7 +663,7 @@ int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done:
                        h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st,
                        sync ? nullptr : h->dd_cntmat); // (on the stream: + the lengths of the lists in use until now, of every
                                                       // rank: what the next poll sizes the messages by)
-    if (h->dd_every > 1) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
+    if (h->dd_every > 1 && !h->dd_ref_in_pack) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
                          // cleared here: the minimizer halts in the very evaluation that raises it, and an MD call must still
                          // see at its next poll that one of its steps ran on stale lists)
         HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
@@ -813,6 +813,13 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     if (occ_in_pack) (void)hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream);
     const DDGrid *const ddg = occ_in_pack ? h->dd_grid : nullptr;
     unsigned long long *const ddo = occ_in_pack ? h->dd_occ : nullptr;
+    // decomposed ranks, lists kept over dd_every > 1 evaluations: the trial move itself checks the owned beads against where they
+    // were when the lists were built (and records that place when this evaluation rebuilds them)
+    const bool ref_in_pack = dd && h->dd_every > 1 && use_halo(h) && !h->dd_frozen && h->dd_xref && mode == PACK_MOVE &&
+                             (redecomp != 0 || h->dd_lists_valid);
+    const float dd_half = 0.5f * h->dd_skin_cur;
+    const RefArgs RD = ref_in_pack ? RefArgs{h->dd_xref, redecomp ? 3 : 1, dd_half * dd_half, 1} : RefArgs{nullptr, 0, 0.f};
+    h->dd_ref_in_pack = ref_in_pack;
     // kept cell structure (see mmx_handle_s::cell_reuse): trial moves of a single-domain minimization only
     // (and only on grids wider than the cutoff: without a skin there is nothing to keep, and the reference costs 24 B / bead)
     const bool tracked = fuse_count && mode == PACK_MOVE && h->cell_reuse && !h->capturing && !h->use_graph && h->cell_xref &&
@@ -902,7 +909,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         if (mode == PACK_MOVE)
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, dcnt,
-                               dir_args(h), RefArgs{nullptr, 0, 0.f}, h->st, T, ddg, ddo);
+                               dir_args(h), RD, h->st, T, ddg, ddo);
         else
             hipLaunchKernelGGL((k_pack<false, true, false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell, dcnt,
@@ -910,8 +917,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     } else if (mode == PACK_MOVE)
         hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
-                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h), RefArgs{nullptr, 0, 0.f},
-                           (MinState *)nullptr, SlotArgs{nullptr, 0, 0}, ddg, ddo);
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h), RD,
+                           ref_in_pack ? h->st : (MinState *)nullptr, SlotArgs{nullptr, 0, 0}, ddg, ddo);
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr, (int *)nullptr,
@@ -1014,7 +1021,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     if (halo && h->dd_frozen) {
         // nothing to exchange: the ghosts of the last exchange are binned again
     } else if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
-        if (h->dd_every > 1 && !redecomp) { // lists older than this evaluation: still within the skin?
+        if (h->dd_every > 1 && !redecomp && !h->dd_ref_in_pack) { // lists older than this evaluation: still within the skin?
             const float half = 0.5f * h->dd_skin_cur;
             hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
                                half * half, h->st);
