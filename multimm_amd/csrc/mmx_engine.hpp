@@ -126,7 +126,7 @@ constexpr float kWideCellFactor = 1.12f;
 constexpr int kReuseMax = 16;            // evaluations a kept cell structure serves at most
 constexpr int kWideCellsFromBeads = 20000;
 constexpr double kN3MinBeadsPerCell = 20.0;
-constexpr int kN3MinBeads = 100000;
+constexpr int kN3MinBeads = 70000, kN3MinBeadsGauss = 55000; // (round 5: the unsort launch is gone, the crossover moved down -- see use_n3)
 
 // Beads in this handle's cell list: its owned beads and, on a decomposed rank, the ghost slots of its halo.
 int local_beads(const mmx_handle_s *h) {
@@ -156,8 +156,11 @@ bool use_n3(const mmx_handle_s *h) {
     // (the persistent workgroups of the half-shell kernel want several work items each; its path costs one small launch
     // more.)  Below 20 beads per cell nothing was measured: the full-shell kernel, which needs no atomics, stays there;
     // the last poll's cell count decides.  Both kernels compute the same forces to rounding.
+    // Round 5 (k_tail took the unsort launch and its pass over g away; iterations/s over the first 200 iterations, half shell against
+    // full shell): EV + compartment Gaussians 55 000 beads +5.8 %, 62 000 +5.7 %, 70 000 +9.5 %, 85 000 +9.8 %; EV alone 50 000 -2 %,
+    // 55 000 +2.8 %, 62 000 -2.3 % (noise level): from 55 000 beads with the Gaussians, from 70 000 without.
     const int nl = local_beads(h);
-    if (nl < kN3MinBeads) return false;
+    if (nl < (h->P.use_gauss ? kN3MinBeadsGauss : kN3MinBeads)) return false;
     return h->last_ncells <= 0 || (double)nl >= kN3MinBeadsPerCell * (double)h->last_ncells;
 }
 

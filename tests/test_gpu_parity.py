@@ -240,8 +240,8 @@ def test_half_shell_window_passes_are_records_of_their_own():
 
 
 def test_pair_kernel_choice_follows_size_and_cell_occupancy():
-    """Default options (use_n3 in mmx_engine.hpp): systems below 100 000 beads always take the full-shell kernel, larger ones
-    the half-shell kernel as long as the last poll saw >= 20 beads per grid cell.  Whatever is picked, a minimization ends
+    """Default options (use_n3 in mmx_engine.hpp): systems below 55 000 beads (70 000 without the compartment Gaussians) always take
+    the full-shell kernel, larger ones the half-shell kernel as long as the last poll saw >= 20 beads per grid cell.  Whatever is picked, a minimization ends
     where a run pinned to either kernel ends."""
     with engine_for(synthetic_system("gw_200k", n_beads=30000, **ALL_ON)) as eng:
         eng.minimize(tolerance=0.0, max_iters=20)
