@@ -129,6 +129,21 @@ def replicas_per_gpu_leg(workload: str, n_beads, cutoff: float, device: int, k: 
         return {"error": repr(exc)}
 
 
+def committed_traffic(args, n: int):
+    """(bytes per launch, where from) of the pair kernel for this run's workload from profiles/nb_traffic.json, or (None, reason)."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))
+    except Exception as exc:  # noqa: BLE001
+        return None, f"profiles/nb_traffic.json unreadable: {exc!r}"
+    ent = tab.get(args.workload)
+    if ent is None:
+        return None, f"no committed PMC pass for workload {args.workload} (have: {sorted(k for k in tab if not k.startswith('_'))})"
+    if args.n_beads or args.cutoff != 0.6 or args.jitter != 0.0:
+        return None, "no committed PMC pass for this size / cutoff / start (the committed ones: preset size, 0.6 nm, lattice start)"
+    return ent["bytes_per_launch"], (f"committed rocprofv3 --pmc passes (profiles/nb_traffic.json: {ent['kernel']}, `{ent['command']}`; "
+                                     f"2 x FETCH_SIZE + WRITE_SIZE)")
+
+
 def cpu_baseline(system, budget_s: float) -> dict | None:
     """CPU baseline on this box's host cores, bounded sample.  North star: OpenMM's CPU platform -- probed at run time
     (oracle/openmm_probe.py): when ``import openmm`` works, the same System (built by this repo's host code) is
@@ -529,14 +544,12 @@ def main():
         roofline = None
         if nb_us:
             achieved = NB_BYTES_PER_BEAD * n / (nb_us * 1e-6) / 1e9
-            traffic = args.nb_traffic_bytes
-            if traffic is None and args.cutoff > 0 and n == 200000:
-                # per-launch HBM bytes of the same kernel on the same workload from the committed
-                # rocprofv3 --pmc passes (PMC collection cannot share a run with the timed region)
-                try:
-                    traffic = json.load(open(os.path.join(ROOT, "profiles", "nb_traffic.json")))["bytes_per_launch"]
-                except Exception:
-                    traffic = None
+            traffic, traffic_note = args.nb_traffic_bytes, None
+            if traffic is None:
+                # per-launch HBM bytes of the same kernel on the same workload from the committed rocprofv3 --pmc passes (PMC
+                # collection cannot share a run with the timed region): profiles/nb_traffic.json, one entry per workload
+                # (scripts/r5_traffic.sh); anything else -- another size, cutoff or start -- has no committed pass: null + why
+                traffic, traffic_note = committed_traffic(args, n)
             # the cell-list path picks its pair kernel per state (DESIGN_HISTORY.md 5c): name the one that ran, and how often
             n3_share = (eng.get_option("n3_launches") - n3_before) / max(st.kernel_launches[K_NONBONDED], 1)
             kname = ("k_nb_allpairs" if args.cutoff <= 0 else "k_nb_n3" if n3_share > 0.99 else "k_nb_clusters_j" if n3_share < 0.01
@@ -546,8 +559,8 @@ def main():
             # (algorithmic bytes / launch time against 8 TB/s); valu_view prices the same launch against the fp32 peak.
             roofline = {"bound": "valu+latency", "kernel": kname,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc pass (profiles/nb_traffic.json)"
-                        if traffic is not None and args.nb_traffic_bytes is None else "command line" if traffic is not None else None,
+                        "traffic": traffic, "traffic_source": traffic_note if args.nb_traffic_bytes is None else "command line",
+                        "traffic_over_algorithmic": (traffic / (NB_BYTES_PER_BEAD * n)) if traffic else None,
                         "launch_us": nb_us, "samples": int(st.kernel_samples[K_NONBONDED]),
                         "note": "achieved/peak/frac = HBM view (32 B/bead algorithmic bytes over the launch time); the kernel "
                                 "itself is bound by VALU issue and latency, see valu_view and its wait counters"}
@@ -559,12 +572,18 @@ def main():
                                          "frac": tf / VALU_PEAK_TFLOPS, "unique_pairs_within_cutoff": pairs,
                                          "pair_candidates": census["pair_candidates"],
                                          "flop_per_pair": FLOP_PER_PAIR}
-                if n == 200000:  # instruction counters of the half-shell kernel from the committed PMC pass
+                # instruction counters of the half-shell kernel from the committed PMC passes: gw_200k at its lattice state only
+                if args.workload == "gw_200k" and n == 200000 and args.cutoff == 0.6 and args.jitter == 0.0:
                     try:
                         roofline["valu_view"]["issue_from_committed_profile"] = json.load(
                             open(os.path.join(ROOT, "profiles", "nb_valu.json")))
-                    except Exception:
-                        pass
+                        roofline["valu_view"]["instruction_budget"] = "profiles/r05/n3_instruction_budget.txt"
+                    except Exception as exc:  # noqa: BLE001
+                        roofline["valu_view"]["issue_from_committed_profile"] = None
+                        roofline["valu_view"]["issue_note"] = repr(exc)
+                else:
+                    roofline["valu_view"]["issue_from_committed_profile"] = None
+                    roofline["valu_view"]["issue_note"] = "no committed PMC pass for this workload / state (gw_200k, 0.6 nm, lattice start only)"
         kern = {k: v for k, v in d["kernel_us_mean"].items() if v}
         # default: backbone + loops + confinement are ONE pass (38 B/bead + 64 B/loop) that rides in the launch of the
         # cell scan, i.e. inside the "cell_build" slot, which also forms the L-BFGS direction (168 B/bead) in its pack;

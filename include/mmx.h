@@ -9,7 +9,9 @@
  * Conventions
  *   - Units: nm, kJ/mol, rad (OpenMM's defaults, i.e. what the reference's bare floats mean).
  *   - Every function returns int: MMX_OK (0) or a negative MMX_ERR_* class; nothing throws or
- *     aborts across the ABI.  mmx_last_error(h) gives the message of the last failure.
+ *     aborts across the ABI.  mmx_last_error(h) gives the message of the last failure.  On the device side every offset
+ *     derived from counters is checked against its array before it is used as an address (KERR_BOUNDS), every wait between
+ *     workgroups is bounded (KERR_*_WAIT / KERR_N3_SPIN): a corrupt or stale state ends in MMX_ERR_STATE, not in a fault.
  *   - The caller owns all input buffers (host memory); the library copies before returning.
  *     Output buffers are caller-allocated host memory.
  *   - A handle is bound to one GPU and one HIP stream; it is not thread-safe.  Distinct handles
@@ -241,6 +243,19 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     same minimization (+1-2 % iterations/s).  A cell that outgrows its row voids the evaluation, which
  *                     is repeated with longer rows ("cell_slot_halts"; the repeat bins on another grid: from there on
  *                     the run differs from the fill path by rounding); 0: k_cell_fill after the scan               1
+ * "fused_tail"        1: what follows the pair kernel of a minimizer's evaluation is ONE launch (k_tail): the half-shell
+ *                     kernel's forces leave their cluster slots through a bead -> slot table, the history pass runs with the
+ *                     four column groups of k_history sharing x / xp / gp / g through LDS (same summation order: bitwise the
+ *                     same partials), and the workgroup with the highest index folds the others' TAGGED partials -- it polls
+ *                     the values themselves -- and decides (line search, direction coefficients); decomposed ranks: it
+ *                     forms the all-reduce's input.  0: k_nb_n3_unsort, k_history, k_decide as separate launches (A/B)   1
+ * "fused_build"       1: the cell build of a trial move is ONE launch behind the pack (k_build_direct; decomposed ranks:
+ *                     k_dd_unpack_count + k_build_direct_dd): the pack keeps per-row cluster totals, every workgroup finds its
+ *                     offsets by itself (no scan stage), cells of <= 256 beads are sorted by one wave in registers, the bonded
+ *                     pass and the half-shell kernel's work items ride along.  Same clusters in the same order as the
+ *                     scan-based build (bitwise the same `deterministic` runs).  Needs "cell_slots"; grids beyond 64 cells per
+ *                     row or 2048 (decomposed: 1024) rows void one evaluation and fall back.  0: the scan-based build (A/B)   1
+ * "direct_builds"     (get only) full builds enqueued through it
  * "cell_edge_auto"    1: once a poll finds fewer than 32 beads per cutoff-sized grid cell (systems of >= 20 000 beads) the grid
  *                     switches to cells 1.12 x wider (same results: the box tests are exact; the in-cell ordering is a
  *                     latency chain per cell, fewer and fuller cells take 8-10 us off the cell build for +2 us of pair
@@ -293,7 +308,10 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     bit 2 sizes the halo messages of a decomposed run without slack, so that any growth of a
  *                     ghost list exercises the halt-and-repeat protocol; bit 3 gives a kept cell structure ("cell_reuse")
  *                     a skin of nothing, so that every evaluation on one is voided and repeated after a full build; bit 4 cuts the
- *                     slot table ("cell_slots") in rows of 64 slots at every poll: crowded cells overflow, halt, repeat    0
+ *                     slot table ("cell_slots") in rows of 64 slots at every poll: crowded cells overflow, halt, repeat;
+ *                     bit 5 makes k_tail's folding workgroup give up before its first poll (MMX_ERR_STATE); bit 6 makes the
+ *                     direct build find its grid too large (one void evaluation, then the scan-based build)          0
+ * "slot_cap", "slot_cells", "cell_edge"   (get only) rows of the slot table as cut at the last poll; cell edge of the last build
  */
 int mmx_set_option(mmx_handle h, const char *key, double value);
 int mmx_get_option(mmx_handle h, const char *key, double *value);
