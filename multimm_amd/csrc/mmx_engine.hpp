@@ -956,7 +956,9 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             h->direct_slots[vi] = per_cu * std::max(h->n_cus, 1);
         }
         const int nbr = (nvb + 1) / 2;
-        const int go = std::max(256, std::min(2048, h->direct_slots[vi] - nib - nbr));
+        // (large grids: a wave should not walk more than ~3 cells one after the other -- the prologue then amortises over a
+        //  second round of workgroups: gw_1m, 39 000 cells)
+        const int go = std::max(std::max(256, std::min(2048, h->direct_slots[vi] - nib - nbr)), std::min(4096, h->last_ncells / 12));
         const size_t cset = (size_t)h->maxcells + 1;
         const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
         const bool loops_on = h->n_rows > 0 && h->lstart;

@@ -643,7 +643,8 @@ struct TailArgs {
     unsigned epoch;     // tag of this launch's partials (rows_publish): never 0, different from the previous launch's
     int spin_limit;     // polls before the folding workgroup gives up (tests inject 0)
 };
-constexpr int kTailKeep = 4; // tiles of a workgroup whose merged gradient stays in LDS between the merge and the history pass
+constexpr int kTailKeep = 12; // tiles of a workgroup whose merged gradient stays in LDS between the merge and the history pass
+                            // (48 KB: every tile of systems up to a million beads -- beyond, the rest is read back from g)
 template <bool UNSORT, bool SOLO>
 __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict__ x, const float4 *__restrict__ xp,
                                                float4 *g, const float4 *__restrict__ gp,
