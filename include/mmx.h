@@ -255,6 +255,8 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     pass and the half-shell kernel's work items ride along.  Same clusters in the same order as the
  *                     scan-based build (bitwise the same `deterministic` runs).  Needs "cell_slots"; grids beyond 64 cells per
  *                     row or 2048 (decomposed: 1024) rows void one evaluation and fall back.  0: the scan-based build (A/B)   1
+ * "key32"             1: the direct build of systems of <= 2^20 beads sorts 32-bit keys (12-bit Hilbert index << 20 | bead: the same
+ *                     order as the 64-bit ones, half the shuffles); 0: 64-bit keys (A/B)                                 1
  * "direct_builds"     (get only) full builds enqueued through it
  * "cell_edge_auto"    1: once a poll finds fewer than 32 beads per cutoff-sized grid cell (systems of >= 20 000 beads) the grid
  *                     switches to cells 1.12 x wider (same results: the box tests are exact; the in-cell ordering is a

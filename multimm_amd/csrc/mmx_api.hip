@@ -587,6 +587,7 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
         HIPCHK(h, hipMemsetAsync(h->rows, 0, sizeof(double) * (size_t)MMX_NROWSUM * kPartStride, h->stream));
     }
     else if (k == "fused_build") h->fused_build = value != 0.0;
+    else if (k == "key32") h->key32 = value != 0.0;
     else if (k == "use_graph") h->use_graph = value != 0.0;
     else if (k == "dd_halo") h->dd_halo = value != 0.0;
     else if (k == "dd_skin") {
@@ -630,6 +631,7 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "overlap_bonded") *value = h->overlap_bonded;
     else if (k == "fused_tail") *value = h->fused_tail;
     else if (k == "fused_build") *value = h->fused_build;
+    else if (k == "key32") *value = h->key32;
     else if (k == "use_graph") *value = h->use_graph;
     else if (k == "inject_fault") *value = h->inject_fault;
     else if (k == "n3_launches") *value = (double)h->n3_launches;   // read-only: how often the half-shell kernel ran

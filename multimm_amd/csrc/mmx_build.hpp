@@ -23,6 +23,7 @@
 // Limits: nx <= 64 (one lane per cell of a row), ny * nz <= kDirectMaxRows; a grid beyond them voids the evaluation (k_pack)
 // and the host falls back to the scan-based build.
 #pragma once
+#include <type_traits>
 #include "mmx_bonded.hpp"
 #include "mmx_nonbonded_n3.hpp"
 
@@ -123,8 +124,8 @@ __device__ __forceinline__ int direct_row_before(const int cl_lane, const int la
 
 // Bitonic sort of 64 * H keys held by ONE wave, H per lane (element h * 64 + lane in v[h]; the first H registers of the array):
 // partners at distance < 64 by wave shuffles, at 64 / 128 in another register of the same lane.  Ascending.
-template <int H, int HMAX>
-__device__ __forceinline__ void wave_sort_keys(unsigned long long (&v)[HMAX], const int lane) {
+template <int H, int HMAX, class KeyT>
+__device__ __forceinline__ void wave_sort_keys(KeyT (&v)[HMAX], const int lane) {
     constexpr int N = 64 * H;
 #pragma unroll
     for (int k = 2; k <= N; k <<= 1) {
@@ -138,7 +139,7 @@ __device__ __forceinline__ void wave_sort_keys(unsigned long long (&v)[HMAX], co
                 for (int h = 0; h < H; ++h) {
                     if ((h & dh) == 0 && h + dh < H) {
                         const bool up = (((h * 64 + lane) & k) == 0);
-                        const unsigned long long a = v[h], b = v[h + dh];
+                        const KeyT a = v[h], b = v[h + dh];
                         if ((a > b) == up) {
                             v[h] = b;
                             v[h + dh] = a;
@@ -148,7 +149,7 @@ __device__ __forceinline__ void wave_sort_keys(unsigned long long (&v)[HMAX], co
             } else {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const unsigned long long o = __shfl_xor(v[h], j, 64);
+                    const KeyT o = __shfl_xor(v[h], j, 64);
                     const bool keep_min = ((lane & j) == 0) == (((h * 64 + lane) & k) == 0);
                     v[h] = keep_min ? (v[h] < o ? v[h] : o) : (v[h] < o ? o : v[h]);
                 }
@@ -158,16 +159,17 @@ __device__ __forceinline__ void wave_sort_keys(unsigned long long (&v)[HMAX], co
 }
 
 // Cluster slots of one sorted cell from the keys in registers: entry e = h * 64 + lane of the cell's clusters is lane's v[h].
-template <int H, int HMAX, class DA>
-__device__ __forceinline__ void direct_emit_wave(const DA &D, MinState *__restrict__ st, const unsigned long long (&v)[HMAX],
+template <int H, int HMAX, class DA, class KeyT>
+__device__ __forceinline__ void direct_emit_wave(const DA &D, MinState *__restrict__ st, const KeyT (&v)[HMAX],
                                                  const int c, const int cnt, const int cb, const int cap_slots, const int lane) {
+    constexpr unsigned kBeadMask = sizeof(KeyT) == 4 ? 0xfffffu : 0xffffffffu;
     const int ncl = (cnt + 7) >> 3;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         const int e = h * 64 + lane;
         if (e < ncl * 8) {
             bool real = e < cnt;
-            int bead = real ? (int)(unsigned)(v[h] & 0xffffffffull) : -1;
+            int bead = real ? (int)((unsigned)v[h] & kBeadMask) : -1;
             if (real && (unsigned)bead >= (unsigned)D.n_beads) { // (a key that is no bead: counters and keys of different builds)
                 atomicOr(&st->kernel_error, (int)KERR_BOUNDS);
                 real = false;
@@ -209,10 +211,14 @@ __device__ __forceinline__ void direct_emit_wave(const DA &D, MinState *__restri
     }
 }
 
-template <int CHUNK, int CAP, bool N3>
+template <int CHUNK, int CAP, bool N3, bool KEY32 = false>
 __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinState *__restrict__ st, const FFParams P,
                                                        const BondedArgs B) {
     if (st->phase >= PH_DONE) return;
+    // KEY32 (systems of <= 2^20 beads): the pack wrote 32-bit keys (12-bit Hilbert index << 20 | bead) -- the same order as the
+    // 64-bit ones, half the shuffles and simpler compares in every stage of the sorts
+    using KeyT = typename std::conditional<KEY32, unsigned, unsigned long long>::type;
+    const KeyT *const keys = reinterpret_cast<const KeyT *>(D.keys);
     __shared__ unsigned long long s_buf[CAP]; // order: the block sort; item builders: the waves' cluster-offset scratch
     __shared__ int s_cl[kDirectMaxRows + 1], s_big[kDirectMaxRows + 1];
     __shared__ double s_w[4];
@@ -345,10 +351,10 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         // one load round: the row's populations (lane = cell) and -- at an address that needs no offset -- the cell's keys
         const int cnt_l = lane < nx ? D.count[row * nx + lane] : 0;
         const bool in_table = c < D.slot_cells;
-        unsigned long long v[kWaveCellMax / 64];
+        KeyT v[kWaveCellMax / 64];
 #pragma unroll
-        for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = ~0ull;
-        if (in_table) v[0] = D.keys[(size_t)c * D.slot_cap + lane]; // (slot_cap >= 64: the first 64 keys of the row are there)
+        for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = (KeyT)~0ull;
+        if (in_table) v[0] = keys[(size_t)c * D.slot_cap + lane]; // (slot_cap >= 64: the first 64 keys of the row are there)
         const int cnt = __shfl(cnt_l, x, 64);
         const int cb = s_cl[row] + direct_row_before((cnt_l + 7) >> 3, lane, x);
         if (lane == 0) D.cstart[c] = min(cb, D.cap_clusters);
@@ -357,11 +363,11 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         if (cnt > 64) { // the rest of a larger cell's keys: a second load round, for those cells only
 #pragma unroll
             for (int h = 1; h < kWaveCellMax / 64; ++h)
-                if (h * 64 < cnt && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
+                if (h * 64 < cnt && h < kvec) v[h] = keys[(size_t)c * D.slot_cap + h * 64 + lane];
         }
 #pragma unroll
         for (int h = 0; h < kWaveCellMax / 64; ++h)
-            if (h * 64 + lane >= cnt) v[h] = ~0ull;
+            if (h * 64 + lane >= cnt) v[h] = (KeyT)~0ull;
         if (cnt <= 64) {
             if (cnt > 1) wave_sort_keys<1>(v, lane);
             direct_emit_wave<1>(D, st, v, c, cnt, cb, cap_slots, lane);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         const int cb = s_cl[row] + direct_row_before((cnt_l + 7) >> 3, lane, x);
         if (threadIdx.x == 0) D.cstart[c] = min(cb, D.cap_clusters);
         if (c >= D.slot_cells || cnt > D.slot_cap) continue; // (a void evaluation: k_pack flagged it)
-        const unsigned long long *kp = D.keys + (size_t)c * D.slot_cap;
+        const KeyT *kp = keys + (size_t)c * D.slot_cap;
         __syncthreads(); // s_buf free (emit of the previous cell has read it)
         if (cnt <= 1024) { // keys in registers, <= 3 exchanges through LDS
             int n2 = 128;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
             while (n2 < cnt) n2 <<= 1;
             for (int q = threadIdx.x; q < n2; q += 256) {
                 unsigned long long kq = ~0ull;
-                if (q < cnt) kq = kp[q];
+                if (q < cnt) kq = widen_key(kp[q]);
                 s_buf[q] = kq;
             }
             __syncthreads();
@@ -452,9 +458,13 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
             continue;
         }
         // above CAP: arrival order (still correct, not bitwise reproducible), straight from the slot table
+        if (KEY32) { // (its rows hold 32-bit keys: no place to widen a cell that large -- one void evaluation, then the scan-based build)
+            if (threadIdx.x == 0) atomicOr(&st->cell_stale, 4);
+            continue;
+        }
         if (threadIdx.x == 0) atomicAdd(&st->order_fallbacks, 1);
-        emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own, kp, D.sbead, D.slot_of,
-                      cap_slots, st, D.n_beads);
+        emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own,
+                      reinterpret_cast<const unsigned long long *>(kp), D.sbead, D.slot_of, cap_slots, st, D.n_beads);
     }
     BUILD_DONE_STAMP();
 }

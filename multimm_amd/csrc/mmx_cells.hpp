@@ -157,6 +157,7 @@ struct SlotArgs {
     int force_void = 0;                      // tests (inject_fault bit 6): behave as if the grid were beyond the direct build
     int max_rows = kDirectMaxRows;           // rows (ny * nz) the build that follows can take
     float dd_margin = -1.f;                  // decomposed ranks: the cutoff the grid box was grown by (>= 0: record the owned beads' excess)
+    int key32 = 0;                           // single domain, <= 2^20 beads: 32-bit keys (12-bit Hilbert index << 20 | bead): same order, half the sort
 };
 
 template <bool MOVE, bool COUNT = false, bool DIR = false>
@@ -299,8 +300,11 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
             if ((threadIdx.x & 63) == 0 && ex > 0.f && __float_as_uint(ex) > stw->dd_excess_bits) atomicMax(&stw->dd_excess_bits, __float_as_uint(ex));
         }
         if (T.keys && act) {
-            if (c < T.cells && r < T.cap)
-                T.keys[(size_t)c * T.cap + r] = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, bead_c, false);
+            if (c < T.cells && r < T.cap) {
+                const unsigned long long k64 = order_key(make_float4(px, py, pz, 0.f), G, cx, cy, cz, bead_c, false);
+                if (T.key32) reinterpret_cast<unsigned *>(T.keys)[(size_t)c * T.cap + r] = ((unsigned)(k64 >> 32) << 20) | (unsigned)bead_c;
+                else T.keys[(size_t)c * T.cap + r] = k64;
+            }
             else
                 atomicOr(&stw->cell_stale, 2); // the table is too small for this state: the evaluation is void (k_decide halts)
         }
@@ -692,8 +696,11 @@ __global__ __launch_bounds__(256) void k_refresh_clusters(const int *__restrict_
 // another wave) go through LDS -- against 45 LDS round trips of the all-LDS network this replaces (measured on
 // gw_200k: 15 us of the 23 us of k_cell_order were the sort).  On return s_buf[0..n2) holds the sorted keys.
 // Whole block must call; waves with w >= n2 / C hold padding keys and only take part in the barriers.
-template <int H>
-__device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const unsigned long long *__restrict__ src,
+// 32-bit keys of the direct build (12-bit Hilbert index << 20 | bead) widened to the 64-bit layout (index << 32 | bead)
+__device__ __forceinline__ unsigned long long widen_key(unsigned long long k) { return k; }
+__device__ __forceinline__ unsigned long long widen_key(unsigned k) { return ((unsigned long long)(k >> 20) << 32) | (k & 0xfffffu); }
+template <int H, class KeyT = unsigned long long>
+__device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const KeyT *__restrict__ src,
                                                 int cnt, int n2) {
     constexpr int C = 64 * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -703,7 +710,8 @@ __device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         const int i = base + h * 64 + lane;
-        v[h] = (live && i < cnt) ? src[i] : ~0ull;
+        v[h] = ~0ull;
+        if (live && i < cnt) v[h] = widen_key(src[i]);
     }
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {

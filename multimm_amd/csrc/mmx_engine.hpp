@@ -886,8 +886,9 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             if (direct) direct_claim_set(h, par);
             int *const dcnt = h->dcount + (size_t)par * ((size_t)h->maxcells + 1);
             int *const drcl = h->drows + (size_t)par * kDirectRowSet, *const drbig = drcl + kDirectMaxRows;
+            h->direct_key32 = direct && h->n <= (1 << 20) && h->key32;
             const SlotArgs T{h->slots_now ? h->slotkeys : nullptr, h->slot_cap, h->slot_cells, direct ? drcl : nullptr,
-                             direct ? drbig : nullptr, (h->inject_fault & 64) ? 1 : 0};
+                             direct ? drbig : nullptr, (h->inject_fault & 64) ? 1 : 0, kDirectMaxRows, -1.f, h->direct_key32 ? 1 : 0};
             hipLaunchKernelGGL((k_pack<true, true, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                                h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, cur, h->cell_of, h->rank_in_cell,
                                direct ? dcnt : h->count, dir_args(h), R, h->st, T);
@@ -940,14 +941,14 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         // is resident at once -- the bonded pass in half as many workgroups as it has virtual blocks, the rest of the slots order
         // cells (a wave per cell: four cells in flight per workgroup)
         const int vi = (small_cells ? 0 : 2) + (h->n3_build ? 1 : 0);
-        if (h->direct_slots[vi] <= 0) {
+        if (h->direct_slots[vi] <= 0) { // (the 32-bit-key instances use no more registers than their 64-bit twins)
             int per_cu = 0;
             hipError_t oe = hipErrorUnknown;
             switch (vi) {
-            case 0: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, false>, 256, 0); break;
-            case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, true>, 256, 0); break;
-            case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, false>, 256, 0); break;
-            default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, true>, 256, 0); break;
+            case 0: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, false, false>, 256, 0); break;
+            case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 1024, true, false>, 256, 0); break;
+            case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, false, false>, 256, 0); break;
+            default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct<kChunk, 4096, true, false>, 256, 0); break;
             }
             if (oe != hipSuccess || per_cu <= 0) {
                 (void)hipGetLastError();
@@ -997,7 +998,13 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         const BondedArgs BA{bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part,
                             h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb};
         const dim3 gd(nib + nbr + go);
-#define BUILD_DIRECT(CAPV, N3V) hipLaunchKernelGGL((k_build_direct<kChunk, CAPV, N3V>), gd, dim3(256), 0, h->stream, D, h->st, h->P, BA)
+#define BUILD_DIRECT(CAPV, N3V)                                                                                      \
+    do {                                                                                                              \
+        if (h->direct_key32)                                                                                          \
+            hipLaunchKernelGGL((k_build_direct<kChunk, CAPV, N3V, true>), gd, dim3(256), 0, h->stream, D, h->st, h->P, BA); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_build_direct<kChunk, CAPV, N3V, false>), gd, dim3(256), 0, h->stream, D, h->st, h->P, BA); \
+    } while (0)
         if (small_cells) {
             if (h->n3_build) BUILD_DIRECT(1024, true);
             else BUILD_DIRECT(1024, false);

@@ -236,6 +236,8 @@ struct mmx_handle_s {
     bool dset_dirty[2] = {false, false};         // the direct build's counter set of that parity holds the counts of an earlier build
                                                  // (a direct build leaves its own set behind and zeroes the other one; builds through
                                                  // the scan in between flip the parity without touching either)
+    int key32 = 1;                               // option: 32-bit sort keys in the direct build (systems of <= 2^20 beads); 0: 64-bit (A/B)
+    bool direct_key32 = false;                   // ... the build being enqueued uses them
     bool direct_ok = true;                       // this call's grids have fitted the direct build so far (nx <= 64, rows <= kDirectMaxRows)
     bool last_build_direct = false;              // the last enqueued full build was a direct one (the polls fetch its fullest cell: k_poll_stats)
     int last_direct_parity = 0;
