@@ -93,13 +93,13 @@ def test_every_single_domain_halt_reason_is_survived(name, n, half_shell):
                 eng.set_option("inject_fault", fault)
                 st, x = _min_job(eng)
                 runs[label] = (st, x, eng.get_option(counter) if counter else None, eng.get_option("direct_builds"),
-                               eng.get_option("kernel_error"))
+                               eng.get_option("kernel_error"), eng.get_option("cell_reuses"))
                 # the energy the minimizer reports for its last point is the energy of that point (a fresh evaluation)
                 eng.set_option("inject_fault", 0)
                 et, _ = eng.compute()
                 assert abs(et.sum() - st.e_final) <= 2e-6 * np.abs(et).sum() + 1e-3, label
         st0, x0 = runs["clean"][0], runs["clean"][1]
-        for label, (st, x, _, _, kerr) in runs.items():
+        for label, (st, x, _, _, kerr, _) in runs.items():
             assert kerr == 0, label
             assert st.iterations == st0.iterations == 120 and st.status == 1, label
             # (a repeated evaluation bins on another grid / another structure: other clusters, other roundings, from there on)
@@ -124,7 +124,9 @@ def test_every_single_domain_halt_reason_is_survived(name, n, half_shell):
                         ("stale structure + grid beyond the direct build", 8 | 64, "cell_stale_halts")),
                        5e-2 if half_shell else 3e-4)   # (120 more iterations of a relaxed state: roundings decide line searches)
     assert relaxed["clean"][3] > 5
-    assert relaxed["stale structure (4)"][2] > 0
+    # (whether a structure is kept within these 120 iterations depends on the displacements the first polls see: where the clean
+    #  run kept any, the injected run must have found them stale)
+    assert relaxed["clean"][5] == 0 or relaxed["stale structure (4)"][2] > 0
 
 
 def test_decomposed_halt_reasons_on_two_loopback_ranks():
