@@ -283,6 +283,11 @@ def dd_leg(args, rank: int, world: int, local_rank: int, tdev, barrier, progress
                     "note": "cell_build contains the need-map all-gather and the halo exchange, reduce the all-reduce",
                 },
             })
+            # what one evaluation keeps rank 0's stream busy for: the HIP-event brackets of its kernel slots (pack + lists + halo
+            # + cell build | pair kernel | tail | all-reduce + decision), collectives included -- the figure to hold against
+            # scripts/dd_projection.py's compute-only critical path (profiles/)
+            slots = [v for v in st.as_dict()["kernel_us_mean"].values() if v]
+            out["critical_path_us"] = sum(slots) if slots else None
         finally:
             eng.close()
         stage = at("single-GPU reference")

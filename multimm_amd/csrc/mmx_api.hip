@@ -597,6 +597,12 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
     else if (k == "dd_rebuild_every") {
         if (!(value >= 1.0)) return fail(h, MMX_ERR_BAD_ARG, "dd_rebuild_every must be >= 1");
         h->dd_every = (int)value;
+        h->dd_adaptive = 0; // a fixed lifetime was asked for (option dd_adaptive, set afterwards, turns the choice by the polls back on)
+        h->dd_lists_valid = false;
+    }
+    else if (k == "dd_adaptive") {
+        h->dd_adaptive = value != 0.0;
+        h->dd_k_cur = 1;
         h->dd_lists_valid = false;
     }
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
@@ -639,6 +645,9 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_skin") *value = h->dd_skin;
     else if (k == "dd_skin_now") *value = h->dd_skin_cur;
     else if (k == "dd_rebuild_every") *value = h->dd_every;
+    else if (k == "dd_adaptive") *value = h->dd_adaptive;
+    else if (k == "dd_move_seen") *value = h->dd_move_seen;
+    else if (k == "dd_lists_serve") *value = dd_K(h); // read-only: evaluations per set of ghost lists in force
     else if (k == "dd_halts") *value = (double)h->dd_halts;
     else if (k == "dd_capacity_updates") *value = (double)h->dd_cap_updates;
     else if (k == "dd_sync_rebuilds") *value = (double)h->dd_sync_rebuilds;
@@ -759,6 +768,7 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
     HIPCHK(h, hipMemsetAsync(h->d, 0, sizeof(float) * nv, h->stream));
 
     h->dd_skin_cur = h->dd_skin;
+    h->dd_k_cur = 1; // (dd_adaptive: exact lists until the polls have seen how far the trial moves go)
     // every exit from here on goes through leave(): per-evaluation profiling back to per-slot sampling, graph dropped
     auto leave = [&](int code) {
         h->prof_eval = -1;
@@ -846,7 +856,10 @@ int mmx_minimize(mmx_handle h, double tolerance, int32_t max_iters, mmx_stats *o
                 h->st_host->cell_stale = 0;
             }
             if (h->st_host->halt_reason & 2) h->dd_slack_div = std::max(1, h->dd_slack_div / 2); // lists grow faster than assumed
-            if (h->st_host->halt_reason & 1) h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f); // the skin did not last dd_every evaluations
+            if (h->st_host->halt_reason & 1) { // the skin did not last: a wider one -- or, option dd_adaptive, fewer evaluations per set of lists
+                if (h->dd_adaptive) h->dd_k_cur = std::max(1, h->dd_k_cur / 2);
+                else h->dd_skin_cur = std::min(2.f * h->dd_skin_cur, 0.8f);
+            }
             ramp = 4; // what follows a halt is polled (and its messages resized) at short intervals again
             h->st_host->phase = h->st_host->halt_phase;
             h->st_host->dd_stale = 0;
@@ -1013,6 +1026,10 @@ int mmx_md_step(mmx_handle h, int32_t n_steps, mmx_md_stats *out) try {
     if (!h || n_steps < 0) return fail(h, MMX_ERR_BAD_ARG, "bad step count");
     if (!h->md_configured) return fail(h, MMX_ERR_STATE, "mmx_md_configure first");
     h->md_active = true;
+    if (h->dd_adaptive && h->dd_k_cur != 1) { // (the polls of a minimization size the lists' lifetime by its trial moves: MD steps get exact lists)
+        h->dd_k_cur = 1;
+        h->dd_lists_valid = false;
+    }
     int rc = prepare(h);
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();

@@ -141,6 +141,7 @@ struct RefArgs {
     float *xref;
     int mode;
     float thr2;
+    int move_track = 0; // decomposed ranks (option dd_adaptive): record the largest squared trial move (MinState::dd_move2_bits)
     int dd = 0; // decomposed ranks: xref = where the owned beads were when the ghost lists were built (dd_rebuild_every > 1); a bead
                 // beyond half the skin raises MinState::dd_stale (k_dd_displacement's job, without its launch and its pass over x)
 };
@@ -247,6 +248,17 @@ __global__ __launch_bounds__(256) void k_pack(int n_own, const Own own, float *_
         const int bead = own.bead(i);
         const int w = (bead << 3) | ((int)labels[bead] + 2);
         pos4[bead] = make_float4(px, py, pz, __int_as_float(w));
+    }
+    if (MOVE && R.move_track) { // how far this trial move takes the owned beads from the last accepted point
+        float m2 = 0.f;
+        if (act) {
+            const float *lx = reinterpret_cast<const float *>(s_xp) + 3 * threadIdx.x;
+            const float dx = px - lx[0], dy = py - lx[1], dz = pz - lx[2];
+            m2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            if (!(m2 >= 0.f)) m2 = 3e38f;
+        }
+        m2 = wave_max(m2);
+        if ((threadIdx.x & 63) == 0 && m2 > 0.f && __float_as_uint(m2) > stw->dd_move2_bits) atomicMax(&stw->dd_move2_bits, __float_as_uint(m2));
     }
     if (R.mode) { // (block-uniform) displacement from where the cell structure in use binned the beads
         float d2 = 0.f;

@@ -169,7 +169,14 @@ struct MinState {
     double coef[MMX_NBASIS];
     double sums[16];             // folded slot sums (all-reduced across ranks in a multi-GPU run)
     double rowsum[MMX_NROWSUM];  // folded k_history rows (same; directly behind sums: ONE all-reduce covers both)
+    double dd_move;              // decomposed ranks: (this evaluation's largest squared trial move of an owned bead, nm^2)^8, summed over the
+                                 // ranks by the same all-reduce: its 8th root is within 1.3 x of the maximum over the ranks, and the same number on every rank
+    double dd_move2_max;         // ... its maximum over the evaluations since the host last cleared it: what the polls size the number of
+                                 // evaluations a set of ghost lists may serve by (option dd_adaptive)
+    unsigned dd_move2_bits;      // (this rank, this evaluation: float bits, k_pack)
+    unsigned dd_pad_;
 };
+static_assert(offsetof(MinState, dd_move) == offsetof(MinState, rowsum) + MMX_NROWSUM * sizeof(double), "dd_move rides behind rowsum in the all-reduce");
 static_assert(offsetof(MinState, rowsum) == offsetof(MinState, sums) + 16 * sizeof(double), "sums and rowsum are reduced as one array");
 
 // Counters of the launch whose workgroups depend on each other (device; zero between launches -- the last workgroup of a

@@ -548,6 +548,8 @@ void coll_halo_exchange(mmx_handle_s *h) {
     for (int q = 0; q < h->world; ++q) h->dd_bytes_sent += (long long)h->dd_scap.cap[q] * 16;
 }
 
+int dd_K(const mmx_handle_s *h);
+
 int dd_alloc(mmx_handle_s *h) {
     if (h->dd_boxes) return MMX_OK;
     const size_t W = (size_t)h->world, S = (size_t)h->slice;
@@ -638,7 +640,7 @@ bool dd_set_capacities(mmx_handle_s *h, const int *mat, bool fresh) {
 int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done: the pack has marked the occupancy already
     const int gb = std::max((h->n_own + 255) / 256, 1);
     const size_t W = (size_t)h->world;
-    const float reach = hmin_of(h) / (1.001f * edge_factor(h)) + (h->dd_every > 1 ? h->dd_skin_cur : 0.f);
+    const float reach = hmin_of(h) / (1.001f * edge_factor(h)) + (dd_K(h) > 1 ? h->dd_skin_cur : 0.f);
     if (sync) {
         hipLaunchKernelGGL(k_dd_bbox, dim3(1), dim3(256), 0, h->stream, h->bbox_part, (h->n_own + 255) / 256,
                            h->dd_boxes + 6 * h->rank);
@@ -666,7 +668,7 @@ int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done:
                        h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st,
                        sync ? nullptr : h->dd_cntmat); // (on the stream: + the lengths of the lists in use until now, of every
                                                       // rank: what the next poll sizes the messages by)
-    if (h->dd_every > 1 && !h->dd_ref_in_pack) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
+    if (dd_K(h) > 1 && !h->dd_ref_in_pack) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
                          // cleared here: the minimizer halts in the very evaluation that raises it, and an MD call must still
                          // see at its next poll that one of its steps ran on stale lists)
         HIPCHK(h, hipMemcpyAsync(h->dd_xref, h->x, sizeof(float) * 3 * (size_t)h->n_own, hipMemcpyDeviceToDevice, h->stream));
@@ -687,10 +689,13 @@ int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done:
     return MMX_OK;
 }
 
-// Which rebuild the next evaluation of a running call gets: 2 = on the stream (every dd_every-th evaluation), 0 = none.
+// Evaluations a set of ghost lists serves: the option dd_rebuild_every, or -- option dd_adaptive -- what the polls derive from the
+// trial moves they read back (1 while the structure collapses: exact lists, no skin; up to dd_rebuild_every once it has settled)
+int dd_K(const mmx_handle_s *h) { return h->dd_adaptive ? std::max(1, std::min(h->dd_k_cur, std::max(h->dd_every, 1))) : h->dd_every; }
+// Which rebuild the next evaluation of a running call gets: 2 = on the stream (every dd_K-th evaluation), 0 = none.
 int dd_schedule(mmx_handle_s *h) {
     if (!use_halo(h) || !h->dd_lists_valid) return 0;
-    return ++h->dd_since >= h->dd_every ? 2 : 0;
+    return ++h->dd_since >= dd_K(h) ? 2 : 0;
 }
 
 void enqueue_bonded(mmx_handle_s *h, CtlArgs &A, bool in_scan);
@@ -818,10 +823,11 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     unsigned long long *const ddo = occ_in_pack ? h->dd_occ : nullptr;
     // decomposed ranks, lists kept over dd_every > 1 evaluations: the trial move itself checks the owned beads against where they
     // were when the lists were built (and records that place when this evaluation rebuilds them)
-    const bool ref_in_pack = dd && h->dd_every > 1 && use_halo(h) && !h->dd_frozen && h->dd_xref && mode == PACK_MOVE &&
+    const bool ref_in_pack = dd && dd_K(h) > 1 && use_halo(h) && !h->dd_frozen && h->dd_xref && mode == PACK_MOVE &&
                              (redecomp != 0 || h->dd_lists_valid);
     const float dd_half = 0.5f * h->dd_skin_cur;
-    const RefArgs RD = ref_in_pack ? RefArgs{h->dd_xref, redecomp ? 3 : 1, dd_half * dd_half, 1} : RefArgs{nullptr, 0, 0.f};
+    const int track = (dd && h->dd_adaptive && use_halo(h) && mode == PACK_MOVE) ? 1 : 0;
+    const RefArgs RD = ref_in_pack ? RefArgs{h->dd_xref, redecomp ? 3 : 1, dd_half * dd_half, track, 1} : RefArgs{nullptr, 0, 0.f, track, 0};
     h->dd_ref_in_pack = ref_in_pack;
     // kept cell structure (see mmx_handle_s::cell_reuse): trial moves of a single-domain minimization only
     // (and only on grids wider than the cutoff: without a skin there is nothing to keep, and the reference costs 24 B / bead)
@@ -922,7 +928,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         hipLaunchKernelGGL((k_pack<true, false, true>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x,
                            h->xp, h->d, h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr,
                            (int *)nullptr, (int *)nullptr, (int *)nullptr, dir_args(h), RD,
-                           ref_in_pack ? h->st : (MinState *)nullptr, SlotArgs{nullptr, 0, 0}, ddg, ddo);
+                           (ref_in_pack || track) ? h->st : (MinState *)nullptr, SlotArgs{nullptr, 0, 0}, ddg, ddo);
     else
         hipLaunchKernelGGL((k_pack<false>), dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->x, h->xp, h->d,
                            h->labels, h->pos4, h->bbox_part, h->st, (const GridParams *)nullptr, (int *)nullptr,
@@ -1033,7 +1039,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     if (halo && h->dd_frozen) {
         // nothing to exchange: the ghosts of the last exchange are binned again
     } else if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
-        if (h->dd_every > 1 && !redecomp && !h->dd_ref_in_pack) { // lists older than this evaluation: still within the skin?
+        if (dd_K(h) > 1 && !redecomp && !h->dd_ref_in_pack) { // lists older than this evaluation: still within the skin?
             const float half = 0.5f * h->dd_skin_cur;
             hipLaunchKernelGGL(k_dd_displacement, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_xref,
                                half * half, h->st);
@@ -1266,7 +1272,7 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
             on = prof_begin(h, MMX_K_REDUCE, ep);
             EventPair cep{};
             const bool con = coll_prof_begin(h, kCollAllreduce, cep);
-            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM + 1);
             prof_end(h, con, cep);
             hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
             prof_end(h, on, ep);
@@ -1293,7 +1299,7 @@ void enqueue_eval(mmx_handle_s *h, int mode, int fold, int redecomp = 0) {
             hipLaunchKernelGGL(k_reduce_all, dim3(1), dim3(kCtlThreads), 0, h->stream, A, h->part, gh, h->rows, h->st);
             EventPair cep{};
             const bool con = coll_prof_begin(h, kCollAllreduce, cep);
-            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM);
+            coll_allreduce(h, h->st->sums, 16 + MMX_NROWSUM + 1);
             prof_end(h, con, cep);
             hipLaunchKernelGGL(k_decide_reduced, dim3(1), dim3(64), 0, h->stream, h->st);
         }
@@ -1447,6 +1453,20 @@ int pull_state(mmx_handle_s *h) {
         K = std::max(1, std::min(K, kReuseMax));
         h->reuse_K = std::min(K, std::max(2 * h->reuse_K, 2));
         HIPCHK(h, hipMemsetAsync(&h->st->disp2_bits, 0, sizeof(unsigned), h->stream));
+    }
+    // decomposed ranks, option dd_adaptive: how many evaluations may a set of ghost lists serve?  dd_move2_max = the largest squared
+    // trial move of an owned bead on any rank (all-reduced: the same number everywhere) since the last poll; lists hold while the
+    // moves since their build stay below half the skin: 70 % of that room is used, the figure at most doubles per poll, a stale
+    // halt halves it (mmx_minimize).  1 = lists rebuilt before every evaluation, exact, no skin (the collapse from the lattice).
+    if (halo && h->dd_adaptive && !h->md_active) { // (MD steps are not trial moves: exact lists there, mmx_md_step)
+        const double m = std::sqrt(std::pow(std::max(h->st_host->dd_move2_max, 0.0), 1.0 / 8.0)); // (dd_move: 8th power of the squared move)
+        h->dd_move_seen = m;
+        int K = m > 0.0 ? (int)(0.7 * 0.5 * (double)h->dd_skin_cur / m) : std::max(h->dd_every, 1);
+        K = std::max(1, std::min(K, std::max(h->dd_every, 1)));
+        K = std::min(K, std::max(2 * h->dd_k_cur, 2));
+        if ((K > 1) != (h->dd_k_cur > 1)) h->dd_since = 1 << 20; // lists with / without a skin from the next evaluation on: rebuild
+        h->dd_k_cur = K;
+        HIPCHK(h, hipMemsetAsync(&h->st->dd_move2_max, 0, sizeof(double), h->stream));
     }
     if (h->comm && g_rccl.CommGetAsyncError && !h->coll_failed) { // errors RCCL found after the call returned
         ncclResult_t ar = ncclSuccess;

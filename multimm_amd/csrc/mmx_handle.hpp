@@ -165,11 +165,14 @@ struct mmx_handle_s {
     double **lbox[2] = {nullptr, nullptr}; // device arrays [world] of the ranks' mailboxes, per parity
     // ghost-bead halo of a decomposed run with a communicator (mmx_dd.hpp); dd_halo = 0 keeps the all-gather of every position
     int dd_halo = 1;
-    int dd_every = 1;                           // ghost lists are rebuilt (on the stream) before every dd_every-th evaluation;
-                                                // 1: before each one -- lists exact for the positions they serve, no skin
+    int dd_every = 4;                           // ghost lists are rebuilt (on the stream) before every dd_every-th evaluation at most
+                                                // (dd_adaptive: the polls choose 1 .. dd_every; 1 = lists exact for the positions they serve, no skin)
+    int dd_adaptive = 1;                        // option (default on; setting dd_rebuild_every fixes the lifetime and switches it off): the polls choose how many evaluations (1 .. dd_every) the ghost lists serve (dd_K)
+    int dd_k_cur = 1;
+    double dd_move_seen = 0.0;                  // largest trial move (nm) the last poll read back
     int dd_since = 0;                           // evaluations enqueued since the last rebuild
-    float dd_skin = 0.2f;                       // nm (dd_every > 1): the lists hold while no bead has moved more than half of it
-    float dd_skin_cur = 0.2f;                   // ... as adapted by the minimizer: doubled (up to 0.8) when a list went stale
+    float dd_skin = 0.15f;                      // nm (lists kept over more than one evaluation): the lists hold while no bead has moved more than half of it
+    float dd_skin_cur = 0.15f;                  // ... as adapted by the minimizer: doubled (up to 0.8) when a list went stale
     float *dd_boxes = nullptr;                  // [world][6] owned bounding boxes (all-gathered at a synchronous rebuild)
     DDGrid *dd_grid = nullptr;                  // coarse grid of the need-maps (device)
     unsigned long long *dd_occ = nullptr;       // [kDDWords] coarse cells of the owned beads

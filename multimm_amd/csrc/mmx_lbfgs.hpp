@@ -595,18 +595,28 @@ __device__ __forceinline__ void reduce_all_block(const CtlArgs &A, const double 
     // slot 12 of the all-reduced array: "some rank's ghost lists are out of date" (see k_dd_displacement)
     if (threadIdx.x < 16) st->sums[threadIdx.x] = flag_or_sum(st, s_out, threadIdx.x);
     if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = s_rows[threadIdx.x];
+    if (threadIdx.x == 64) { // this rank's largest trial move of the evaluation rides in the same all-reduce
+        // (the all-reduce SUMS: the 8th power of the squared move, so that the sum over the ranks is within 8^(1/8) = 1.3 of the
+        //  largest term -- the host takes the 8th root)
+        const float m2 = __uint_as_float(st->dd_move2_bits);
+        const double q = (m2 >= 0.f && m2 < 1e4f) ? (double)m2 : 1e4, q2 = q * q, q4 = q2 * q2;
+        st->dd_move = q4 * q4;
+        st->dd_move2_bits = 0u;
+    }
 }
 __global__ __launch_bounds__(1024) void k_reduce_all(const CtlArgs A, const double *__restrict__ part, int nblk_rows,
                                                      const double *__restrict__ rows, MinState *__restrict__ st) {
     if (st->phase >= PH_DONE) {
         if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0;
         if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) st->dd_move = 0.0;
         return;
     }
     reduce_all_block<false>(A, part, nblk_rows, rows, st);
 }
 __global__ void k_decide_reduced(MinState *__restrict__ st) {
     if (st->phase >= PH_DONE || threadIdx.x != 0) return;
+    if (st->dd_move > st->dd_move2_max) st->dd_move2_max = st->dd_move;
     if (st->sums[kSumKernelError] <= 0.5 && (st->sums[kSumStale] > 0.5 || st->sums[kSumOverflow] > 0.5 || st->sums[kSumCellVoid] > 0.5)) { // a ghost is missing somewhere, or a rank's cell build was void: this evaluation never happened (every rank sees the same sums)
         const double cv = st->sums[kSumCellVoid];
         st->halt_phase = st->phase;
@@ -656,6 +666,7 @@ __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict_
         if (!SOLO && blockIdx.x == 0) { // keep the collective's input finite (k_reduce_all)
             if (threadIdx.x < 16) st->sums[threadIdx.x] = 0.0;
             if (threadIdx.x < MMX_NROWSUM) st->rowsum[threadIdx.x] = 0.0;
+            if (threadIdx.x == 0) st->dd_move = 0.0;
         }
         return;
     }

@@ -46,7 +46,7 @@ for world in worlds:
         for r, e in enumerate(engines):     # one rank at a time, alone on the GPU
             e.set_option("dd_freeze", 1)
             t = {k: e.time_kernel(kk, 10)[0] for k, kk in SLOTS}
-            K = max(1.0, e.get_option("dd_rebuild_every"))
+            K = max(1.0, e.get_option("dd_lists_serve"))   # evaluations per set of ghost lists in force at this state
             f_us, l_us = e.time_kernel(K_FORCES, 10)[0], e.time_kernel(K_DD_LISTS, 10)[0]
             # critical path of an evaluation on this rank, kernels only: the force evaluation as launched + the halo's own
             # kernels (list rebuild charged once per K evaluations: the message pack / unpack part of the slot is small)

@@ -255,7 +255,7 @@ def test_stale_ghost_lists_halt_and_repeat():
     that notices decides nothing (PH_HALT on every rank, through the all-reduced flag), the host rebuilds the lists at the
     trial point and repeats it.  The minimization must come out as with lists rebuilt before every evaluation."""
     s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
-    ref = run_ranks(s, 3, _halting_job)
+    ref = run_ranks(s, 3, _halting_job, dd_rebuild_every=1)
     assert ref[0][2] == 0                                       # exact lists, comfortable messages: nothing to repeat
     thin = run_ranks(s, 3, _halting_job, dd_rebuild_every=4, dd_skin=1e-5)   # doubles on every halt: 1e-5 ... 0.01 nm
     _same_minimization(ref, thin)
@@ -269,8 +269,8 @@ def test_ghost_list_outgrowing_its_message_halts_and_repeats():
     """Messages sized without any slack (inject_fault bit 2): whenever a ghost list grows between two polls of the host it
     no longer fits, the evaluation is void on every rank and is repeated with fresh capacities."""
     s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
-    ref = run_ranks(s, 3, _halting_job)
-    tight = run_ranks(s, 3, _halting_job, inject_fault=4)
+    ref = run_ranks(s, 3, _halting_job, dd_rebuild_every=1)
+    tight = run_ranks(s, 3, _halting_job, dd_rebuild_every=1, inject_fault=4)
     _same_minimization(ref, tight)
     assert tight[0][2] >= 1
 
@@ -468,3 +468,29 @@ def test_randomised_decompositions():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "bad cases: 0" in r.stdout
+
+
+def test_adaptive_lifetime_of_the_ghost_lists():
+    """Option dd_adaptive: the polls choose how many evaluations (1 .. dd_rebuild_every) a set of ghost lists serves from the
+    largest trial move they read back (all-reduced: every rank arrives at the same number) -- 1, exact lists and no skin, while
+    the structure collapses; more once it has settled.  The minimization must come out as with lists rebuilt before every
+    evaluation, and on a relaxed structure the lists must really be kept."""
+    s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
+    ref = run_ranks(s, 3, _halting_job, dd_rebuild_every=1)
+    ada = run_ranks(s, 3, _halting_job, dd_rebuild_every=4, dd_adaptive=1, dd_skin=0.15)
+    _same_minimization(ref, ada)
+    with engine_for(s) as eng:
+        eng.minimize(tolerance=0.0, max_iters=400)
+        s.positions = eng.get_positions().astype(np.float64)
+
+    def job(e):
+        st = e.minimize(tolerance=0.0, max_iters=150)
+        return (st.iterations, st.evaluations, st.status, st.e_final), e.get_positions(), e.get_option("dd_halts"), \
+            e.get_option("dd_lists_serve"), e.get_option("dd_redecompositions"), e.get_option("dd_move_seen")
+
+    ref2 = run_ranks(s, 3, job, dd_rebuild_every=1)
+    ada2 = run_ranks(s, 3, job, dd_rebuild_every=4, dd_adaptive=1, dd_skin=0.15)
+    for a, b in zip(ref2, ada2):
+        assert a[0][0] == b[0][0] and abs(a[0][3] - b[0][3]) <= 3e-3 * abs(a[0][3])
+    assert all(b[3] == ada2[0][3] for b in ada2)                 # every rank the same lifetime
+    assert ada2[0][3] > 1 and ada2[0][4] < 0.7 * ref2[0][4], (ada2[0][3:], ref2[0][4])     # lists kept over several evaluations: fewer rebuilds

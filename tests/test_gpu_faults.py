@@ -125,19 +125,19 @@ def test_every_single_domain_halt_reason_is_survived(name, n, half_shell):
                        5e-2 if half_shell else 3e-4)   # (120 more iterations of a relaxed state: roundings decide line searches)
     assert relaxed["clean"][3] > 5
     # (whether a structure is kept within these 120 iterations depends on the displacements the first polls see: where the clean
-    #  run kept any, the injected run must have found them stale)
-    assert relaxed["clean"][5] == 0 or relaxed["stale structure (4)"][2] > 0
+    #  run kept structures for ten evaluations or more, the injected run must have found some stale)
+    assert relaxed["clean"][5] < 10 or relaxed["stale structure (4)"][2] > 0
 
 
 def test_decomposed_halt_reasons_on_two_loopback_ranks():
     from test_gpu_dd import ALL_ON, _halting_job, _same_minimization, run_ranks
     s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
-    ref = run_ranks(s, 2, _halting_job)
+    ref = run_ranks(s, 2, _halting_job, dd_rebuild_every=1)
     assert ref[0][2] == 0
     stale = run_ranks(s, 2, _halting_job, dd_rebuild_every=4, dd_skin=1e-5)     # reason 1
     _same_minimization(ref, stale)
     assert stale[0][2] > 5
-    tight = run_ranks(s, 2, _halting_job, inject_fault=4)                        # reason 2
+    tight = run_ranks(s, 2, _halting_job, dd_rebuild_every=1, inject_fault=4)    # reason 2
     _same_minimization(ref, tight)
     assert tight[0][2] >= 1
 
