@@ -1232,13 +1232,12 @@ int mmx_time_kernel(mmx_handle h, int32_t kernel, int32_t reps, double *mean_us,
             if (!use_halo(h) || !h->dd_lists_valid) break;
             const int gbl = std::max((h->n_own + 255) / 256, 1);
             // (the occupancy map itself is marked by the evaluation's k_pack: enqueue_build, occ_in_pack)
-            HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
+            // (as dd_rebuild enqueues it on the stream: the two kernels zero the list lengths / the occupancy words themselves)
             hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
-                               h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
-            HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * (size_t)h->world, h->stream));
+                               h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st, 1);
             hipLaunchKernelGGL(k_dd_build_lists, dim3(gbl), dim3(256), 0, h->stream, h->n_own, own_of(h), h->rank, h->world, h->x,
                                h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, h->dd_scap, h->st,
-                               h->dd_cntmat);
+                               h->dd_cntmat, h->dd_occ);
             int mx = 1;
             for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scap.cap[q], h->dd_rcap.cap[q]));
             const dim3 gq(std::min((mx + 255) / 256, 256), h->world);

@@ -121,13 +121,16 @@ __global__ __launch_bounds__(256) void k_dd_occupancy(int n_own, const float *__
 // block appends the lengths of the send lists in use (built by the previous rebuild) for the capacity bookkeeping of
 // the host.  17 blocks of 256 threads.
 __global__ __launch_bounds__(256) void k_dd_dilate(const unsigned long long *__restrict__ occ, const DDGrid *__restrict__ grid,
-                                                   unsigned long long *__restrict__ payload, const int *__restrict__ send_cnt,
-                                                   int world, const MinState *__restrict__ st) {
+                                                   unsigned long long *__restrict__ payload, int *__restrict__ send_cnt,
+                                                   int world, const MinState *__restrict__ st, const int reset_cnt = 0) {
     if (st->phase >= PH_DONE) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= kDDWords) {
         const int q = t - kDDWords;
-        if (q < kDDMaxWorld) reinterpret_cast<int *>(payload + kDDWords)[q] = q < world ? send_cnt[q] : 0;
+        if (q < kDDMaxWorld) {
+            reinterpret_cast<int *>(payload + kDDWords)[q] = q < world ? send_cnt[q] : 0;
+            if (reset_cnt && q < world) send_cnt[q] = 0; // (the lists that follow count from zero: no memset launch in between)
+        }
         return;
     }
     const int R = grid->radius;
@@ -151,8 +154,12 @@ __global__ __launch_bounds__(256) void k_dd_build_lists(int n_own, const Own own
                                                         const unsigned long long *__restrict__ static_mask,
                                                         int *__restrict__ send_ids, int slice, int *__restrict__ send_cnt,
                                                         const DDCaps caps, MinState *__restrict__ st,
-                                                        int *__restrict__ cntmat = nullptr) {
+                                                        int *__restrict__ cntmat = nullptr,
+                                                        unsigned long long *__restrict__ occ_zero = nullptr) {
     if (st->phase >= PH_DONE) return;
+    // (the occupancy words have been dilated and sent: zero again for the pack of the next evaluation that marks them)
+    if (occ_zero)
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < kDDWords; t += gridDim.x * 256) occ_zero[t] = 0ull;
     // rebuilds on the stream: block 0 also copies the list lengths that came with the maps -- rank r's send list for q as it
     // was until now -- into the world x world matrix the host reads at its next poll
     if (cntmat && blockIdx.x == 0)

@@ -648,11 +648,14 @@ int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done:
         hipLaunchKernelGGL(k_dd_grid, dim3(1), dim3(64), 0, h->stream, h->dd_boxes, h->world, reach, h->dd_grid);
     }
     if (!occ_done) {
+        h->dd_occ_clean = false;
         HIPCHK(h, hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream));
         hipLaunchKernelGGL(k_dd_occupancy, dim3(gb), dim3(256), 0, h->stream, h->n_own, h->x, h->dd_grid, h->dd_occ, h->st);
     }
+    // rebuilds on the stream: the dilation zeroes the list lengths after it has read them, the list kernel the occupancy words after
+    // the dilation has: two memset launches less per evaluation (the words are zero whenever a pack is about to mark them: h->dd_occ_clean)
     hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
-                       h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st);
+                       h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st, sync ? 0 : 1);
     {
         EventPair cep{};
         const bool con = coll_prof_begin(h, kCollNeedmap, cep);
@@ -660,14 +663,16 @@ int dd_rebuild(mmx_handle_s *h, bool sync, bool occ_done = false) { // occ_done:
                              [](mmx_handle_s *o) { return (void *)o->dd_maps; });
         prof_end(h, con, cep);
     }
-    HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
+    if (sync) HIPCHK(h, hipMemsetAsync(h->dd_send_cnt, 0, sizeof(int) * W, h->stream));
     DDCaps caps = h->dd_scap;
     if (sync)
         for (int q = 0; q < h->world; ++q) caps.cap[q] = h->slice;
     hipLaunchKernelGGL(k_dd_build_lists, dim3(gb), dim3(256), 0, h->stream, h->n_own, own_of(h), h->rank, h->world, h->x,
                        h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, caps, h->st,
-                       sync ? nullptr : h->dd_cntmat); // (on the stream: + the lengths of the lists in use until now, of every
+                       sync ? nullptr : h->dd_cntmat, // (on the stream: + the lengths of the lists in use until now, of every
                                                       // rank: what the next poll sizes the messages by)
+                       h->dd_occ);
+    h->dd_occ_clean = true;
     if (dd_K(h) > 1 && !h->dd_ref_in_pack) // the lists start a new life: reference positions of the displacement test.  (st->dd_stale is NOT
                          // cleared here: the minimizer halts in the very evaluation that raises it, and an MD call must still
                          // see at its next poll that one of its steps ran on stale lists)
@@ -818,7 +823,8 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     // has the new positions in registers (one launch and one pass over x less per evaluation)
     const bool occ_in_pack = dd && redecomp == 2 && use_halo(h) && !h->dd_frozen && h->dd_occ && h->dd_grid &&
                              (mode == PACK_MOVE || mode == PACK_PLAIN);
-    if (occ_in_pack) (void)hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream);
+    if (occ_in_pack && !h->dd_occ_clean) (void)hipMemsetAsync(h->dd_occ, 0, sizeof(unsigned long long) * kDDWords, h->stream);
+    if (occ_in_pack) h->dd_occ_clean = false; // (marked by this pack; the rebuild that follows zeroes it again)
     const DDGrid *const ddg = occ_in_pack ? h->dd_grid : nullptr;
     unsigned long long *const ddo = occ_in_pack ? h->dd_occ : nullptr;
     // decomposed ranks, lists kept over dd_every > 1 evaluations: the trial move itself checks the owned beads against where they

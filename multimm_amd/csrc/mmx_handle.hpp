@@ -190,6 +190,7 @@ struct mmx_handle_s {
     long long dd_halts = 0, dd_cap_updates = 0, dd_sync_rebuilds = 0; // statistics
     DDOffsets dd_off{};
     bool dd_lists_valid = false, dd_static_dirty = true;
+    bool dd_occ_clean = false;                  // the occupancy words are zero (the last list rebuild left them so)
     bool dd_ref_in_pack = false;                // the pack of the evaluation being enqueued checks / records the lists' reference positions
     int dd_rc = 0;                              // first error of a re-decomposition inside a launch sequence
     long long dd_redecompositions = 0, dd_exchanges = 0, dd_bytes_sent = 0; // statistics (options dd_*)
