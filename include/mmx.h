@@ -217,11 +217,23 @@ int mmx_disable_term(mmx_handle h, int32_t term);
  *                     peers' need-maps -- coarse-cell occupancy grown by the cutoff --, ncclSend/ncclRecv of the
  *                     listed beads per evaluation); 0 = all-gather of every position per evaluation (round-1 path,
  *                     A/B; also what a run with chromosomal blocks uses: that term has no cutoff)  1
- * "dd_rebuild_every"  K: the ghost lists are rebuilt, on the stream, before every K-th evaluation.  1: before each
- *                     one -- exact lists, no skin, one 32 KB all-gather more per evaluation; K > 1: the lists reach
- *                     cutoff + dd_skin and hold while no bead has moved more than dd_skin / 2 (checked on the
- *                     device; a violation voids the evaluation, which is repeated with fresh lists)          1
- * "dd_skin"           nm, K > 1 only; doubled (up to 0.8) for the rest of a call whenever a list went stale   0.2
+ * "dd_adaptive"       1: the polls of mmx_minimize choose how many evaluations K (1 .. "dd_rebuild_every", default 4) a set of
+ *                     ghost lists serves, from the largest trial move any rank saw since the last poll (all-reduced);
+ *                     K = 1 -- exact lists, no skin -- while the structure collapses; MD steps always get K = 1     1
+ * "dd_rebuild_every"  K: the ghost lists are rebuilt, on the stream, before every K-th evaluation; setting it fixes the
+ *                     lifetime (switches "dd_adaptive" off).  1: before each one -- exact lists, no skin, one 32 KB
+ *                     all-gather more per evaluation; K > 1: the lists reach cutoff + dd_skin and hold while no bead has
+ *                     moved more than dd_skin / 2 (checked by the pack; a violation voids the evaluation, which is
+ *                     repeated with fresh lists)                                                             4
+ * "dd_skin"           nm, K > 1 only; doubled (up to 0.8) for the rest of a call whenever a list went stale   0.15
+ * "dd_lists_serve", "dd_move_seen"   (get only) K in force; largest trial move (nm) the last poll read back
+ * "dd_overlap"        1: half-shell kernel on decomposed ranks -- list kernels, need-map all-gather, message pack, send / recv
+ *                     and ghost count go to a second stream of the handle, beside the owned beads' share of the cell build;
+ *                     the ghosts' clusters, the work items and the bonded pass follow in a second launch.  Same cluster
+ *                     list.  Off by default: on one MI355X the fork / join of the two streams and the second launch cost
+ *                     more than the 25 us they hide (profiles/r05/dd_overlap_ab.txt).  3: the halo's
+ *                     launches are enqueued before the owned build (A/B); "dd_overlap_go": workgroups of the owned
+ *                     build's launch (A/B); "dd_overlapped" (get only): evaluations that ran this way               0
  * "dd_spatial"        1: mmx_minimize re-assigns the 62-bead segments to the ranks by recursive bisection of their
  *                     centroids while the structure deforms (first attempt after "dd_reassign_first" evaluations, the
  *                     interval doubling up to "dd_reassign_max"; an attempt that would move < 2 % of the segments

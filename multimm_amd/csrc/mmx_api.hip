@@ -119,7 +119,16 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             // the rows' ghost-cluster totals
             HIPCHK(h, dalloc(&h->dcount, (size_t)2 * ((size_t)h->maxcells + 1)));
             HIPCHK(h, dalloc(&h->drows, (size_t)2 * kDirectRowSet));
-            if (world > 1) HIPCHK(h, dalloc(&h->dcount_g, (size_t)2 * ((size_t)h->maxcells + 1)));
+            if (world > 1) {
+                HIPCHK(h, dalloc(&h->dcount_g, (size_t)2 * ((size_t)h->maxcells + 1)));
+                // the halo's own stream (enqueue_build, dd_overlap); without it the decomposed evaluation stays on the one stream
+                if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    h->stream2 = nullptr; // (option dd_overlap then stays off)
+                }
+            }
             h->n3_cap = n3_configure(kN3MaxCap);
             // a run starts at a dense cell, at a segment start or every 16 clusters: never more than cells + clusters / 16 (<= n_all /
             // 128 + cells / 16) runs; a run is one record per window pass over its candidates: the rest of n_all / 16 is theirs
@@ -277,6 +286,9 @@ int mmx_destroy(mmx_handle h) try {
         (void)hipEventDestroy(ep.a);
         (void)hipEventDestroy(ep.b);
     }
+    if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
+    if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MMX_OK;
@@ -605,6 +617,8 @@ int mmx_set_option(mmx_handle h, const char *key, double value) try {
         h->dd_k_cur = 1;
         h->dd_lists_valid = false;
     }
+    else if (k == "dd_overlap") h->dd_overlap = (value != 0.0 && h->stream2 && h->ev_pack && h->ev_halo) ? (int)value : 0;
+    else if (k == "dd_overlap_go") h->dd_overlap_go = (int)value;
     else if (k == "graph_evals") h->graph_evals = std::max(2, 2 * ((int)value / 2));
     else if (k == "inject_fault") h->inject_fault = (int)value;
     else if (k == "n3_long_items") h->n3_long_items = value < 0.0 ? -1 : value == 2.0 ? 2 : value != 0.0;
@@ -646,6 +660,8 @@ int mmx_get_option(mmx_handle h, const char *key, double *value) try {
     else if (k == "dd_skin_now") *value = h->dd_skin_cur;
     else if (k == "dd_rebuild_every") *value = h->dd_every;
     else if (k == "dd_adaptive") *value = h->dd_adaptive;
+    else if (k == "dd_overlap") *value = h->dd_overlap;
+    else if (k == "dd_overlapped") *value = (double)h->dd_overlapped; // read-only: evaluations whose halo ran beside the owned build
     else if (k == "dd_move_seen") *value = h->dd_move_seen;
     else if (k == "dd_lists_serve") *value = dd_K(h); // read-only: evaluations per set of ghost lists in force
     else if (k == "dd_halts") *value = (double)h->dd_halts;

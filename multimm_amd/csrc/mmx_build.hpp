@@ -476,12 +476,13 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
 // layout of the half-shell kernel's DD instance) -- and of the cells that hold more than kWaveCellMax beads ALTOGETHER.  The grid
 // is the one the previous build laid out from its owned box grown by the cutoff; beads and ghosts beyond it are clamped into
 // its boundary cells, which keeps every pair within the cutoff inside the 27-cell stencil (k_dd_unpack_count).
-constexpr int kDirectRowSet = 3 * kDirectMaxRows; // ints of one set of row totals: clusters, large cells, ghost clusters
+constexpr int kDirectRowSet = 4 * kDirectMaxRows; // ints of one set of row totals: clusters, large cells, ghost clusters, cells of many ghosts
 constexpr int kDirectDDCap = 2048;  // beads of the largest cell its block sort takes (LDS); beyond: KERR_ORDER_DD
 constexpr int kDirectDDRows = 1024; // rows of a rank's grid the build handles (LDS: three prefix arrays)
 struct DirectDD {
     const int *count_g, *rowclg; // ghosts per cell, ghost clusters per row (this build's set)
     int *count_g_zero, *rowclg_zero;
+    int *rowbigg_zero;           // the other set's count of cells of many ghosts (what a two-launch build's PHASE 2 takes as D.rowbig)
     int *istart;                 // [cells + 1] out: ghost-cluster offsets per cell (counted from the first ghost cluster)
     float expand;                // the next grid: owned box grown by this much (the cutoff)
     Own own;
@@ -586,19 +587,37 @@ __device__ __forceinline__ void direct_emit_wave_dd(const DirectArgs &D, const D
     }
 }
 
-template <int CAP, bool N3>
+// PHASE (the build in two launches, so that the halo exchange runs beside the first: enqueue_build, dd_overlap; split layout
+// only): 0 = owned beads and ghosts in ONE launch; 1 = the owned beads' share -- next grid, owned clusters, cstart: nothing in it
+// waits for a peer --; 2 = the ghosts' share once they have arrived -- ghost clusters, istart, work items, bonded pass (its loop
+// partners and chain neighbours may be ghosts).  A cell is "large" (block sort) by what the launch sorts: D.rowbig counts the cells
+// of > kWaveCellMax beads altogether (0), owned beads (1), ghosts (2).  The result is the same list bit for bit: owned beads
+// sort before ghosts in a cell's keys, and the two kinds never share a cluster.
+template <int CAP, bool N3, int PHASE = 0>
 __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, const DirectDD X, MinState *__restrict__ st,
                                                           const FFParams P, const BondedArgs B) {
     if (st->phase >= PH_DONE) return;
+    static_assert(PHASE == 0 || N3, "the two-launch build needs the split layout of the half-shell kernel");
+    constexpr bool OWN = PHASE != 2, GHO = PHASE != 1;
     __shared__ unsigned long long s_buf[CAP];
     __shared__ int s_cl[kDirectDDRows + 1], s_clg[kDirectDDRows + 1], s_big[kDirectDDRows + 1];
     __shared__ double s_w[4];
+#ifdef MMX_STAGE_TIMING // per workgroup (< 2730): start, row prefixes done, end (scripts/stage_build_dd.py)
+    if (threadIdx.x == 0 && blockIdx.x < 2730) g_stage_t[blockIdx.x * 3] = wall_clock64();
+#define DD_STAMP(k)                                                                                              \
+    do {                                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 2730) g_stage_t[blockIdx.x * 3 + (k)] = wall_clock64();              \
+    } while (0)
+#else
+#define DD_STAMP(k) do {} while (0)
+#endif
     static_assert(sizeof(unsigned long long) * CAP >= sizeof(int) * 4 * (kN3Runs + kN3GhostRuns) * 66, "item builders' scratch");
     const int nbb = D.n_bonded_blocks;
     if ((int)blockIdx.x >= D.n_items_blocks && (int)blockIdx.x < D.n_items_blocks + nbb) {
         for (int vb = (int)blockIdx.x - D.n_items_blocks; vb < B.nvb; vb += nbb)
             bonded_fused_block<256>(P, D.pos4, B.flags, B.lstart, B.partner, B.r0, B.cf_w, B.g, B.part, B.loop_form, B.lam_form,
                                     B.cf_form, vb, B.nvb, s_w);
+        DD_STAMP(2);
         return;
     }
     const GridParams G = *D.grid;
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
     // the prefix of both kinds together and s_clg stays zero.
     constexpr bool SPLIT = N3;
     direct_row_prefix1(D.rowcl, nrows, s_cl);
-    direct_row_prefix1(X.rowclg, nrows, s_clg);
+    if (GHO) direct_row_prefix1(X.rowclg, nrows, s_clg);
     direct_row_prefix1(D.rowbig, nrows, s_big);
     if (!SPLIT) {
         for (int r = threadIdx.x; r <= nrows; r += 256) {
@@ -621,27 +640,33 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         }
         __syncthreads();
     }
-    const int tot_cl = s_cl[nrows], tot_clg = s_clg[nrows], nbig = s_big[nrows];
+    const int tot_cl = s_cl[nrows], tot_clg = GHO ? s_clg[nrows] : 0, nbig = s_big[nrows];
+    DD_STAMP(1);
 
     if ((int)blockIdx.x < D.n_items_blocks) {
         if (blockIdx.x == 0) {
-            __shared__ float s_red[6 * 4];
-            const GridParams GN = grid_from_parts<256>(D.bbox_part, D.nblk_bbox, D.hmin, D.maxcells, s_red, X.expand);
-            if (threadIdx.x == 0) {
-                *D.grid_next = GN;
+            if (OWN) {
+                __shared__ float s_red[6 * 4];
+                const GridParams GN = grid_from_parts<256>(D.bbox_part, D.nblk_bbox, D.hmin, D.maxcells, s_red, X.expand);
+                if (threadIdx.x == 0) {
+                    *D.grid_next = GN;
+                    st->n_clusters_own = tot_cl; // (interleaved layout: all of them, as the scan-based build reports it)
+                    st->n_big = nbig;
+                    st->ncells = ncells;
+                    st->ncells_set[D.parity] = ncells;
+                    st->cell_edge = (double)G.h;
+                    D.cstart[ncells] = min(tot_cl, D.cap_clusters);
+                }
+            }
+            if (GHO && threadIdx.x == 0) {
                 st->n_clusters = tot_cl + tot_clg;
-                st->n_clusters_own = tot_cl; // (interleaved layout: all of them, as the scan-based build reports it)
-                st->n_big = nbig;
-                st->ncells = ncells;
-                st->ncells_set[D.parity] = ncells;
-                st->cell_edge = (double)G.h;
-                D.cstart[ncells] = min(tot_cl, D.cap_clusters);
+                if (PHASE == 2) atomicAdd(&st->n_big, nbig);
                 X.istart[ncells] = min(tot_clg, D.cap_clusters);
                 st->dd_excess_bits = 0u; // (read by this build's ghost count, which ran before; the next pack starts from zero)
                 if (tot_cl + tot_clg > D.cap_clusters) atomicOr(&st->kernel_error, (int)KERR_BOUNDS);
             }
         }
-        if (!N3) return;
+        if (!N3 || PHASE == 1) return;
         // work items: offsets of the five owned rows and the nine ghost rows around the wave's row, from the populations
         int *const cs_w = reinterpret_cast<int *>(s_buf) + wave * ((kN3Runs + kN3GhostRuns) * 66);
         n3_items_rows((int)blockIdx.x, D.n_items_blocks, G, D.n3_items, D.n3_max_items, st, (D.n3_flags & 4) ? 2 : (D.n3_flags & 1),
@@ -695,6 +720,7 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
                           R.gbase = tot_cl;
                           R.err = &st->kernel_error;
                       });
+        DD_STAMP(2);
         return;
     }
 
@@ -702,51 +728,57 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
     {
         const int nz_cells = min(st->ncells_set[D.parity ^ 1], D.maxcells);
         for (int q = bid * 256 + (int)threadIdx.x; q < nz_cells; q += nblk * 256) {
-            D.count_zero[q] = 0;
-            X.count_g_zero[q] = 0;
+            if (OWN) D.count_zero[q] = 0;
+            if (GHO) X.count_g_zero[q] = 0;
         }
         for (int q = bid * 256 + (int)threadIdx.x; q < kDirectDDRows; q += nblk * 256) {
-            D.rowcl_zero[q] = 0;
-            D.rowbig_zero[q] = 0;
-            X.rowclg_zero[q] = 0;
+            if (OWN) {
+                D.rowcl_zero[q] = 0;
+                D.rowbig_zero[q] = 0;
+            }
+            if (GHO) {
+                X.rowclg_zero[q] = 0;
+                X.rowbigg_zero[q] = 0; // (whichever kind of build used that set: a one-launch build never counted into it)
+            }
         }
     }
     const int nB = min(nbig, nblk - (nblk >> 2));
     const int kvec = min(D.slot_cap >> 6, kWaveCellMax / 64);
     for (int c = (bid - nB) * 4 + wave; bid >= nB && c < ncells; c += (nblk - nB) * 4) {
         const int row = c / nx, x = c - row * nx;
-        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = lane < nx ? X.count_g[row * nx + lane] : 0;
+        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = (GHO && lane < nx) ? X.count_g[row * nx + lane] : 0;
         const bool in_table = c < D.slot_cells;
         unsigned long long v[kWaveCellMax / 64];
 #pragma unroll
         for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = ~0ull;
-        if (in_table) v[0] = D.keys[(size_t)c * D.slot_cap + lane];
-        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64), k = ko + kg;
+        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64);
+        const int k = PHASE == 0 ? ko + kg : PHASE == 1 ? ko : kg; // keys this launch sorts ...
+        const int koff = PHASE == 2 ? ko : 0;                       // ... from this place of the cell's row of the slot table
         const int cb = s_cl[row] + direct_row_before(SPLIT ? (ko_l + 7) >> 3 : ((ko_l + 7) >> 3) + ((kg_l + 7) >> 3), lane, x);
         const int cg = SPLIT ? tot_cl + s_clg[row] + direct_row_before((kg_l + 7) >> 3, lane, x) : cb + ((ko + 7) >> 3);
         if (lane == 0) {
-            D.cstart[c] = min(cb, D.cap_clusters);
-            X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
+            if (OWN) D.cstart[c] = min(cb, D.cap_clusters);
+            if (GHO) X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
         }
         if (k > kWaveCellMax || k == 0) continue;
-        if (!in_table || k > D.slot_cap) continue; // (a void evaluation: the counting kernels flagged it)
-        if (k > 64) {
+        if (!in_table || koff + k > D.slot_cap) continue; // (a void evaluation: the counting kernels flagged it)
 #pragma unroll
-            for (int h = 1; h < kWaveCellMax / 64; ++h)
-                if (h * 64 < k && h < kvec) v[h] = D.keys[(size_t)c * D.slot_cap + h * 64 + lane];
-        }
+        for (int h = 0; h < kWaveCellMax / 64; ++h)
+            if (h * 64 < k && (h == 0 || h < kvec) && koff + h * 64 + lane < D.slot_cap)
+                v[h] = D.keys[(size_t)c * D.slot_cap + koff + h * 64 + lane];
 #pragma unroll
         for (int h = 0; h < kWaveCellMax / 64; ++h)
             if (h * 64 + lane >= k) v[h] = ~0ull;
+        const int eo = PHASE == 2 ? 0 : ko, eg = PHASE == 1 ? 0 : kg;
         if (k <= 64) {
             if (k > 1) wave_sort_keys<1>(v, lane);
-            direct_emit_wave_dd<1>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+            direct_emit_wave_dd<1>(D, X, st, v, c, eo, eg, cb, cg, cap_slots, lane);
         } else if (k <= 128) {
             wave_sort_keys<2>(v, lane);
-            direct_emit_wave_dd<2>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+            direct_emit_wave_dd<2>(D, X, st, v, c, eo, eg, cb, cg, cap_slots, lane);
         } else {
             wave_sort_keys<4>(v, lane);
-            direct_emit_wave_dd<4>(D, X, st, v, c, ko, kg, cb, cg, cap_slots, lane);
+            direct_emit_wave_dd<4>(D, X, st, v, c, eo, eg, cb, cg, cap_slots, lane);
         }
     }
     for (int bi = bid; bid < nB && bi < nbig; bi += nB) {
@@ -757,21 +789,22 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
             else hi = mid;
         }
         const int row = lo;
-        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = lane < nx ? X.count_g[row * nx + lane] : 0;
-        unsigned long long m = __ballot(ko_l + kg_l > kWaveCellMax);
+        const int ko_l = lane < nx ? D.count[row * nx + lane] : 0, kg_l = (GHO && lane < nx) ? X.count_g[row * nx + lane] : 0;
+        unsigned long long m = __ballot((PHASE == 0 ? ko_l + kg_l : PHASE == 1 ? ko_l : kg_l) > kWaveCellMax);
         for (int k = bi - s_big[row]; k > 0 && m; --k) m &= m - 1;
         if (!m) continue;
         const int x = __ffsll((long long)m) - 1;
         const int c = row * nx + x;
-        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64), cnt = ko + kg;
+        const int ko = __shfl(ko_l, x, 64), kg = __shfl(kg_l, x, 64);
+        const int cnt = PHASE == 0 ? ko + kg : PHASE == 1 ? ko : kg, koff = PHASE == 2 ? ko : 0;
         const int cb = s_cl[row] + direct_row_before(SPLIT ? (ko_l + 7) >> 3 : ((ko_l + 7) >> 3) + ((kg_l + 7) >> 3), lane, x);
         const int cg = SPLIT ? tot_cl + s_clg[row] + direct_row_before((kg_l + 7) >> 3, lane, x) : cb + ((ko + 7) >> 3);
         if (threadIdx.x == 0) {
-            D.cstart[c] = min(cb, D.cap_clusters);
-            X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
+            if (OWN) D.cstart[c] = min(cb, D.cap_clusters);
+            if (GHO) X.istart[c] = SPLIT ? min(cg - tot_cl, D.cap_clusters) : 0;
         }
-        if (c >= D.slot_cells || cnt > D.slot_cap) continue;
-        const unsigned long long *kp = D.keys + (size_t)c * D.slot_cap;
+        if (c >= D.slot_cells || koff + cnt > D.slot_cap) continue;
+        const unsigned long long *kp = D.keys + (size_t)c * D.slot_cap + koff;
         __syncthreads();
         if (cnt > CAP) { // owned beads and ghosts cannot be kept in separate clusters without the sort: the evaluation is void
             if (threadIdx.x == 0) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
@@ -809,10 +842,12 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
             }
             __syncthreads();
         }
-        emit_clusters(c, 0, cnt, ko, cb, cg, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, X.own, s_buf, D.sbead,
-                      D.slot_of, cap_slots, st, D.n_beads);
+        emit_clusters(c, 0, cnt, PHASE == 2 ? 0 : ko, cb, PHASE == 1 ? -1 : cg, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x,
+                      256, X.own, s_buf, D.sbead, D.slot_of, cap_slots, st, D.n_beads);
     }
+    DD_STAMP(2);
 }
+#undef DD_STAMP
 
 // The fullest cell of the last direct build, for the host's polls (the scan used to publish it per build): the counter set is
 // intact until the next build zeroes it.

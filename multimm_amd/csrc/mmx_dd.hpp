@@ -234,6 +234,7 @@ struct GhostCount {
     int *rowclg, *rowbig;    // [rows]
     unsigned long long *keys;
     int cap, cells;
+    int split_big;           // two-launch build (k_build_direct_dd, PHASE 1 / 2): rowbig counts the cells of many GHOSTS, not of many beads altogether
 };
 __global__ __launch_bounds__(256) void k_dd_unpack_count(const float4 *__restrict__ recvbuf, const DDOffsets O, int slice,
                                                          float4 *__restrict__ pos4, int *__restrict__ ghost_ids, int n_all,
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void k_dd_unpack_count(const float4 *__restric
             c = (cz * G.ny + cy) * G.nx + cx;
             C.cell_of[id] = c;
         }
-        const int r = cell_rank(todo, c, todo ? id : 0, C.rank, C.count_g, nullptr, true, C.rowclg, C.rowbig, G.nx, s_rows, C.count_o);
+        const int r = cell_rank(todo, c, todo ? id : 0, C.rank, C.count_g, nullptr, true, C.rowclg, C.rowbig, G.nx, s_rows,
+                                C.split_big ? nullptr : C.count_o);
         if (todo) {
             const int at = C.count_o[c] + r; // behind the cell's owned beads
             if (c < C.cells && at < C.cap) C.keys[(size_t)c * C.cap + at] = order_key(p, G, cx, cy, cz, id, true);

@@ -719,40 +719,49 @@ void direct_claim_set(mmx_handle_s *h, const int par) {
 }
 
 // Decomposed ranks, direct build: what arrived from the peers goes to pos4 AND is counted into this parity's ghost set
-void dd_ghost_count(mmx_handle_s *h, const dim3 gq) {
+void dd_ghost_count(mmx_handle_s *h, const dim3 gq, const bool split) { // split: a two-launch build follows (cells are large by their ghosts alone)
     const int par = h->build_idx & 1;
     const size_t cset = (size_t)h->maxcells + 1;
     int *const drcl = h->drows + (size_t)par * kDirectRowSet;
     const GhostCount C{h->grid + par, h->cell_of, h->rank_in_cell, h->dcount_g + (size_t)par * cset, h->dcount + (size_t)par * cset,
-                       drcl + 2 * kDirectMaxRows, drcl + kDirectMaxRows, h->slotkeys, h->slot_cap, h->slot_cells};
+                       drcl + 2 * kDirectMaxRows, drcl + (split ? 3 : 1) * kDirectMaxRows, h->slotkeys, h->slot_cap, h->slot_cells,
+                       split ? 1 : 0};
     hipLaunchKernelGGL(k_dd_unpack_count, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4, h->dd_ghost_ids,
                        h->n_all, C, h->st);
 }
 
 int local_beads(const mmx_handle_s *h);
 bool use_n3(const mmx_handle_s *h);
-void launch_build_direct_dd(mmx_handle_s *h, CtlArgs &bonded, const int gb) {
+// phase 0: the whole build in one launch; 1 / 2: the owned beads' share (nothing in it waits for a peer) and the ghosts' share +
+// work items + bonded pass (k_build_direct_dd<.., PHASE>; half-shell kernel's split list only)
+void launch_build_direct_dd(mmx_handle_s *h, CtlArgs &bonded, const int gb, const int phase = 0) {
     const float hm = hmin_of(h);
     const int par = h->build_idx & 1;
     GridParams *cur = h->grid + par, *next = h->grid + (par ^ 1);
     h->grid_factor[par ^ 1] = edge_factor(h);
     h->grid_factor[par] = edge_factor(h);
-    h->n3_build = use_n3(h);
+    if (phase != 2) h->n3_build = use_n3(h);
     const int nvb = grid_beads(h->n_own);
-    const int nib = h->n3_build ? kN3ItemBlocks : 1;
-    const int vi = h->n3_build ? 1 : 0;
+    const int nib = (h->n3_build && phase != 1) ? kN3ItemBlocks : 1;
+    const int vi = phase ? 1 + phase : h->n3_build ? 1 : 0;
     if (h->direct_dd_slots[vi] <= 0) {
         int per_cu = 0;
-        const hipError_t oe = vi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, true>, 256, 0)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, false>, 256, 0);
+        hipError_t oe = hipErrorUnknown;
+        switch (vi) {
+        case 0: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, false, 0>, 256, 0); break;
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, true, 0>, 256, 0); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, true, 1>, 256, 0); break;
+        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_build_direct_dd<kDirectDDCap, true, 2>, 256, 0); break;
+        }
         if (oe != hipSuccess || per_cu <= 0) {
             (void)hipGetLastError();
             per_cu = 3;
         }
         h->direct_dd_slots[vi] = per_cu * std::max(h->n_cus, 1);
     }
-    const int nbr = (nvb + 1) / 2;
-    const int go = std::max(256, std::min(2048, h->direct_dd_slots[vi] - nib - nbr));
+    const int nbr = phase == 1 ? 0 : (nvb + 1) / 2;
+    int go = std::max(256, std::min(2048, h->direct_dd_slots[vi] - nib - nbr));
+    if (phase == 1 && h->dd_overlap_go > 0) go = std::max(64, std::min(go, h->dd_overlap_go));
     const size_t cset = (size_t)h->maxcells + 1;
     const bool bb_on = h->flags && (h->P.use_bond || h->P.use_angle);
     const bool loops_on = h->n_rows > 0 && h->lstart;
@@ -766,7 +775,7 @@ void launch_build_direct_dd(mmx_handle_s *h, CtlArgs &bonded, const int gb) {
     D.maxcells = h->maxcells;
     D.count = h->dcount + (size_t)par * cset;
     D.rowcl = h->drows + (size_t)par * kDirectRowSet;
-    D.rowbig = D.rowcl + kDirectMaxRows;
+    D.rowbig = D.rowcl + (phase == 2 ? 3 : 1) * kDirectMaxRows; // (phase 2: the cells of many ghosts)
     D.count_zero = h->dcount + (size_t)(par ^ 1) * cset;
     D.rowcl_zero = h->drows + (size_t)(par ^ 1) * kDirectRowSet;
     D.rowbig_zero = D.rowcl_zero + kDirectMaxRows;
@@ -793,14 +802,18 @@ void launch_build_direct_dd(mmx_handle_s *h, CtlArgs &bonded, const int gb) {
     X.rowclg = D.rowcl + 2 * kDirectMaxRows;
     X.count_g_zero = h->dcount_g + (size_t)(par ^ 1) * cset;
     X.rowclg_zero = D.rowcl_zero + 2 * kDirectMaxRows;
+    X.rowbigg_zero = D.rowcl_zero + 3 * kDirectMaxRows;
     X.istart = h->istart;
     X.expand = hm / edge_factor(h); // (grown by the cutoff, whatever the cell edge)
     X.own = own_of(h);
     const BondedArgs BA{bb_on ? h->flags : nullptr, loops_on ? h->lstart : nullptr, h->partner, h->loop_r0, h->cf_w, h->g, h->part,
                         h->Q.loop_form, h->Q.lam_form, h->Q.cf_form, nvb};
     const dim3 gd(nib + nbr + go);
-    if (h->n3_build) hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, true>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
-    else hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, false>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    if (phase == 1) hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, true, 1>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    else if (phase == 2) hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, true, 2>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    else if (h->n3_build) hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, true, 0>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    else hipLaunchKernelGGL((k_build_direct_dd<kDirectDDCap, false, 0>), gd, dim3(256), 0, h->stream, D, X, h->st, h->P, BA);
+    if (phase == 1) return; // (the second launch closes the build)
     enqueue_bonded(h, bonded, true);
     h->gcur = cur;
     h->build_idx++;
@@ -1035,6 +1048,22 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         return;
     }
     h->last_build_direct = false;
+    // Decomposed ranks, the halo BESIDE the owned beads' share of the build (option dd_overlap): everything between the pack and the
+    // arrival of the ghosts -- list kernels, need-map all-gather, message pack, send / recv, ghost count -- goes to the handle's
+    // second stream, fenced by two events; this stream meanwhile lays out the next grid and sorts the owned beads into their clusters
+    // (k_build_direct_dd<.., 1>), waits for the ghosts, and finishes with their clusters, the work items and the bonded pass (<.., 2>).
+    // Not for synchronous rebuilds (the host waits in them anyway) and not for the full-shell kernel's interleaved list (a cell's
+    // owned clusters are placed behind the ghosts' counts there).
+    const bool overlap = direct_dd && h->dd_overlap && h->stream2 && h->ev_pack && h->ev_halo && redecomp != 1 && h->dd_lists_valid &&
+                         use_n3(h);
+    hipStream_t const main_stream = h->stream;
+    if (overlap) {
+        (void)hipEventRecord(h->ev_pack, main_stream);
+        if (!(h->dd_overlap & 2)) launch_build_direct_dd(h, *bonded, gb, 1);
+        (void)hipStreamWaitEvent(h->stream2, h->ev_pack, 0);
+        h->stream = h->stream2; // (every launch and collective below is enqueued through h->stream)
+        h->dd_overlapped++;
+    }
     // dd_frozen (measurement: scripts/dd_projection.py): no collective is issued -- the ghost lists and the ghost positions
     // last received stay, so one rank's kernels can be timed alone on exactly the beads it holds in a real run
     if (redecomp && use_halo(h) && !h->dd_frozen) { // fresh ghost lists from the positions the pack has just written
@@ -1043,7 +1072,19 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
     }
     const bool halo = use_halo(h) && h->dd_lists_valid;
     if (halo && h->dd_frozen) {
-        // nothing to exchange: the ghosts of the last exchange are binned again
+        // nothing to exchange: the ghosts of the last exchange are binned again (below); an overlapped evaluation also runs the
+        // list kernels of a rebuild on the stream, so that what is timed is what a real evaluation puts beside the owned build
+        if (overlap) {
+            hipLaunchKernelGGL(k_dd_dilate, dim3(kDDWords / 256 + 1), dim3(256), 0, h->stream, h->dd_occ, h->dd_grid,
+                               h->dd_maps + (size_t)h->rank * kDDPayload, h->dd_send_cnt, h->world, h->st, 1);
+            hipLaunchKernelGGL(k_dd_build_lists, dim3(std::max(gb, 1)), dim3(256), 0, h->stream, h->n_own, own_of(h), h->rank, h->world,
+                               h->x, h->dd_grid, h->dd_maps, h->dd_static, h->dd_send_ids, h->slice, h->dd_send_cnt, h->dd_scap, h->st,
+                               h->dd_cntmat, h->dd_occ);
+            int mx = 1;
+            for (int q = 0; q < h->world; ++q) mx = std::max(mx, std::max(h->dd_scap.cap[q], h->dd_rcap.cap[q]));
+            hipLaunchKernelGGL(k_dd_pack, dim3(std::min((mx + 255) / 256, 256), h->world), dim3(256), 0, h->stream, h->dd_send_ids,
+                               h->dd_send_cnt, h->slice, h->pos4, h->dd_sendbuf, h->dd_scap, h->st);
+        }
     } else if (halo) { // ghosts for pairs, bonds, loops: the listed beads only (mmx_dd.hpp)
         if (dd_K(h) > 1 && !redecomp && !h->dd_ref_in_pack) { // lists older than this evaluation: still within the skin?
             const float half = 0.5f * h->dd_skin_cur;
@@ -1062,7 +1103,7 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
             prof_end(h, con, cep);
         }
         if (direct_dd) {
-            dd_ghost_count(h, gq);
+            dd_ghost_count(h, gq, overlap);
         } else
             hipLaunchKernelGGL(k_dd_unpack, gq, dim3(256), 0, h->stream, h->dd_recvbuf, h->dd_off, h->slice, h->pos4,
                                h->dd_ghost_ids, h->n_all, h->st);
@@ -1072,9 +1113,15 @@ void enqueue_build(mmx_handle_s *h, int mode, bool init = false, CtlArgs *bonded
         if (halo && h->dd_frozen) { // (measurement: the ghosts of the last exchange are counted again, nothing is exchanged)
             int mx = 1;
             for (int q = 0; q < h->world; ++q) mx = std::max(mx, h->dd_rcap.cap[q]);
-            dd_ghost_count(h, dim3(std::min((mx + 255) / 256, 256), h->world));
+            dd_ghost_count(h, dim3(std::min((mx + 255) / 256, 256), h->world), overlap);
         }
-        launch_build_direct_dd(h, *bonded, gb);
+        if (overlap) { // the ghosts are in place and counted: back to the evaluation's own stream
+            (void)hipEventRecord(h->ev_halo, h->stream);
+            h->stream = main_stream;
+            if (h->dd_overlap & 2) launch_build_direct_dd(h, *bonded, gb, 1); // (A/B: the halo's launches enqueued first)
+            (void)hipStreamWaitEvent(main_stream, h->ev_halo, 0);
+        }
+        launch_build_direct_dd(h, *bonded, gb, overlap ? 2 : 0);
         return;
     }
     const bool in_scan = bonded && h->fused_bonded && h->overlap_bonded && has_nb(h) && !all_pairs(h);

@@ -197,6 +197,13 @@ struct mmx_handle_s {
     float *xg = nullptr;      // [3 * n_all] global positions as last set by the host (multi-GPU only)
     bool pos4_dirty = false;  // pos4 of non-owned beads must be refilled from xg before the next evaluation
     hipStream_t stream = nullptr;
+    // decomposed ranks, halo beside the owned beads' share of the cell build (enqueue_build): the list kernels, the two collectives
+    // of the halo and the ghost count run on stream2 between ev_pack (the pack is done) and ev_halo (the ghosts are in place)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    int dd_overlap = 0;                         // option (default OFF: measured slower; half-shell kernel's split cluster list only): 1 = the halo on stream2 beside the owned build
+    int dd_overlap_go = 0;                      // option (A/B): workgroups of the owned build's launch while the halo runs beside it (0: what fills the device)
+    long long dd_overlapped = 0;                // statistics: evaluations whose halo ran beside the owned build
     FFParams P{};
     bool have_pos = false;
     // vectors (float, padded to n4*4)
@@ -233,10 +240,10 @@ struct mmx_handle_s {
     unsigned tail_epoch = 0u;                    // tag of the last k_tail launch's partials (TailArgs::epoch)
     int fused_tail = 1;                          // option: unsort + history + decision in one launch (k_tail); 0: the separate kernels (A/B)
     int *dcount = nullptr;                       // direct build: two sets of cell populations [2][maxcells + 1] ...
-    int *drows = nullptr;                        // ... and of row totals [2][3][kDirectMaxRows] (clusters, large cells, ghost clusters), alternating with the build's parity
+    int *drows = nullptr;                        // ... and of row totals [2][4][kDirectMaxRows] (clusters, large cells, ghost clusters, cells of many ghosts), alternating with the build's parity
     int *dcount_g = nullptr;                     // decomposed ranks: the ghosts' populations [2][maxcells + 1]
     int direct_slots[4] = {0, 0, 0, 0};          // workgroups of k_build_direct<CAP, N3> resident at once (occupancy x CUs), per instance
-    int direct_dd_slots[2] = {0, 0};             // ... of k_build_direct_dd<N3>
+    int direct_dd_slots[4] = {0, 0, 0, 0};       // ... of k_build_direct_dd<N3, PHASE>: [N3 ? 1 : 0] one launch, [2] / [3] the two launches of the overlapped build
     bool dset_dirty[2] = {false, false};         // the direct build's counter set of that parity holds the counts of an earlier build
                                                  // (a direct build leaves its own set behind and zeroes the other one; builds through
                                                  // the scan in between flip the parity without touching either)

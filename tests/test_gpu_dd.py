@@ -98,6 +98,47 @@ def test_half_shell_pair_kernel_on_decomposed_ranks(world):
 
 
 @pytest.mark.parametrize("world", [2, 4])
+def test_halo_beside_the_owned_build(world):
+    """Option dd_overlap (off by default: DESIGN.md section 8): list kernels, both collectives of the halo and the ghost count on the
+    handle's second stream while the evaluation's own stream sorts the owned beads into their clusters; the ghosts' clusters, the
+    work items and the bonded pass follow in a second launch once the ghosts are in place.  The cluster list is the one-launch
+    build's (owned beads sort before ghosts, the kinds never share a cluster): same decisions, same energies to summation order.
+    (Without chromosomal blocks: that term has no cutoff and keeps the all-gather of every position.  20 000 beads per rank: the
+    slot table of the direct build does not fit systems much smaller.)"""
+    s = synthetic_system("gw_200k", n_beads=20000 * world, jitter=0.02, seed=7)
+
+    def job(e):
+        e.minimize(tolerance=0.0, max_iters=15)   # (the slot table of the direct build is sized by the first call's polls)
+        st = e.minimize(tolerance=0.0, max_iters=25)
+        et, f = e.compute()
+        return ((st.iterations, st.status, st.e_initial, st.e_final), et, f, e.owned_beads(), e.get_option("dd_overlapped"),
+                e.get_option("direct_builds"), e.get_option("n3_launches"), e.get_positions())
+
+    one = run_ranks(s, world, job, nb_variant=4096, dd_overlap=0)
+    two = run_ranks(s, world, job, nb_variant=4096, dd_overlap=1)
+    for a, b in zip(one, two):
+        assert a[4] == 0 and b[4] >= 20, (a[4], b[4])          # every evaluation after the first synchronous rebuild overlapped
+        assert a[5] > 0 and b[5] > 0 and b[6] > 0               # direct builds, half-shell kernel
+        assert a[0][:2] == b[0][:2]
+        # (the half-shell kernel's float atomics make two runs of ONE build differ as much: the collapse amplifies rounding)
+        assert abs(a[0][3] - b[0][3]) <= 0.15 * abs(a[0][2] - a[0][3])
+        for r in (a, b):
+            # the energy the minimizer's last (overlapped) evaluation accepted = a fresh evaluation of the final positions, which
+            # rebuilds its lists synchronously and takes the one-launch build
+            assert abs(r[1].sum() - r[0][3]) <= 2e-6 * np.abs(r[1]).sum() + 1e-2, (r[1].sum(), r[0][3])
+    # ... and that fresh evaluation's forces against one domain
+    x = two[0][7]
+    with engine_for(s) as eng:
+        eng.set_positions(x)
+        et0, F0 = eng.compute()
+    F = np.zeros_like(F0)
+    for r in two:
+        assert np.allclose(r[1], et0, rtol=2e-6, atol=1e-3), (r[1], et0)
+        F[r[3]] = r[2]
+    assert np.abs(F - F0).max() <= 4e-6 * np.abs(F0).max() + 2e-3
+
+
+@pytest.mark.parametrize("world", [2, 4])
 def test_minimize_decomposed_matches_single_domain(world):
     s = synthetic_system("gw_200k", n_beads=6000, jitter=0.02, seed=2, **ALL_ON)
     with engine_for(s) as eng:
