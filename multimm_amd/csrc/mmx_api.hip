@@ -1424,6 +1424,12 @@ int mmx_nb_census(mmx_handle h, int64_t *n_cells, int32_t *max_per_cell, double 
 } // extern "C"
 
 #ifdef MMX_STAGE_TIMING
+extern "C" int mmx_debug_build_cells(int *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_stage_c), sizeof(int) * 8192);
+}
+extern "C" int mmx_debug_build_times(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_stage_b), sizeof(unsigned long long) * 8192);
+}
 extern "C" int mmx_debug_stage_times(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mmx::g_stage_t), sizeof(unsigned long long) * 8192);
 }

@@ -223,12 +223,14 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
     __shared__ int s_cl[kDirectMaxRows + 1], s_big[kDirectMaxRows + 1];
     __shared__ double s_w[4];
     const int nbb = D.n_bonded_blocks;
+    BUILD_STAMP(0); // (timing build: scripts/stage_build.py)
     // ---- bonded pass: workgroups [n_items_blocks, n_items_blocks + nbb)
     if ((int)blockIdx.x >= D.n_items_blocks && (int)blockIdx.x < D.n_items_blocks + nbb) {
         // (a virtual block of the bonded pass per round: the partials stay those of the stand-alone pass, workgroup by workgroup)
         for (int vb = (int)blockIdx.x - D.n_items_blocks; vb < B.nvb; vb += nbb)
             bonded_fused_block<256>(P, D.pos4, B.flags, B.lstart, B.partner, B.r0, B.cf_w, B.g, B.part, B.loop_form, B.lam_form,
                                     B.cf_form, vb, B.nvb, s_w);
+        BUILD_STAMP(2);
         return;
     }
 #ifdef MMX_STAGE_TIMING
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
 #endif
     direct_row_prefix(D.rowcl, D.rowbig, nrows, s_cl, s_big);
     const int tot_cl = s_cl[nrows], nbig = s_big[nrows];
+    BUILD_STAMP(1);
 #ifdef MMX_STAGE_TIMING
     {
         const int nB_ = min(nbig, D.n_order - (D.n_order >> 2));
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
 #define BUILD_DONE_STAMP()                                                                            \
     do {                                                                                               \
         if (tbase >= 0 && threadIdx.x == 0) g_stage_t[tbase + 3] = wall_clock64();                     \
+        BUILD_STAMP(2);                                                                                \
     } while (0)
 #else
 #define BUILD_DONE_STAMP() do {} while (0)
@@ -356,6 +360,12 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         for (int h = 0; h < kWaveCellMax / 64; ++h) v[h] = (KeyT)~0ull;
         if (in_table) v[0] = keys[(size_t)c * D.slot_cap + lane]; // (slot_cap >= 64: the first 64 keys of the row are there)
         const int cnt = __shfl(cnt_l, x, 64);
+#ifdef MMX_STAGE_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && c == (bid - nB) * 4) {
+            g_stage_c[blockIdx.x * 2] = c;
+            g_stage_c[blockIdx.x * 2 + 1] = cnt;
+        }
+#endif
         const int cb = s_cl[row] + direct_row_before((cnt_l + 7) >> 3, lane, x);
         if (lane == 0) D.cstart[c] = min(cb, D.cap_clusters);
         if (cnt > kWaveCellMax || cnt == 0) continue; // (larger: pass B)
@@ -602,22 +612,14 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
     __shared__ unsigned long long s_buf[CAP];
     __shared__ int s_cl[kDirectDDRows + 1], s_clg[kDirectDDRows + 1], s_big[kDirectDDRows + 1];
     __shared__ double s_w[4];
-#ifdef MMX_STAGE_TIMING // per workgroup (< 2730): start, row prefixes done, end (scripts/stage_build_dd.py)
-    if (threadIdx.x == 0 && blockIdx.x < 2730) g_stage_t[blockIdx.x * 3] = wall_clock64();
-#define DD_STAMP(k)                                                                                              \
-    do {                                                                                                          \
-        if (threadIdx.x == 0 && blockIdx.x < 2730) g_stage_t[blockIdx.x * 3 + (k)] = wall_clock64();              \
-    } while (0)
-#else
-#define DD_STAMP(k) do {} while (0)
-#endif
+    BUILD_STAMP(0); // (timing build: scripts/stage_build_dd.py)
     static_assert(sizeof(unsigned long long) * CAP >= sizeof(int) * 4 * (kN3Runs + kN3GhostRuns) * 66, "item builders' scratch");
     const int nbb = D.n_bonded_blocks;
     if ((int)blockIdx.x >= D.n_items_blocks && (int)blockIdx.x < D.n_items_blocks + nbb) {
         for (int vb = (int)blockIdx.x - D.n_items_blocks; vb < B.nvb; vb += nbb)
             bonded_fused_block<256>(P, D.pos4, B.flags, B.lstart, B.partner, B.r0, B.cf_w, B.g, B.part, B.loop_form, B.lam_form,
                                     B.cf_form, vb, B.nvb, s_w);
-        DD_STAMP(2);
+        BUILD_STAMP(2);
         return;
     }
     const GridParams G = *D.grid;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         __syncthreads();
     }
     const int tot_cl = s_cl[nrows], tot_clg = GHO ? s_clg[nrows] : 0, nbig = s_big[nrows];
-    DD_STAMP(1);
+    BUILD_STAMP(1);
 
     if ((int)blockIdx.x < D.n_items_blocks) {
         if (blockIdx.x == 0) {
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
                           R.gbase = tot_cl;
                           R.err = &st->kernel_error;
                       });
-        DD_STAMP(2);
+        BUILD_STAMP(2);
         return;
     }
 
@@ -845,9 +847,8 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         emit_clusters(c, 0, cnt, PHASE == 2 ? 0 : ko, cb, PHASE == 1 ? -1 : cg, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x,
                       256, X.own, s_buf, D.sbead, D.slot_of, cap_slots, st, D.n_beads);
     }
-    DD_STAMP(2);
+    BUILD_STAMP(2);
 }
-#undef DD_STAMP
 
 // The fullest cell of the last direct build, for the host's polls (the scan used to publish it per build): the counter set is
 // intact until the next build zeroes it.

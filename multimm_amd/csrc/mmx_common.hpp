@@ -198,12 +198,20 @@ namespace stage_timing_ {}
 // workgroup; [4200 ..] k_build_direct: +0..3 workgroup 0 (start, grid, prefix, done), +4..7 the first order workgroup that takes
 // small cells (start, grid, prefix, done), +8..11 the first one that takes large cells, +12..15 item workgroup 1
 __device__ unsigned long long g_stage_t[8192];
+// ... and of the direct builds (k_build_direct, k_build_direct_dd): [workgroup * 3 + {0 start, 1 row prefixes done, 2 end}], workgroups < 2730
+__device__ unsigned long long g_stage_b[8192];
+__device__ int g_stage_c[8192]; // [workgroup * 2 + {0 first cell of wave 0, 1 its population}]
+#define BUILD_STAMP(k)                                                                                \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 2730) g_stage_b[blockIdx.x * 3 + (k)] = wall_clock64();   \
+    } while (0)
 #define STAGE_STAMP(idx)                                                                              \
     do {                                                                                               \
         if (threadIdx.x == 0) g_stage_t[(idx)] = wall_clock64();                                       \
     } while (0)
 #else
 #define STAGE_STAMP(idx) do {} while (0)
+#define BUILD_STAMP(k) do {} while (0)
 #endif
 // ---- wave helpers ---------------------------------------------------------------------------
 // The xor butterfly (offsets 32, 16, 8, 4, 2, 1: every lane ends up with the wave's total, association fixed) WITHOUT the LDS

@@ -24,7 +24,7 @@ for r, e in enumerate(engines[:2]):
     e.set_option("dd_overlap", 0)
     us = e.time_kernel(K_FORCES, 5)[0]
     t = np.zeros(8192, np.uint64)
-    lib.mmx_debug_stage_times(C.c_void_p(t.ctypes.data))
+    lib.mmx_debug_build_times(C.c_void_p(t.ctypes.data))
     blk = t[:8190].astype(np.int64).reshape(2730, 3)
     live = blk[:, 0] > 0
     n = int(live.sum())
