@@ -212,7 +212,7 @@ __device__ __forceinline__ void direct_emit_wave(const DA &D, MinState *__restri
 }
 
 template <int CHUNK, int CAP, bool N3, bool KEY32 = false>
-__global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinState *__restrict__ st, const FFParams P,
+__global__ __launch_bounds__(256, 6) void k_build_direct(const DirectArgs D, MinState *__restrict__ st, const FFParams P,
                                                        const BondedArgs B) {
     if (st->phase >= PH_DONE) return;
     // KEY32 (systems of <= 2^20 beads): the pack wrote 32-bit keys (12-bit Hilbert index << 20 | bead) -- the same order as the
@@ -413,12 +413,27 @@ __global__ __launch_bounds__(256) void k_build_direct(const DirectArgs D, MinSta
         if (c >= D.slot_cells || cnt > D.slot_cap) continue; // (a void evaluation: k_pack flagged it)
         const KeyT *kp = keys + (size_t)c * D.slot_cap;
         __syncthreads(); // s_buf free (emit of the previous cell has read it)
-        if (cnt <= 1024) { // keys in registers, <= 3 exchanges through LDS
-            int n2 = 128;
-            while (n2 < cnt) n2 <<= 1;
-            if (n2 <= 256) block_sort_regs<1>(s_buf, kp, cnt, n2);
-            else if (n2 == 512) block_sort_regs<2>(s_buf, kp, cnt, n2);
-            else block_sort_regs<4>(s_buf, kp, cnt, n2);
+#ifdef MMX_STAGE_TIMING
+        if (bid == 0 && bi == bid && threadIdx.x == 0) {
+            g_stage_t[4216] = wall_clock64(); // the cell is known (row search, population row)
+            g_stage_t[4219] = (unsigned long long)cnt;
+        }
+#endif
+        if (cnt <= 512) { // (nearly all of them) by counting: block_rank_sort
+            static_assert(CAP >= 1024, "input copy in the first 512 entries of s_buf, sorted keys in the next 512");
+            block_rank_sort<KeyT>(reinterpret_cast<KeyT *>(s_buf), s_buf + 512, kp, cnt);
+#ifdef MMX_STAGE_TIMING
+            if (bid == 0 && bi == bid && threadIdx.x == 0) g_stage_t[4217] = wall_clock64(); // sorted
+#endif
+            emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own, s_buf + 512, D.sbead,
+                          D.slot_of, cap_slots, st, D.n_beads);
+#ifdef MMX_STAGE_TIMING
+            if (bid == 0 && bi == bid && threadIdx.x == 0) g_stage_t[4218] = wall_clock64(); // emitted
+#endif
+            continue;
+        }
+        if (cnt <= 1024) { // 513..1024: the bitonic network, keys in registers, three exchanges through LDS
+            block_sort_regs<4>(s_buf, kp, cnt, 1024);
             emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own, s_buf, D.sbead,
                           D.slot_of, cap_slots, st, D.n_beads);
             continue;
@@ -812,12 +827,13 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
             if (threadIdx.x == 0) atomicOr(&st->kernel_error, (int)KERR_ORDER_DD);
             continue;
         }
-        if (cnt <= 1024) {
-            int n2 = 128;
-            while (n2 < cnt) n2 <<= 1;
-            if (n2 <= 256) block_sort_regs<1>(s_buf, kp, cnt, n2);
-            else if (n2 == 512) block_sort_regs<2>(s_buf, kp, cnt, n2);
-            else block_sort_regs<4>(s_buf, kp, cnt, n2);
+        const unsigned long long *sorted = s_buf;
+        if (cnt <= 512) { // by counting (block_rank_sort): input copy in s_buf[0 .. 512), sorted keys behind it
+            static_assert(CAP >= 1024, "two regions of 512 keys");
+            block_rank_sort<unsigned long long>(s_buf, s_buf + 512, kp, cnt);
+            sorted = s_buf + 512;
+        } else if (cnt <= 1024) {
+            block_sort_regs<4>(s_buf, kp, cnt, 1024);
         } else {
             int n2 = 128;
             while (n2 < cnt) n2 <<= 1;
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
             __syncthreads();
         }
         emit_clusters(c, 0, cnt, PHASE == 2 ? 0 : ko, cb, PHASE == 1 ? -1 : cg, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x,
-                      256, X.own, s_buf, D.sbead, D.slot_of, cap_slots, st, D.n_beads);
+                      256, X.own, sorted, D.sbead, D.slot_of, cap_slots, st, D.n_beads);
     }
     BUILD_STAMP(2);
 }

@@ -782,6 +782,50 @@ __device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const
     __syncthreads();
 }
 
+// Sort of <= 512 keys by COUNTING (whole workgroup of 256 threads): a key's place in the sorted cell is the number of keys below it
+// -- keys are unique: the bead id is part of them --, counted against broadcast reads of the keys in LDS; no exchange network, two
+// barriers.  The bitonic network above takes 45 dependent stages for 257..512 keys (9.7 us measured, profiles/r05/build_stages.txt:
+// the ~300 large cells of a collapsing gw_200k ended the build's launch 5 us after everything else); this takes ~2.
+// s_in: LDS [512] KeyT (input copy); s_out: LDS [512] sorted keys, widened to 64 bits (what emit_clusters reads).  Same order as
+// the network: ascending keys.
+template <class KeyT>
+__device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *s_out, const KeyT *__restrict__ src, const int cnt) {
+    const int t = threadIdx.x;
+    const bool one = t < cnt, two = t + 256 < cnt;
+    KeyT a0 = (KeyT)~0ull, a1 = (KeyT)~0ull; // (padding: never below a real key)
+    if (one) a0 = src[t];
+    if (two) a1 = src[t + 256];
+    s_in[t] = a0;
+    s_in[t + 256] = a1;
+    __syncthreads();
+    const bool wave_two = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)) + 256 < cnt; // any lane of this wave holds a second key
+    const int cnt4 = (cnt + 3) & ~3;
+    int r0 = 0, r1 = 0;
+    if (wave_two) {
+        for (int q = 0; q < cnt4; q += 4) {
+            KeyT k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r0 += k[u] < a0 ? 1 : 0;
+                r1 += k[u] < a1 ? 1 : 0;
+            }
+        }
+    } else {
+        for (int q = 0; q < cnt4; q += 4) {
+            KeyT k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r0 += k[u] < a0 ? 1 : 0;
+        }
+    }
+    if (one) s_out[r0] = widen_key(a0);
+    if (two) s_out[r1] = widen_key(a1);
+    __syncthreads();
+}
+
 // `bid` of `nblk` workgroups (k_cell_order: blockIdx / gridDim; k_order_items: the launch's first nblk workgroups)
 template <int CHUNK, int CAP>
 __device__ __forceinline__ void cell_order_block(const int bid, const int nblk, const GridParams *__restrict__ grid,

@@ -32,3 +32,6 @@ if t[4200] > 0:
     print("    first order workgroup, small cells    ", f(4))
     print("    first order workgroup, large cells    ", f(8))
     print("    item workgroup 1                      ", f(12))
+    if t[4216] > 0:
+        g = lambda i: round((int(t[i]) - int(b[0])) / 100.0, 2)
+        print(f"    first large-cell workgroup, its first cell ({int(t[4219])} beads): cell known {g(4216)}, sorted {g(4217)}, emitted {g(4218)}")
