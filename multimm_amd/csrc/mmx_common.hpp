@@ -307,6 +307,35 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_partner<0xb1>(v);
     return v;
 }
+// Twelve wave totals for the price of three and a half: the first two butterfly steps are done PAIRWISE -- v_permlane32_swap of
+// two different registers leaves {x[0:31], y[0:31]} and {x[32:63], y[32:63]}, whose sum is x's step in the lower half of the wave
+// and y's in the upper one; v_permlane16_swap does the same with rows -- so twelve values shrink to six, then to three registers
+// that hold four values each (one per row of 16 lanes); the steps within a row follow as in wave_sum.  Every addition has the
+// operands wave_sum gives it (in one order or the other): the same bits.  out[j], lanes 16 r .. 16 r + 15: total of v[j + 3 r].
+__device__ __forceinline__ double swap32_add(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap16_add(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void wave_sum12(const double (&v)[12], double (&out)[3]) {
+    double h[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = swap32_add(v[k], v[k + 6]); // lower half: v[k], upper half: v[k + 6]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double q = swap16_add(h[j], h[j + 3]); // rows 0..3: v[j], v[j + 3], v[j + 6], v[j + 9]
+        q += dpp_partner<0x128>(q);
+        q += dpp_partner<0x124>(q);
+        q += dpp_partner<0x4e>(q);
+        q += dpp_partner<0xb1>(q);
+        out[j] = q;
+    }
+}
 // Wave total by DPP (no LDS crossbar): butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, 8),
 // then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (gfx9 DPP controls).  The total is valid in
 // lanes 48..63; the result is broadcast from lane 63 through a scalar register.  Fixed order => deterministic.

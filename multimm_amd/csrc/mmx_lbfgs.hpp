@@ -794,13 +794,21 @@ __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict_
     }
     STAGE_STAMP(blockIdx.x * 4 + 2);
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3; // wave of the group
+    {
+        // the twelve wave totals in one go (wave_sum12: the same bits as twelve wave_sum calls, a third of their instructions --
+        // sixteen waves per CU fold here, and every workgroup's partials are on the critical path of the one that decides)
+        static_assert(MMX_NROWS * 4 == 12, "wave_sum12");
+        double flat[12], tot[3];
 #pragma unroll
-    for (int r = 0; r < MMX_NROWS; ++r)
+        for (int r = 0; r < MMX_NROWS; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double sm = wave_sum(acc[r][k]);
-            if (lane == 0) s_w[cg][(r * 4 + k) * 4 + wave] = sm;
+            for (int k = 0; k < 4; ++k) flat[r * 4 + k] = acc[r][k];
+        wave_sum12(flat, tot);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s_w[cg][(j + 3 * (lane >> 4)) * 4 + wave] = tot[j];
         }
+    }
     __syncthreads();
     if (tv < MMX_NROWS * 4) {
         const int r = tv >> 2, k = tv & 3;

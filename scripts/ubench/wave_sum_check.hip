@@ -46,6 +46,17 @@ __global__ void k(const double *d, const float *f, const int *ii, unsigned long 
     okx = okx && lane_xor<16>(ii[i]) == __shfl_xor(ii[i], 16, 64) && lane_xor<32>(ii[i]) == __shfl_xor(ii[i], 32, 64);
     for (int j = 1; j < 64; j <<= 1) okx = okx && lane_xor_rt(key, j) == __shfl_xor(key, j, 64);
     if (!okx) atomicAdd(bad + 5, 1ull);
+    // wave_sum12 against twelve wave_sum calls
+    double v12[12], t12[3];
+    for (int q = 0; q < 12; ++q) v12[q] = d[(i + 977 * q) & ((1 << 20) - 1)] * (q + 1);
+    wave_sum12(v12, t12);
+    bool ok12 = true;
+    for (int q = 0; q < 12; ++q) {
+        const double want = wave_sum(v12[q]);
+        const int lane = threadIdx.x & 63;
+        if ((lane >> 4) == q / 3 && __double_as_longlong(t12[q % 3]) != __double_as_longlong(want)) ok12 = false;
+    }
+    if (!ok12) atomicAdd(bad + 6, 1ull);
 }
 int main() {
     const int n = 1 << 20;
@@ -60,14 +71,14 @@ int main() {
         ii[i] = rand() - RAND_MAX / 2;
     }
     double *dd; float *df; int *di; unsigned long long *bad;
-    hipMalloc(&dd, n * 8); hipMalloc(&df, n * 4); hipMalloc(&di, n * 4); hipMalloc(&bad, 6 * 8);
+    hipMalloc(&dd, n * 8); hipMalloc(&df, n * 4); hipMalloc(&di, n * 4); hipMalloc(&bad, 7 * 8);
     hipMemcpy(dd, d.data(), n * 8, hipMemcpyHostToDevice);
     hipMemcpy(df, f.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(di, ii.data(), n * 4, hipMemcpyHostToDevice);
-    hipMemset(bad, 0, 6 * 8);
+    hipMemset(bad, 0, 7 * 8);
     hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dd, df, di, bad);
-    unsigned long long h[6];
-    hipMemcpy(h, bad, 6 * 8, hipMemcpyDeviceToHost);
-    printf("lanes that differ: sum f64 %llu, sum f32 %llu, min %llu, max %llu, max int %llu, lane_xor %llu (of %d)\n", h[0], h[1], h[2], h[3], h[4], h[5], n);
-    return (h[0] | h[1] | h[2] | h[3] | h[4] | h[5]) ? 1 : 0;
+    unsigned long long h[7];
+    hipMemcpy(h, bad, 7 * 8, hipMemcpyDeviceToHost);
+    printf("lanes that differ: sum f64 %llu, sum f32 %llu, min %llu, max %llu, max int %llu, lane_xor %llu, wave_sum12 %llu (of %d)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], n);
+    return (h[0] | h[1] | h[2] | h[3] | h[4] | h[5] | h[6]) ? 1 : 0;
 }
