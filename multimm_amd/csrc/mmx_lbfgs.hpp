@@ -166,6 +166,14 @@ __device__ __forceinline__ bool rows_poll(const double *__restrict__ rows, int n
 // kerr: a force kernel of this evaluation reported that it could not do its work (MinState::kernel_error; multi-GPU: of
 // any rank, through the all-reduce): the sums are partial, nothing may be decided on them.
 __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums, const bool kerr) {
+    // Everything the decision reads from *st, loaded up front in ONE round trip: the branches below depend on loaded values, and a
+    // load behind each branch is a dependent L2 round trip of its own (four of them: 1.8 us of single-thread time in k_tail's
+    // folding workgroup, profiles/r05/tail_stages.txt).  Nobody else writes these fields while this thread runs.
+    const int phase = st->phase;
+    const int evals0 = st->evals, ls_count0 = st->ls_count, nan_seen0 = st->nan_seen, iters0 = st->iters, k0 = st->k,
+              max_iters = st->max_iters;
+    const double finit = st->finit, step0 = st->step, dginit0 = st->dginit, epsilon0 = st->epsilon, tolerance = st->tolerance,
+                 n_total = st->n_total;
     double f = 0.0;
     for (int t = 0; t < 9; ++t) {
         st->eterms[t] = sums[t];
@@ -173,7 +181,6 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     }
     st->ftrial = f;
     const double dg = sums[P_GD], gg = sums[P_GG], xx = sums[P_XX];
-    const int phase = st->phase;
     if (kerr) {
         st->kernel_error |= 0x100; // (a rank without a failure of its own learns of it here)
         st->accepted = 0;
@@ -189,7 +196,7 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     const double ftol = 1e-4, wolfe = 0.9, min_step = 1e-20, max_step = 1e20;
     const int max_linesearch = 40;
     const bool finite = (f - f == 0.0) && (gg - gg == 0.0);
-    st->evals += 1;
+    st->evals = evals0 + 1;
     st->accepted = 0;
     st->store_hist = 0;
 
@@ -205,13 +212,15 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
         double xn = sqrt(xx);
         // OpenMM LocalEnergyMinimizer: epsilon = tolerance / max(1, sqrt(mean_i |x_i|^2)) of the starting positions
         // (x.x of this very evaluation: no copy of the positions to the host, no all-gather on a decomposed run)
-        double rms = sqrt(xx / st->n_total);
+        double rms = sqrt(xx / n_total);
         if (rms < 1.0) rms = 1.0;
-        st->epsilon = st->tolerance / rms;
+        const double epsilon = tolerance / rms;
+        st->epsilon = epsilon;
         if (xn < 1.0) xn = 1.0;
         st->xnorm = xn;
-        st->gnorm = sqrt(gg);
-        if (st->gnorm / xn <= st->epsilon) {
+        const double gnorm = sqrt(gg);
+        st->gnorm = gnorm;
+        if (gnorm / xn <= epsilon) {
             st->status = 0;
             st->phase = PH_DONE;
             return;
@@ -221,15 +230,17 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     }
 
     // PH_LINESEARCH
-    st->ls_count += 1;
-    if (!finite) st->nan_seen += 1;
+    const int ls_count = ls_count0 + 1;
+    st->ls_count = ls_count;
+    const int nan_seen = nan_seen0 + (finite ? 0 : 1);
+    if (!finite) st->nan_seen = nan_seen;
     double width;
     bool accept = false;
-    if (!finite || f > st->finit + st->step * ftol * st->dginit) {
+    if (!finite || f > finit + step0 * ftol * dginit0) {
         width = 0.5;
-    } else if (dg < wolfe * st->dginit) {
+    } else if (dg < wolfe * dginit0) {
         width = 2.1;
-    } else if (dg > -wolfe * st->dginit) {
+    } else if (dg > -wolfe * dginit0) {
         width = 0.5;
     } else {
         accept = true;
@@ -237,31 +248,32 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     }
     if (!accept) {
         int err = 0;
-        if (st->step < min_step) err = -3;
-        else if (st->step > max_step) err = -4;
-        else if (max_linesearch <= st->ls_count) err = -5;
+        if (step0 < min_step) err = -3;
+        else if (step0 > max_step) err = -4;
+        else if (max_linesearch <= ls_count) err = -5;
         if (err) {
-            st->status = (st->nan_seen > 0 && !finite) ? -6 : err;
+            st->status = (nan_seen > 0 && !finite) ? -6 : err;
             st->phase = PH_DONE; // host restores x = xp (liblbfgs reverts to the previous point)
             return;
         }
-        st->step *= width;
+        st->step = step0 * width;
         return;
     }
     // accepted: one L-BFGS iteration finished
-    st->iters += 1;
+    st->iters = iters0 + 1;
     st->fx = f;
     for (int t = 0; t < 9; ++t) st->eterms_acc[t] = sums[t];
     double xn = sqrt(xx);
     if (xn < 1.0) xn = 1.0;
     st->xnorm = xn;
-    st->gnorm = sqrt(gg);
-    if (st->gnorm / xn <= st->epsilon) {
+    const double gnorm = sqrt(gg);
+    st->gnorm = gnorm;
+    if (gnorm / xn <= epsilon0) {
         st->status = 0;
         st->phase = PH_DONE;
         return;
     }
-    if (st->max_iters != 0 && st->max_iters < st->k + 1) {
+    if (max_iters != 0 && max_iters < k0 + 1) {
         st->status = 1;
         st->phase = PH_DONE;
         return;
