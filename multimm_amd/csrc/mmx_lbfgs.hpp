@@ -120,25 +120,38 @@ __device__ __forceinline__ bool rows_poll(const double *__restrict__ rows, int n
                                           const int spin_limit) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long w0[3][4], w1[3][4];
+    bool have[3][4]; // this lane's partial (j, k) has arrived: later rounds fetch only what is still missing -- the last rounds,
+                     // the ones the decision waits for, are a load or two per lane instead of 24
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            have[j][k] = false;
+            w0[j][k] = w1[j][k] = 0ull;
+        }
     bool arrived = false;
     for (int spins = 0; spins <= spin_limit; ++spins) {
-        bool ok = true;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned long long *p =
                 reinterpret_cast<const unsigned long long *>(rows + (size_t)min(wave + 16 * j, NQ - 1) * kPartStride);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int b = min(lane + 64 * k, nblk - 1);
-                w0[j][k] = __hip_atomic_load(p + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w1[j][k] = __hip_atomic_load(p + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!have[j][k]) {
+                    const int b = min(lane + 64 * k, nblk - 1);
+                    w0[j][k] = __hip_atomic_load(p + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1[j][k] = __hip_atomic_load(p + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
+        bool ok = true;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                ok = ok && (unsigned)(w0[j][k] >> 32) == epoch && (unsigned)(w1[j][k] >> 32) == epoch;
+            for (int k = 0; k < 4; ++k) {
+                have[j][k] = (unsigned)(w0[j][k] >> 32) == epoch && (unsigned)(w1[j][k] >> 32) == epoch;
+                ok = ok && have[j][k];
+            }
         if (__all(ok)) {
             arrived = true;
             break;
