@@ -782,10 +782,14 @@ __device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const
     __syncthreads();
 }
 
-// Sort of <= 512 keys by COUNTING (whole workgroup of 256 threads): a key's place in the sorted cell is the number of keys below it
-// -- keys are unique: the bead id is part of them --, counted against broadcast reads of the keys in LDS; no exchange network, two
-// barriers.  The bitonic network above takes 45 dependent stages for 257..512 keys (9.7 us measured, profiles/r05/build_stages.txt:
-// the ~300 large cells of a collapsing gw_200k ended the build's launch 5 us after everything else); this takes ~2.
+// Sort of <= 512 keys by COUNTING (whole workgroup of 256 threads): a key's place in the sorted cell is the number of keys below it,
+// counted against broadcast reads of the keys in LDS; no exchange network, two barriers.  The bitonic network above takes 45
+// dependent stages for 257..512 keys (9.7 us measured, profiles/r05/build_stages.txt: the ~300 large cells of a collapsing gw_200k
+// ended the build's launch 5 us after everything else); this takes ~2.
+// Keys of a valid evaluation are unique (the bead id is part of them).  A VOID one may hold the same key twice -- a send list that
+// outgrew its message keeps stale ids behind its last entry, and the ghost arrives twice: equal keys are therefore ranked by their
+// place in the input, so that every key gets a place of its own and every place a key (a collision would leave a place unwritten,
+// i.e. an arbitrary bead id in the cluster list of an evaluation that is merely to be repeated).
 // s_in: LDS [512] KeyT (input copy); s_out: LDS [512] sorted keys, widened to 64 bits (what emit_clusters reads).  Same order as
 // the network: ascending keys.
 template <class KeyT>
@@ -808,8 +812,8 @@ __device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *
             for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                r0 += k[u] < a0 ? 1 : 0;
-                r1 += k[u] < a1 ? 1 : 0;
+                r0 += (k[u] < a0 || (k[u] == a0 && q + u < t)) ? 1 : 0;
+                r1 += (k[u] < a1 || (k[u] == a1 && q + u < t + 256)) ? 1 : 0;
             }
         }
     } else {
@@ -818,7 +822,7 @@ __device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *
 #pragma unroll
             for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r0 += k[u] < a0 ? 1 : 0;
+            for (int u = 0; u < 4; ++u) r0 += (k[u] < a0 || (k[u] == a0 && q + u < t)) ? 1 : 0;
         }
     }
     if (one) s_out[r0] = widen_key(a0);

@@ -142,6 +142,29 @@ def test_decomposed_halt_reasons_on_two_loopback_ranks():
     assert tight[0][2] >= 1
 
 
+def test_a_send_list_that_outgrows_its_message_under_the_direct_build():
+    """Decomposed ranks at a size where the one-launch build runs (20 000 beads per rank), collapsing from the lattice (cells of
+    more than 256 beads: the workgroup-wide sort by counting), messages without slack (inject_fault bit 2): a list that outgrows its
+    message keeps stale ids behind its last entry, the peer receives some ghosts TWICE -- equal keys in a cell.  The evaluation is
+    void (flag through the all-reduce) and must be repeated, not end the call: equal keys may not cost the sort a place
+    (block_rank_sort ranks them by their place in the input).  Round 5 regression: the RCCL twin of this failed once with
+    KERR_BOUNDS before that."""
+    from test_gpu_dd import run_ranks
+    s = synthetic_system("gw_200k", n_beads=60000, jitter=0.02, seed=7)
+
+    def job(e):
+        e.minimize(tolerance=0.0, max_iters=15)   # (sizes the slot table: the direct build runs from the second call on)
+        st = e.minimize(tolerance=0.0, max_iters=60)
+        return st.iterations, st.status, st.e_final, e.get_option("dd_halts"), e.get_option("direct_builds"), e.get_positions()
+
+    ref = run_ranks(s, 3, job, nb_variant=4096)
+    tight = run_ranks(s, 3, job, nb_variant=4096, inject_fault=4)
+    for a, b in zip(ref, tight):
+        assert a[:2] == b[:2] and b[4] > 0
+        assert b[3] >= 1                                        # lists did outgrow their messages
+    assert all(np.array_equal(t[5], tight[0][5]) for t in tight)   # ranks agree bit for bit
+
+
 def test_a_fold_that_never_gets_its_partials_is_an_error_code():
     """k_tail's folding workgroup polls the other workgroups' tagged partial sums with a bounded spin (inject_fault bit 5: it
     gives up at once): the evaluation is void, the call ends in MMX_ERR_STATE, the handle works again afterwards."""
