@@ -421,11 +421,15 @@ __global__ __launch_bounds__(256, 6) void k_build_direct(const DirectArgs D, Min
 #endif
         if (cnt <= 512) { // (nearly all of them) by counting: block_rank_sort
             static_assert(CAP >= 1024, "input copy in the first 512 entries of s_buf, sorted keys in the next 512");
-            block_rank_sort<KeyT>(reinterpret_cast<KeyT *>(s_buf), s_buf + 512, kp, cnt);
+            const unsigned long long *sorted = s_buf + 512;
+            if (!block_rank_sort<KeyT>(reinterpret_cast<KeyT *>(s_buf), s_buf + 512, kp, cnt)) { // equal keys (a void evaluation's)
+                block_sort_regs<2>(s_buf, kp, cnt, 512);
+                sorted = s_buf;
+            }
 #ifdef MMX_STAGE_TIMING
             if (bid == 0 && bi == bid && threadIdx.x == 0) g_stage_t[4217] = wall_clock64(); // sorted
 #endif
-            emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own, s_buf + 512, D.sbead,
+            emit_clusters(c, 0, cnt, cnt, cb, -1, nullptr, D.pos4, D.spos4, D.cl_lo, nullptr, threadIdx.x, 256, own, sorted, D.sbead,
                           D.slot_of, cap_slots, st, D.n_beads);
 #ifdef MMX_STAGE_TIMING
             if (bid == 0 && bi == bid && threadIdx.x == 0) g_stage_t[4218] = wall_clock64(); // emitted
@@ -830,8 +834,11 @@ __global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, con
         const unsigned long long *sorted = s_buf;
         if (cnt <= 512) { // by counting (block_rank_sort): input copy in s_buf[0 .. 512), sorted keys behind it
             static_assert(CAP >= 1024, "two regions of 512 keys");
-            block_rank_sort<unsigned long long>(s_buf, s_buf + 512, kp, cnt);
             sorted = s_buf + 512;
+            if (!block_rank_sort<unsigned long long>(s_buf, s_buf + 512, kp, cnt)) { // equal keys (a void evaluation's: a ghost that arrived twice)
+                block_sort_regs<2>(s_buf, kp, cnt, 512);
+                sorted = s_buf;
+            }
         } else if (cnt <= 1024) {
             block_sort_regs<4>(s_buf, kp, cnt, 1024);
         } else {

@@ -783,17 +783,18 @@ __device__ __forceinline__ void block_sort_regs(unsigned long long *s_buf, const
 }
 
 // Sort of <= 512 keys by COUNTING (whole workgroup of 256 threads): a key's place in the sorted cell is the number of keys below it,
-// counted against broadcast reads of the keys in LDS; no exchange network, two barriers.  The bitonic network above takes 45
-// dependent stages for 257..512 keys (9.7 us measured, profiles/r05/build_stages.txt: the ~300 large cells of a collapsing gw_200k
-// ended the build's launch 5 us after everything else); this takes ~2.
+// counted against broadcast reads of the keys in LDS; no exchange network.  The bitonic network above takes 45 dependent stages
+// for 257..512 keys (9.7 us measured, profiles/r05/build_stages.txt: the ~300 large cells of a collapsing gw_200k ended the
+// build's launch 5 us after everything else); this takes ~2.
 // Keys of a valid evaluation are unique (the bead id is part of them).  A VOID one may hold the same key twice -- a send list that
-// outgrew its message keeps stale ids behind its last entry, and the ghost arrives twice: equal keys are therefore ranked by their
-// place in the input, so that every key gets a place of its own and every place a key (a collision would leave a place unwritten,
-// i.e. an arbitrary bead id in the cluster list of an evaluation that is merely to be repeated).
+// outgrew its message keeps stale ids behind its last entry, and the ghost arrives twice: equal keys get the same place and leave
+// the next one unwritten, i.e. an arbitrary bead id in the cluster list of an evaluation that is merely to be repeated.  The places
+// are therefore pre-filled with a value no key has and checked afterwards: false (block-uniform) = some place stayed empty, the
+// caller sorts the cell with the network instead (tests/test_gpu_faults.py: ..._outgrows_its_message_under_the_direct_build).
 // s_in: LDS [512] KeyT (input copy); s_out: LDS [512] sorted keys, widened to 64 bits (what emit_clusters reads).  Same order as
 // the network: ascending keys.
 template <class KeyT>
-__device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *s_out, const KeyT *__restrict__ src, const int cnt) {
+__device__ __forceinline__ bool block_rank_sort(KeyT *s_in, unsigned long long *s_out, const KeyT *__restrict__ src, const int cnt) {
     const int t = threadIdx.x;
     const bool one = t < cnt, two = t + 256 < cnt;
     KeyT a0 = (KeyT)~0ull, a1 = (KeyT)~0ull; // (padding: never below a real key)
@@ -801,6 +802,8 @@ __device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *
     if (two) a1 = src[t + 256];
     s_in[t] = a0;
     s_in[t + 256] = a1;
+    s_out[t] = ~0ull;
+    s_out[t + 256] = ~0ull;
     __syncthreads();
     const bool wave_two = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)) + 256 < cnt; // any lane of this wave holds a second key
     const int cnt4 = (cnt + 3) & ~3;
@@ -812,8 +815,8 @@ __device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *
             for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                r0 += (k[u] < a0 || (k[u] == a0 && q + u < t)) ? 1 : 0;
-                r1 += (k[u] < a1 || (k[u] == a1 && q + u < t + 256)) ? 1 : 0;
+                r0 += k[u] < a0 ? 1 : 0;
+                r1 += k[u] < a1 ? 1 : 0;
             }
         }
     } else {
@@ -822,12 +825,14 @@ __device__ __forceinline__ void block_rank_sort(KeyT *s_in, unsigned long long *
 #pragma unroll
             for (int u = 0; u < 4; ++u) k[u] = s_in[q + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r0 += (k[u] < a0 || (k[u] == a0 && q + u < t)) ? 1 : 0;
+            for (int u = 0; u < 4; ++u) r0 += k[u] < a0 ? 1 : 0;
         }
     }
     if (one) s_out[r0] = widen_key(a0);
     if (two) s_out[r1] = widen_key(a1);
     __syncthreads();
+    const bool hole = (one && s_out[t] == ~0ull) || (two && s_out[t + 256] == ~0ull);
+    return __syncthreads_or(hole ? 1 : 0) == 0;
 }
 
 // `bid` of `nblk` workgroups (k_cell_order: blockIdx / gridDim; k_order_items: the launch's first nblk workgroups)
