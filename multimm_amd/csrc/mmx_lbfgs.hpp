@@ -741,7 +741,13 @@ __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict_
         nmine = shared_src[ic]; // (group 3 with UNSORT: taken again below, after the merge)
         nD = d[ic];
     };
-    if (ntile > 0) prefetch(0);
+    // (the first tile's loads go out BEHIND the merge's gathers: loads return in order, and the gathers -- the second link of the
+    //  merge's chain bead -> slot -> force -- would otherwise wait for six streaming loads that nobody needs before the history pass)
+    bool fetched = false;
+    if (!UNSORT && ntile > 0) {
+        prefetch(0);
+        fetched = true;
+    }
     if (UNSORT) {
         // ---- the pair forces leave their cluster slots.  All the tiles of the workgroup at once: group q merges tiles q, q + 4, ...
         for (int t = cg; t < ntile; t += 4) {
@@ -763,6 +769,10 @@ __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict_
                         *p = 0.f;
                     }
                 }
+                if (!fetched) {
+                    prefetch(0);
+                    fetched = true;
+                }
                 G.x -= f[0];
                 G.y -= f[1];
                 G.z -= f[2];
@@ -771,6 +781,7 @@ __global__ __launch_bounds__(1024) void k_tail(int n4, const float4 *__restrict_
                 if (t < kTailKeep) s_g[t][tv] = G;
             }
         }
+        if (!fetched && ntile > 0) prefetch(0); // (a thread that merged nothing)
         if (ntile > kTailKeep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tiles beyond kTailKeep are read back from g by another wave
         __syncthreads();
     }
