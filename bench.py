@@ -629,7 +629,7 @@ def main():
             "status": st.status, "e_initial": st.e_initial, "e_final": st.e_final, "rms_force": st.rms_force,
             "kernel_us_mean": kern,
             "bonded_kernels": ("separate" if args.separate_bonded else "one pass, confine slot" if not in_scan
-                               else "one pass inside the cell-scan launch (cell_build slot)"),
+                               else "one pass inside the cell build's launch (k_build_direct; cell_build slot)"),
             "kernel_algorithmic_GBps": kernel_gbs,
             "roofline": roofline,
         }
