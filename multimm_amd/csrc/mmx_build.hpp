@@ -623,7 +623,7 @@ __device__ __forceinline__ void direct_emit_wave_dd(const DirectArgs &D, const D
 // of > kWaveCellMax beads altogether (0), owned beads (1), ghosts (2).  The result is the same list bit for bit: owned beads
 // sort before ghosts in a cell's keys, and the two kinds never share a cluster.
 template <int CAP, bool N3, int PHASE = 0>
-__global__ __launch_bounds__(256) void k_build_direct_dd(const DirectArgs D, const DirectDD X, MinState *__restrict__ st,
+__global__ __launch_bounds__(256, 5) void k_build_direct_dd(const DirectArgs D, const DirectDD X, MinState *__restrict__ st,
                                                           const FFParams P, const BondedArgs B) {
     if (st->phase >= PH_DONE) return;
     static_assert(PHASE == 0 || N3, "the two-launch build needs the split layout of the half-shell kernel");
