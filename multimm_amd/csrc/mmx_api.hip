@@ -114,7 +114,6 @@ static int create_impl(int32_t n_beads, int32_t rank, int32_t world, int32_t dev
             HIPCHK(h, dalloc(&h->fsort, (size_t)3 * h->fstride));
             HIPCHK(h, dalloc(&h->sbead, (size_t)h->fstride));
             HIPCHK(h, dalloc(&h->slot_of, (size_t)std::max(world > 1 ? h->slice : h->n_own, 1)));
-            HIPCHK(h, dalloc(&h->sync, (size_t)1));
             // direct build: two sets (build parity) of cell populations and row totals; decomposed ranks: + the ghosts' populations and
             // the rows' ghost-cluster totals
             HIPCHK(h, dalloc(&h->dcount, (size_t)2 * ((size_t)h->maxcells + 1)));
@@ -264,7 +263,7 @@ int mmx_destroy(mmx_handle h) try {
                     (void *)h->lbox[1], (void *)h->okeys, (void *)h->lstart, (void *)h->biglist, (void *)h->fsort, (void *)h->n3_items, (void *)h->dd_boxes,
                     (void *)h->dd_static, (void *)h->dd_send_ids, (void *)h->dd_send_cnt, (void *)h->dd_cntmat,
                     (void *)h->dd_ghost_ids, (void *)h->dd_sendbuf, (void *)h->dd_recvbuf, (void *)h->dd_xref,
-                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->sync, (void *)h->dcount, (void *)h->drows, (void *)h->dcount_g,
+                    (void *)h->dd_grid, (void *)h->dd_occ, (void *)h->dd_maps, (void *)h->count_own, (void *)h->sbead, (void *)h->slot_of, (void *)h->dcount, (void *)h->drows, (void *)h->dcount_g,
                     (void *)h->d_seg_own, (void *)h->d_seg_local, (void *)h->mig, (void *)h->seg_cent, (void *)h->d_mig_src,
                     (void *)h->md_snap, (void *)h->cell_xref, (void *)h->slotkeys})
         if (p) (void)hipFree(p);

@@ -179,20 +179,6 @@ struct MinState {
 static_assert(offsetof(MinState, dd_move) == offsetof(MinState, rowsum) + MMX_NROWSUM * sizeof(double), "dd_move rides behind rowsum in the all-reduce");
 static_assert(offsetof(MinState, rowsum) == offsetof(MinState, sums) + 16 * sizeof(double), "sums and rowsum are reduced as one array");
 
-// Counters of the launch whose workgroups depend on each other (device; zero between launches -- the last workgroup of a
-// launch puts them back).  k_build (mmx_build.hpp): the stages of the cell build -- count, scan, fill, order / work items -- are roles of ONE launch; a role takes
-// a ticket, and only ever waits for roles with lower tickets, which are therefore resident or done.
-struct LaunchSync {
-    unsigned build_ticket; // k_build: next logical workgroup id
-    unsigned build_exits;  // ... workgroups that have left
-    int grid_done;         // ... the grid of this build is in place (decomposed ranks: k_grid_init's work)
-    int count_done;        // ... workgroups of the count stage that have finished
-    int scan_done;         // ... offsets, cluster counts, big-cell list, next grid are in place
-    int fill_done;         // ... workgroups of the fill stage that have finished
-    int pad[2];
-};
-
-namespace stage_timing_ {}
 #ifdef MMX_STAGE_TIMING
 // timing build (10 ns ticks): [workgroup * 4 + {0 start, 1 merge done, 2 loop done, 3 published}] of k_tail, [4096 ..] its folding
 // workgroup; [4200 ..] k_build_direct: +0..3 workgroup 0 (start, grid, prefix, done), +4..7 the first order workgroup that takes

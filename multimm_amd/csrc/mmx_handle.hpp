@@ -236,7 +236,6 @@ struct mmx_handle_s {
     bool fsort_dirty = false;                    // a minimization ended abnormally: k_tail only clears the slots of beads the build
                                                  // binned, so fsort is cleared wholesale before the next call (prepare)
     int *slot_of = nullptr;                      // [owned beads, local order] cluster slot of the bead (emit_clusters): what k_tail gathers by
-    LaunchSync *sync = nullptr;                  // tickets / stage flags of the launches whose workgroups depend on each other
     unsigned tail_epoch = 0u;                    // tag of the last k_tail launch's partials (TailArgs::epoch)
     int fused_tail = 1;                          // option: unsort + history + decision in one launch (k_tail); 0: the separate kernels (A/B)
     int *dcount = nullptr;                       // direct build: two sets of cell populations [2][maxcells + 1] ...
