@@ -178,15 +178,39 @@ __device__ __forceinline__ bool rows_poll(const double *__restrict__ rows, int n
 // LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE.  Every rank executes it on identical inputs.
 // kerr: a force kernel of this evaluation reported that it could not do its work (MinState::kernel_error; multi-GPU: of
 // any rank, through the all-reduce): the sums are partial, nothing may be decided on them.
-__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums, const bool kerr) {
-    // Everything the decision reads from *st, loaded up front in ONE round trip: the branches below depend on loaded values, and a
-    // load behind each branch is a dependent L2 round trip of its own (four of them: 1.8 us of single-thread time in k_tail's
-    // folding workgroup, profiles/r05/tail_stages.txt).  Nobody else writes these fields while this thread runs.
-    const int phase = st->phase;
-    const int evals0 = st->evals, ls_count0 = st->ls_count, nan_seen0 = st->nan_seen, iters0 = st->iters, k0 = st->k,
-              max_iters = st->max_iters;
-    const double finit = st->finit, step0 = st->step, dginit0 = st->dginit, epsilon0 = st->epsilon, tolerance = st->tolerance,
-                 n_total = st->n_total;
+// Everything the decision reads from *st.  The branches of controller_decide depend on loaded values, and a load behind each branch
+// is a dependent L2 round trip of its own (four of them: 1.8 us of single-thread time); loaded up front they are ONE -- and
+// k_tail's folding workgroup takes that one BEFORE it starts to poll for the other workgroups' partials (decide_block), so that
+// nothing but arithmetic stands between the last partial and the decision.  Nobody else writes these fields in between: the
+// kernels of the evaluation are done when the tail starts, the next evaluation's wait for it.
+struct DecideIn {
+    int phase, evals, ls_count, nan_seen, iters, k, max_iters, kernel_error, cell_stale;
+    double finit, step, dginit, epsilon, tolerance, n_total;
+};
+__device__ __forceinline__ DecideIn decide_in(const MinState *__restrict__ st) {
+    DecideIn in;
+    in.phase = st->phase;
+    in.evals = st->evals;
+    in.ls_count = st->ls_count;
+    in.nan_seen = st->nan_seen;
+    in.iters = st->iters;
+    in.k = st->k;
+    in.max_iters = st->max_iters;
+    in.kernel_error = st->kernel_error;
+    in.cell_stale = st->cell_stale;
+    in.finit = st->finit;
+    in.step = st->step;
+    in.dginit = st->dginit;
+    in.epsilon = st->epsilon;
+    in.tolerance = st->tolerance;
+    in.n_total = st->n_total;
+    return in;
+}
+__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums, const bool kerr, const DecideIn &in) {
+    const int phase = in.phase;
+    const int evals0 = in.evals, ls_count0 = in.ls_count, nan_seen0 = in.nan_seen, iters0 = in.iters, k0 = in.k, max_iters = in.max_iters;
+    const double finit = in.finit, step0 = in.step, dginit0 = in.dginit, epsilon0 = in.epsilon, tolerance = in.tolerance,
+                 n_total = in.n_total;
     double f = 0.0;
     for (int t = 0; t < 9; ++t) {
         st->eterms[t] = sums[t];
@@ -295,6 +319,11 @@ __device__ __forceinline__ void controller_decide(MinState *__restrict__ st, con
     st->store_hist = 1;
 }
 
+
+__device__ __forceinline__ void controller_decide(MinState *__restrict__ st, const double *sums, const bool kerr) {
+    const DecideIn in = decide_in(st);
+    controller_decide(st, sums, kerr, in);
+}
 
 // Runs right after every evaluation of the minimizer, BEFORE the line-search decision (so that decision and
 // direction coefficients are one launch, k_decide): s = x - xp, y = g - gp into slot `end` -- the slot the step
@@ -517,8 +546,14 @@ __device__ __forceinline__ void decide_block(const CtlArgs &A, const double *__r
     __shared__ double s_G[MMX_NBASIS * MMX_NBASIS];
     __shared__ int s_n[P_NSLOTS], s_first[P_NSLOTS + 1];
     __shared__ int s_accepted;
+    __shared__ int s_wait_failed;
+    __shared__ DecideIn s_din;
     __shared__ double s_ys[MMX_M];
     double acc[3];
+    if (threadIdx.x == 0) {
+        s_din = decide_in(st); // (before the poll: see DecideIn)
+        s_wait_failed = 0;
+    }
     if (!POLL) rows_load<MMX_NROWSUM>(rows, nblk_rows, acc); // nblk_rows <= 256 (enqueue_history)
     // the Gram matrix rides in the same latency round as the partials
     const double gval = threadIdx.x < MMX_NBASIS * MMX_NBASIS ? st->gram[threadIdx.x] : 0.0;
@@ -528,17 +563,22 @@ __device__ __forceinline__ void decide_block(const CtlArgs &A, const double *__r
     if (threadIdx.x < MMX_NBASIS * MMX_NBASIS) s_G[threadIdx.x] = gval;
     if (threadIdx.x < MMX_M) s_ys[threadIdx.x] = yval;
     // (k_tail: what the other workgroups of this very launch publish is waited for last -- everything above came from earlier launches)
-    if (POLL && !rows_poll<MMX_NROWSUM>(rows, nblk_rows, epoch, acc, spin_limit) && (threadIdx.x & 63) == 0)
+    // (s_din / s_wait_failed were written before the barriers of multi_slot_sum)
+    if (POLL && !rows_poll<MMX_NROWSUM>(rows, nblk_rows, epoch, acc, spin_limit) && (threadIdx.x & 63) == 0) {
         atomicOr(&st->kernel_error, (int)KERR_TAIL_WAIT);
+        s_wait_failed = 1;
+    }
     STAGE_STAMP(4098);
     rows_finish<MMX_NROWSUM>(acc, s_rows); // ends with a barrier: s_G is complete too
     STAGE_STAMP(4099);
     if (threadIdx.x == 0) {
-        if (st->cell_stale && !st->kernel_error) {
+        const DecideIn in = s_din;
+        const bool kerr = in.kernel_error != 0 || s_wait_failed != 0;
+        if (in.cell_stale && !kerr) {
             // the kept cell structure was out of date for this evaluation (k_pack): it never happened.  Nothing is decided;
             // every kernel of the evaluations already in the stream returns at once, the host builds anew and repeats it.
-            st->halt_phase = st->phase;
-            st->halt_reason = ((st->cell_stale & 1) ? 4 : 0) | ((st->cell_stale & 2) ? 8 : 0) | ((st->cell_stale & 4) ? 16 : 0); // stale structure / slot table too small / grid beyond the direct build
+            st->halt_phase = in.phase;
+            st->halt_reason = ((in.cell_stale & 1) ? 4 : 0) | ((in.cell_stale & 2) ? 8 : 0) | ((in.cell_stale & 4) ? 16 : 0); // stale structure / slot table too small / grid beyond the direct build
             st->phase = PH_HALT;
             st->accepted = 0; // the direction of this trial is already formed (k_pack): the repeat must not form it again
             s_accepted = 0;
@@ -547,7 +587,7 @@ __device__ __forceinline__ void decide_block(const CtlArgs &A, const double *__r
 #pragma unroll
             for (int s = 0; s < P_NSLOTS; ++s) sums[s] = s_out[s];
             dots_from_rows(sums, s_rows);
-            controller_decide(st, sums, st->kernel_error != 0);
+            controller_decide(st, sums, kerr, in);
             STAGE_STAMP(4100);
             s_accepted = st->accepted;
             if (s_accepted) coef_decide(st, s_rows, s_G, s_ys);
